@@ -1,0 +1,54 @@
+"""Shared test helpers: golden-vector loading and the seeded model specs they were made from."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from iffnerf_amd import synthetic
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# must equal TINY / SMALL in tests/golden/make_golden.py (checked through ckpt_digest)
+TINY = dict(grid=(12, 14, 16), aabb=((-1.0, -1.2, -0.9), (1.1, 1.0, 1.3)), mask_res=(9, 11, 10), seed=11,
+            step_ratio=0.5, peak=20.0)
+SMALL = dict(grid=(48, 40, 44), aabb=((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5)), mask_res=(30, 28, 26), seed=21,
+             step_ratio=0.5, peak=20.0)
+
+
+def digest(sd) -> str:
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(torch.as_tensor(sd[k]).numpy()).tobytes())
+    return h.hexdigest()
+
+
+class Golden:
+    def __init__(self):
+        self._cache = {}
+
+    def __getitem__(self, name):
+        if name not in self._cache:
+            z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+            self._cache[name] = {k: z[k] for k in z.files}
+        return self._cache[name]
+
+    def t(self, name, key):
+        return torch.from_numpy(np.asarray(self[name][key]))
+
+
+_CKPTS = {}
+
+
+def ckpt(which: str, **over):
+    key = (which, tuple(sorted(over.items())))
+    if key not in _CKPTS:
+        spec = {"tiny": TINY, "small": SMALL}[which]
+        _CKPTS[key] = synthetic.make_field_ckpt(**{**spec, **over})
+    return _CKPTS[key]
+
+
+def check_digest(golden_arr, sd):
+    want = bytes(np.asarray(golden_arr, dtype=np.uint8)).hex()
+    assert digest(sd) == want, "seeded synthetic weights drifted from the ones the golden vectors were made with"
