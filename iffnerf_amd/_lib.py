@@ -1,0 +1,122 @@
+"""ctypes binding of libiffnerf_hip.so (include/iffnerf_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  ``lib()`` raises RuntimeError when the
+shared object is missing (build it with ``python -m iffnerf_amd.build``), and every wrapper raises
+RuntimeError -- the one exception type the reference driver survives (train_eval_pose_est.py:259-260) -- when a
+call returns non-zero or is handed a tensor that is not resident on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
+_lib = None
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [
+        ("grid", C.c_int32 * 3), ("aabb", C.c_float * 6),
+        ("n_density", C.c_int32), ("n_app", C.c_int32), ("app_dim", C.c_int32), ("feature_c", C.c_int32),
+        ("density_plane", C.c_void_p * 3), ("density_line", C.c_void_p * 3),
+        ("app_plane", C.c_void_p * 3), ("app_line", C.c_void_p * 3),
+        ("basis", C.c_void_p), ("mask_volume", C.c_void_p), ("mask_dims", C.c_int32 * 3), ("mask_aabb", C.c_float * 6),
+        ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
+        ("step_size", C.c_float), ("n_samples", C.c_int32), ("near_far", C.c_float * 2),
+        ("softplus", C.c_int32), ("unisphere", C.c_int32),
+        ("normal_w", C.c_void_p), ("normal_b", C.c_void_p), ("tint_w", C.c_void_p), ("tint_b", C.c_void_p),
+        ("rough_w", C.c_void_p), ("rough_b", C.c_void_p), ("diffuse_w", C.c_void_p), ("diffuse_b", C.c_void_p),
+        ("bottleneck_w", C.c_void_p), ("bottleneck_b", C.c_void_p), ("specular_w", C.c_void_p), ("specular_b", C.c_void_p),
+        ("ide_mat", C.c_void_p),
+    ]
+
+
+class IdNetDesc(C.Structure):
+    _fields_ = [("feature_c", C.c_int32), ("fea", C.c_int32), ("img_fea", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("l1_w", "l1_b", "l2_w", "l2_b", "l3_w", "l3_b", "l4_w", "l4_b", "q_w", "q_b", "k_w", "k_b")]
+
+
+# name -> (restype, argtypes); must list every function include/iffnerf_hip.h declares (tests/test_abi.py checks)
+_VP, _I32, _I64, _F, _SZ, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+SIGNATURES = {
+    "iff_last_error": (C.c_char_p, []),
+    "iff_abi_version": (C.c_int, []),
+    "iff_field_create": (C.c_int, [C.POINTER(FieldDesc), _VP, C.POINTER(_VP)]),
+    "iff_field_destroy": (None, [_VP]),
+    "iff_field_table_bytes": (_SZ, [_VP]),
+    "iff_normalize_coord": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_mask_sample": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_density_feature": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_app_feature": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_point_alpha": (C.c_int, [_VP, _VP, _I64, _F, _VP, _VP]),
+    "iff_point_normals": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_ref_shade": (C.c_int, [_VP, _VP, _VP, _I64, _VP, _VP]),
+    "iff_ref_normals": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_isocell_emit": (C.c_int, [c_float_p, _VP, _VP, _I64, _VP, _VP, _VP]),
+    "iff_march_shade": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, c_float_p, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "iff_surface_sample_workspace": (_SZ, [_I64]),
+    "iff_surface_sample": (C.c_int, [_VP, _I64, _I32, _I32, _U64, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "iff_idnet_create": (C.c_int, [C.POINTER(IdNetDesc), _VP, C.POINTER(_VP)]),
+    "iff_idnet_destroy": (None, [_VP]),
+    "iff_ray_encode_workspace": (_SZ, [_VP, _I64]),
+    "iff_ray_encode": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ, _VP]),
+    "iff_q_proj_workspace": (_SZ, [_VP, _I32]),
+    "iff_q_proj": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _SZ, _VP]),
+    "iff_attn_logits": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _F, _VP, _VP, _VP, _VP]),
+    "iff_attn_colsum": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
+    "iff_topk_workspace": (_SZ, [_I64, _I32]),
+    "iff_topk": (C.c_int, [_VP, _I64, _I32, _VP, _VP, _VP, _SZ, _VP]),
+    "iff_pose_from_topk": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _I64, c_float_p, _VP, _VP, _VP]),
+}
+
+
+def lib():
+    """Load (once) and return the C-ABI library; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
+                "Build it with `python -m iffnerf_amd.build` (hipcc, gfx950).")
+        import torch  # noqa: F401  (loads torch's HIP runtime first so both share one libamdhip64)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().iff_last_error().decode(errors="replace")
+        raise RuntimeError(f"libiffnerf_hip {what} failed ({rc}): {msg}")
+
+
+def dptr(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -> Optional[int]:
+    """Device pointer of a contiguous tensor on the GPU, or None for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got device {t.device}); libiffnerf_hip has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def fvec(values) -> "C.Array":
+    vals = [float(v) for v in values]
+    return (C.c_float * len(vals))(*vals)

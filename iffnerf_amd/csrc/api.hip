@@ -1,0 +1,391 @@
+// api.hip -- the extern "C" surface of libiffnerf_hip.so (include/iffnerf_hip.h): argument checking, handle ownership,
+// error reporting.  No torch types; plain pointers and sizes.
+#include "../../include/iffnerf_hip.h"
+#include "iff_device.h"
+#include "iff_launch.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int hip_fail(hipError_t e, const char* what) {
+    return fail((int)e, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+}
+#define IFF_HIP(call)                                     \
+    do {                                                  \
+        hipError_t e__ = (call);                          \
+        if (e__ != hipSuccess) return hip_fail(e__, #call); \
+    } while (0)
+#define IFF_REQUIRE(cond, ...)                            \
+    do {                                                  \
+        if (!(cond)) return fail(IFF_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+    } while (0)
+
+extern "C" const char* iff_last_error(void) { return g_err; }
+extern "C" int iff_abi_version(void) { return IFF_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------ field handle
+struct iff_field {
+    FieldDev dev;
+    void* slab = nullptr;        // every table lives in one allocation
+    size_t slab_bytes = 0;
+    int* occ_list = nullptr;     // occupied mask voxels (ascending), for the surface sampler
+    int n_occ = 0;
+    int n_cus = 256;
+};
+
+extern "C" void iff_field_destroy(iff_field* f) {
+    if (!f) return;
+    if (f->slab) (void)hipFree(f->slab);
+    if (f->occ_list) (void)hipFree(f->occ_list);
+    delete f;
+}
+
+extern "C" size_t iff_field_table_bytes(const iff_field* f) { return f ? f->slab_bytes : 0; }
+
+static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field** out) {
+    IFF_REQUIRE(d && out, "iff_field_create: null argument");
+    *out = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < 3; ++i) {
+        IFF_REQUIRE(d->grid[i] >= 2 && d->grid[i] <= 4096, "gridSize[%d] = %d out of range", i, d->grid[i]);
+        IFF_REQUIRE(d->density_plane[i] && d->density_line[i] && d->app_plane[i] && d->app_line[i], "null VM table %d", i);
+    }
+    if (d->n_app != 48 || d->app_dim != 27)
+        return fail(IFF_ERR_UNSUPPORTED, "only appearance_n_comp = 48 and app_dim = 27 are built (got %d, %d)", d->n_app,
+                    d->app_dim);
+    IFF_REQUIRE(d->n_density >= 4 && d->n_density % 4 == 0 && d->n_density <= 64, "density_n_comp = %d unsupported", d->n_density);
+    IFF_REQUIRE(d->feature_c >= 16 && d->feature_c <= 512 && d->feature_c % 16 == 0, "featureC = %d unsupported", d->feature_c);
+    IFF_REQUIRE(d->basis && d->normal_w && d->normal_b && d->tint_w && d->tint_b && d->rough_w && d->rough_b && d->diffuse_w &&
+                    d->diffuse_b && d->bottleneck_w && d->bottleneck_b && d->specular_w && d->specular_b && d->ide_mat,
+                "null Ref-head / basis tensor");
+    if (d->mask_volume)
+        for (int i = 0; i < 3; ++i) IFF_REQUIRE(d->mask_dims[i] >= 1 && d->mask_dims[i] <= 4096, "mask dim %d out of range", i);
+
+    iff_field* f = new iff_field();
+    FieldDev& v = f->dev;
+    memset(&v, 0, sizeof(v));
+    const int G[3] = {d->grid[0], d->grid[1], d->grid[2]};
+    const HeadOff ho = head_offsets(d->app_dim, d->feature_c);
+    // slab layout
+    size_t off = 0, o_dp[3], o_dl[3], o_ap[3], o_al[3];
+    for (int i = 0; i < 3; ++i) {
+        size_t hw = (size_t)G[mat_a(i)] * G[mat_b(i)], l = (size_t)G[vec_ax(i)];
+        o_dp[i] = off; off = up256(off + hw * d->n_density * 4);
+        o_dl[i] = off; off = up256(off + l * d->n_density * 4);
+        o_ap[i] = off; off = up256(off + hw * d->n_app * 4);
+        o_al[i] = off; off = up256(off + l * d->n_app * 4);
+    }
+    size_t o_basis = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
+    size_t o_basis_l = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
+    size_t o_head = off; off = up256(off + (size_t)ho.total * 4);
+    size_t n_mask = d->mask_volume ? (size_t)d->mask_dims[0] * d->mask_dims[1] * d->mask_dims[2] : 0;
+    size_t o_mask = off; off = up256(off + n_mask);
+    f->slab_bytes = off;
+    hipError_t e = hipMalloc(&f->slab, off);
+    if (e != hipSuccess) { delete f; return hip_fail(e, "hipMalloc(field tables)"); }
+    char* base = (char*)f->slab;
+#define IFF_CREATE_HIP(call)                                           \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) { iff_field_destroy(f); return hip_fail(e__, #call); } \
+    } while (0)
+    IFF_CREATE_HIP(hipMemsetAsync(f->slab, 0, off, s));
+    for (int i = 0; i < 3; ++i) {
+        int64_t hw = (int64_t)G[mat_a(i)] * G[mat_b(i)], l = G[vec_ax(i)];
+        IFF_CREATE_HIP(launch_k0_channels_last(d->density_plane[i], (float*)(base + o_dp[i]), d->n_density, hw, s));
+        IFF_CREATE_HIP(launch_k0_channels_last(d->density_line[i], (float*)(base + o_dl[i]), d->n_density, l, s));
+        IFF_CREATE_HIP(launch_k0_channels_last(d->app_plane[i], (float*)(base + o_ap[i]), d->n_app, hw, s));
+        IFF_CREATE_HIP(launch_k0_channels_last(d->app_line[i], (float*)(base + o_al[i]), d->n_app, l, s));
+        v.dplane[i] = (const float*)(base + o_dp[i]); v.dline[i] = (const float*)(base + o_dl[i]);
+        v.aplane[i] = (const float*)(base + o_ap[i]); v.aline[i] = (const float*)(base + o_al[i]);
+    }
+    IFF_CREATE_HIP(hipMemcpyAsync(base + o_basis, d->basis, (size_t)d->app_dim * 3 * d->n_app * 4, hipMemcpyDeviceToDevice, s));
+    IFF_CREATE_HIP(launch_k0_basis_slices(d->basis, (float*)(base + o_basis_l), d->app_dim, d->n_app, s));
+    v.basis = (const float*)(base + o_basis);
+    v.basis_l = (const float*)(base + o_basis_l);
+    {
+        float* h = (float*)(base + o_head);
+        struct { const float* src; int off; int n; } parts[] = {
+            {d->normal_w, ho.normal_w, 3 * d->app_dim}, {d->normal_b, ho.normal_b, 3},
+            {d->tint_w, ho.tint_w, 3 * d->app_dim}, {d->tint_b, ho.tint_b, 3},
+            {d->rough_w, ho.rough_w, d->app_dim}, {d->rough_b, ho.rough_b, 1},
+            {d->diffuse_w, ho.diffuse_w, 3 * d->app_dim}, {d->diffuse_b, ho.diffuse_b, 3},
+            {d->bottleneck_w, ho.bott_w, d->feature_c * d->app_dim}, {d->bottleneck_b, ho.bott_b, d->feature_c},
+            {d->specular_w, ho.spec_w, 3 * (d->feature_c + 39)}, {d->specular_b, ho.spec_b, 3},
+            {d->ide_mat, ho.ide_mat, 9 * 19}};
+        for (auto& p : parts)
+            IFF_CREATE_HIP(hipMemcpyAsync(h + p.off, p.src, (size_t)p.n * 4, hipMemcpyDeviceToDevice, s));
+        v.head = h;
+    }
+    if (d->mask_volume) {
+        IFF_CREATE_HIP(launch_k0_mask_bytes(d->mask_volume, (uint8_t*)(base + o_mask), (int64_t)n_mask, s));
+        v.mask = (const uint8_t*)(base + o_mask);
+        // occupied-voxel list for the sampler's seeds (pose_estimation/sampling.py:82-102), built once on the host
+        std::vector<uint8_t> hm(n_mask);
+        IFF_CREATE_HIP(hipMemcpyAsync(hm.data(), base + o_mask, n_mask, hipMemcpyDeviceToHost, s));
+        IFF_CREATE_HIP(hipStreamSynchronize(s));
+        std::vector<int> occ;
+        occ.reserve(n_mask / 2 + 1);
+        for (size_t i = 0; i < n_mask; ++i) if (hm[i]) occ.push_back((int)i);
+        f->n_occ = (int)occ.size();
+        if (f->n_occ > 0) {
+            IFF_CREATE_HIP(hipMalloc((void**)&f->occ_list, occ.size() * sizeof(int)));
+            IFF_CREATE_HIP(hipMemcpyAsync(f->occ_list, occ.data(), occ.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            IFF_CREATE_HIP(hipStreamSynchronize(s));
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        v.grid[i] = G[i];
+        v.mask_dims[i] = d->mask_volume ? d->mask_dims[i] : 0;
+        v.aabb_lo[i] = d->aabb[i]; v.aabb_hi[i] = d->aabb[3 + i];
+        v.inv_aabb[i] = 2.0f / (v.aabb_hi[i] - v.aabb_lo[i]);                 // tensorBase.py:357-358
+        v.mask_lo[i] = d->mask_aabb[i]; v.mask_hi[i] = d->mask_aabb[3 + i];
+        v.mask_inv[i] = 1.0f / (v.mask_hi[i] - v.mask_lo[i]) * 2.0f;         // tensorBase.py:58-59
+    }
+    v.density_shift = d->density_shift; v.distance_scale = d->distance_scale; v.weight_thres = d->weight_thres;
+    v.step_size = d->step_size; v.near = d->near_far[0]; v.far = d->near_far[1];
+    v.n_samples = d->n_samples; v.softplus = d->softplus; v.unisphere = d->unisphere;
+    v.n_density = d->n_density; v.n_app = d->n_app; v.app_dim = d->app_dim; v.feature_c = d->feature_c;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) f->n_cus = prop.multiProcessorCount;
+    IFF_CREATE_HIP(hipStreamSynchronize(s));   // the source tensors may be released by the caller after return
+    *out = f;
+    return 0;
+}
+
+#define IFF_FIELD_ARGS(f, p, n) IFF_REQUIRE((f) != nullptr && ((n) == 0 || (p) != nullptr) && (n) >= 0, "%s: bad argument", __func__)
+
+extern "C" int iff_normalize_coord(const iff_field* f, const float* xyz, int64_t n, float* out, void* stream) {
+    IFF_FIELD_ARGS(f, xyz, n);
+    if (n == 0) return 0;
+    IFF_HIP(launch_normalize_coord(f->dev, xyz, n, out, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_mask_sample(const iff_field* f, const float* xyz, int64_t n, float* out, void* stream) {
+    IFF_FIELD_ARGS(f, xyz, n);
+    if (n == 0) return 0;
+    IFF_HIP(launch_mask_sample(f->dev, xyz, n, out, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_density_feature(const iff_field* f, const float* xn, int64_t n, float* out, void* stream) {
+    IFF_FIELD_ARGS(f, xn, n);
+    if (n == 0) return 0;
+    IFF_HIP(launch_density_feature(f->dev, xn, n, out, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_app_feature(const iff_field* f, const float* xn, int64_t n, float* out, void* stream) {
+    IFF_FIELD_ARGS(f, xn, n);
+    if (n == 0) return 0;
+    IFF_HIP(launch_app_feature(f->dev, xn, n, out, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_point_alpha(const iff_field* f, const float* xyz, int64_t n, float length, float* alpha, void* stream) {
+    IFF_FIELD_ARGS(f, xyz, n);
+    if (n == 0) return 0;
+    IFF_HIP(launch_point_alpha(f->dev, xyz, n, length, alpha, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_point_normals(const iff_field* f, const float* xyz, int64_t n, float* normals, void* stream) {
+    IFF_FIELD_ARGS(f, xyz, n);
+    if (n == 0) return 0;
+    IFF_HIP(launch_point_normals(f->dev, xyz, n, normals, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_ref_shade(const iff_field* f, const float* viewdirs, const float* features, int64_t n, float* rgb,
+                             void* stream) {
+    IFF_FIELD_ARGS(f, viewdirs, n);
+    if (n == 0) return 0;
+    IFF_REQUIRE(features && rgb, "iff_ref_shade: null buffer");
+    IFF_HIP(launch_ref_shade(f->dev, viewdirs, features, n, rgb, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_ref_normals(const iff_field* f, const float* features, int64_t n, float* normals, void* stream) {
+    IFF_FIELD_ARGS(f, features, n);
+    if (n == 0) return 0;
+    IFF_REQUIRE(normals, "iff_ref_normals: null buffer");
+    IFF_HIP(launch_ref_normals(f->dev, features, n, normals, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_isocell_emit(const float* cells_host, const float* points, const float* normals, int64_t P, float* ori,
+                                float* dirs, void* stream) {
+    IFF_REQUIRE(P >= 0, "iff_isocell_emit: negative P");
+    if (P == 0) return 0;
+    IFF_REQUIRE(cells_host && points && normals && ori && dirs, "iff_isocell_emit: null buffer");
+    IFF_HIP(launch_isocell_emit(cells_host, points, normals, P, ori, dirs, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                               int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc, float* alpha_opt,
+                               int32_t* counts_opt, void* stream) {
+    IFF_REQUIRE(f != nullptr && R >= 0, "iff_march_shade: bad argument");
+    if (R == 0) return 0;
+    IFF_REQUIRE(rays && rgb && depth && acc && bg_host, "iff_march_shade: null buffer");
+    IFF_REQUIRE(ray_cols == 6 || ray_cols == 7, "iff_march_shade: rays must have 6 or 7 columns (got %d)", ray_cols);
+    IFF_REQUIRE(mode == IFF_MARCH_POINT_CENTRED || mode == IFF_MARCH_SLAB, "iff_march_shade: unknown mode %d", mode);
+    int S = n_samples > 0 ? n_samples : (mode == IFF_MARCH_POINT_CENTRED ? 20 : f->dev.n_samples);
+    IFF_REQUIRE(S >= 1 && S <= (1 << 20), "iff_march_shade: n_samples = %d out of range", S);
+    if (mode == IFF_MARCH_SLAB && f->dev.unisphere)
+        return fail(IFF_ERR_UNSUPPORTED, "slab sampler with contraction_type='unisphere' is not built "
+                                         "(the reference's own branch is unfinished: models/tensorBase.py:511-525)");
+    IFF_HIP(launch_march(f->dev, rays, ray_cols, R, mode, S, bg_host, rgb, depth, acc, alpha_opt, counts_opt, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" size_t iff_surface_sample_workspace(int64_t P) { return P > 0 ? sampler_workspace_bytes(P) : 0; }
+
+extern "C" int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t max_iterations, uint64_t seed,
+                                  float rho, float* samples, float* alpha, int32_t* stats, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(f && samples && alpha && stats && workspace, "iff_surface_sample: null argument");
+    IFF_REQUIRE(P >= 1, "iff_surface_sample: P must be >= 1");
+    if (workspace_bytes < sampler_workspace_bytes(P))
+        return fail(IFF_ERR_WORKSPACE, "iff_surface_sample: workspace %zu < %zu bytes", workspace_bytes, sampler_workspace_bytes(P));
+    if (f->dev.mask && f->n_occ == 0) return fail(IFF_ERR_INVALID_ARGUMENT, "iff_surface_sample: the occupancy mask is empty");
+    IFF_HIP(launch_surface_sample_occ(f->dev, f->occ_list, f->n_occ, P, n_epochs, max_iterations, seed, rho, samples, alpha,
+                                      stats, workspace, workspace_bytes, f->n_cus, (hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ identification net
+struct iff_idnet {
+    IdNetDev dev;
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+};
+
+extern "C" void iff_idnet_destroy(iff_idnet* n) {
+    if (!n) return;
+    if (n->slab) (void)hipFree(n->slab);
+    delete n;
+}
+
+extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet** out) {
+    IFF_REQUIRE(d && out, "iff_idnet_create: null argument");
+    *out = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    IFF_REQUIRE(d->l1_w && d->l1_b && d->l2_w && d->l2_b && d->l3_w && d->l3_b && d->l4_w && d->l4_b && d->q_w && d->q_b &&
+                    d->k_w && d->k_b, "iff_idnet_create: null weight");
+    const int C = d->feature_c, Fe = d->fea, IF = d->img_fea;
+    IFF_REQUIRE(C >= 16 && C % 16 == 0 && Fe >= 16 && Fe % 16 == 0 && IF >= 1, "iff_idnet_create: widths %d/%d/%d unsupported", C, Fe, IF);
+    const int KQ = (IF + 15) / 16 * 16;
+    iff_idnet* n = new iff_idnet();
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = up256(off + floats * 4); return o; };
+    size_t o_w1 = take((size_t)144 * C), o_b1 = take(C), o_w2 = take((size_t)C * C), o_b2 = take(C),
+           o_w3 = take((size_t)(C + 144) * C), o_b3 = take(C), o_w4 = take((size_t)C * Fe), o_b4 = take(Fe),
+           o_wk = take((size_t)Fe * Fe), o_bk = take(Fe), o_wq = take((size_t)KQ * Fe), o_bq = take(Fe);
+    n->slab_bytes = off;
+    hipError_t e = hipMalloc(&n->slab, off);
+    if (e != hipSuccess) { delete n; return hip_fail(e, "hipMalloc(idnet weights)"); }
+    char* b = (char*)n->slab;
+#define IFF_NET_HIP(call)                                              \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) { iff_idnet_destroy(n); return hip_fail(e__, #call); } \
+    } while (0)
+    IFF_NET_HIP(hipMemsetAsync(n->slab, 0, off, s));
+    IFF_NET_HIP(launch_transpose_pad(d->l1_w, (float*)(b + o_w1), C, IFF_RAY_INPUT, 144, 0, s));
+    IFF_NET_HIP(launch_transpose_pad(d->l2_w, (float*)(b + o_w2), C, C, C, 0, s));
+    // layer 3 consumes [h (C) | x (141)]: its weight columns 0..C-1 go to rows 0..C-1, columns C.. to rows C..C+140
+    IFF_NET_HIP(launch_transpose_pad(d->l3_w, (float*)(b + o_w3), C, C + IFF_RAY_INPUT, C + 144, 0, s));
+    IFF_NET_HIP(launch_transpose_pad(d->l4_w, (float*)(b + o_w4), Fe, C, C, 0, s));
+    IFF_NET_HIP(launch_transpose_pad(d->k_w, (float*)(b + o_wk), Fe, Fe, Fe, 0, s));
+    IFF_NET_HIP(launch_transpose_pad(d->q_w, (float*)(b + o_wq), Fe, IF, KQ, 0, s));
+    struct { const float* src; size_t off; int n; } bs[] = {{d->l1_b, o_b1, C}, {d->l2_b, o_b2, C}, {d->l3_b, o_b3, C},
+                                                            {d->l4_b, o_b4, Fe}, {d->k_b, o_bk, Fe}, {d->q_b, o_bq, Fe}};
+    for (auto& p : bs) IFF_NET_HIP(hipMemcpyAsync(b + p.off, p.src, (size_t)p.n * 4, hipMemcpyDeviceToDevice, s));
+    IdNetDev& v = n->dev;
+    v.w1 = (const float*)(b + o_w1); v.b1 = (const float*)(b + o_b1); v.w2 = (const float*)(b + o_w2); v.b2 = (const float*)(b + o_b2);
+    v.w3 = (const float*)(b + o_w3); v.b3 = (const float*)(b + o_b3); v.w4 = (const float*)(b + o_w4); v.b4 = (const float*)(b + o_b4);
+    v.wk = (const float*)(b + o_wk); v.bk = (const float*)(b + o_bk); v.wq = (const float*)(b + o_wq); v.bq = (const float*)(b + o_bq);
+    v.feature_c = C; v.fea = Fe; v.img_fea = IF;
+    IFF_NET_HIP(hipStreamSynchronize(s));
+    *out = n;
+    return 0;
+}
+
+extern "C" size_t iff_ray_encode_workspace(const iff_idnet* n, int64_t N) {
+    return (n && N > 0) ? ray_encode_workspace_bytes(n->dev, N) : 0;
+}
+
+extern "C" int iff_ray_encode(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N, float* feat_opt,
+                              float* k_out, void* workspace, size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(n && N >= 0, "iff_ray_encode: bad argument");
+    if (N == 0) return 0;
+    IFF_REQUIRE(o && d && rgb && workspace, "iff_ray_encode: null buffer");
+    IFF_REQUIRE(feat_opt || k_out, "iff_ray_encode: no output requested");
+    if (workspace_bytes < ray_encode_workspace_bytes(n->dev, N))
+        return fail(IFF_ERR_WORKSPACE, "iff_ray_encode: workspace %zu < %zu bytes", workspace_bytes, ray_encode_workspace_bytes(n->dev, N));
+    IFF_HIP(launch_ray_encode(n->dev, o, d, rgb, N, feat_opt, k_out, workspace, workspace_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" size_t iff_q_proj_workspace(const iff_idnet* n, int32_t M) {
+    if (!n || M <= 0) return 0;
+    return (size_t)M * ((n->dev.img_fea + 15) / 16 * 16) * sizeof(float);
+}
+
+extern "C" int iff_q_proj(const iff_idnet* n, const float* img, int32_t M, float* q, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    IFF_REQUIRE(n && M >= 0, "iff_q_proj: bad argument");
+    if (M == 0) return 0;
+    IFF_REQUIRE(img && q && workspace, "iff_q_proj: null buffer");
+    if (workspace_bytes < iff_q_proj_workspace(n, M)) return fail(IFF_ERR_WORKSPACE, "iff_q_proj: workspace too small");
+    IFF_HIP(launch_q_proj(n->dev, img, M, q, workspace, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_attn_logits(const float* q, const float* k, int32_t M, int64_t N, int32_t D, float divisor, float* logits,
+                               float* row_max, float* row_sumexp, void* stream) {
+    IFF_REQUIRE(M >= 0 && N >= 0 && D > 0 && D % 16 == 0, "iff_attn_logits: bad shape M=%d N=%lld D=%d", M, (long long)N, D);
+    if (M == 0 || N == 0) return 0;
+    IFF_REQUIRE(q && k && logits, "iff_attn_logits: null buffer");
+    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_attn_logits: pass both row statistics or neither");
+    IFF_HIP(launch_attn_logits(q, k, M, N, D, divisor, logits, row_max, row_sumexp, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const float* row_max, const float* row_sumexp,
+                               int32_t write_attention, float* score, void* stream) {
+    IFF_REQUIRE(M >= 1 && M <= 8192 && N >= 0, "iff_attn_colsum: bad shape");
+    if (N == 0) return 0;
+    IFF_REQUIRE(logits_inout && row_max && row_sumexp && score, "iff_attn_colsum: null buffer");
+    IFF_HIP(launch_attn_colsum(logits_inout, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" size_t iff_topk_workspace(int64_t N, int32_t k) { return topk_workspace_bytes(N, k); }
+
+extern "C" int iff_topk(const float* score, int64_t N, int32_t k, int64_t* idx, float* val, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(score && idx && val, "iff_topk: null buffer");
+    IFF_REQUIRE(k >= 1 && k <= 1024, "iff_topk: k = %d outside [1, 1024]", k);
+    IFF_REQUIRE(N >= k, "iff_topk: k = %d exceeds N = %lld (torch.topk raises here too)", k, (long long)N);
+    IFF_HIP(launch_topk(score, N, k, idx, val, workspace, workspace_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_pose_from_topk(const int64_t* idx, const float* val, int32_t k, const float* rays_o, const float* rays_d,
+                                  int64_t N, const float* up_host, float* c2w, float* parts_opt, void* stream) {
+    IFF_REQUIRE(idx && val && rays_o && rays_d && up_host && c2w, "iff_pose_from_topk: null buffer");
+    IFF_REQUIRE(k >= 1 && k <= 1024, "iff_pose_from_topk: k = %d outside [1, 1024]", k);
+    IFF_HIP(launch_pose(idx, val, k, rays_o, rays_d, N, up_host, c2w, parts_opt, (hipStream_t)stream));
+    return 0;
+}

@@ -1,0 +1,224 @@
+// field_kernels.hip -- K0 table re-layout and the per-point lookups (K1 point_alpha, K2 point_normals, ...).
+// Hand-written for gfx950 (wave64).  Each point is served by 4 consecutive lanes: one lane per 16-byte quarter of a
+// 64-byte (16-channel fp32) texel, so a tap is one contiguous 64-B read per point and a wave keeps 16 points x 18
+// taps in flight.
+#include "iff_device.h"
+#include "iff_launch.h"
+
+// ------------------------------------------------------------------------------------------------ K0
+// [C][H*W] -> [H*W][C]
+__global__ void k0_channels_last(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t HW) {
+    int64_t n = (int64_t)C * HW;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t px = t / C;
+        int c = (int)(t - px * C);
+        dst[t] = src[(int64_t)c * HW + px];
+    }
+}
+
+__global__ void k0_mask_bytes(const float* __restrict__ src, uint8_t* __restrict__ dst, int64_t n) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        dst[t] = (src[t] > 0.0f) ? 1 : 0;
+}
+
+// basis_mat [app_dim][3*n_app] -> [app_dim][4][3*n_app/4]: slice `sub` holds, in order (plane i, j, e), the weights of
+// channels ch = 16 j + 4 sub + e -- the order app_products_slice() produces them in.
+__global__ void k0_basis_slices(const float* __restrict__ src, float* __restrict__ dst, int app_dim, int n_app) {
+    int npl = n_app / 4;
+    int per = 3 * npl;
+    int n = app_dim * 4 * per;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        int kk = t % per;
+        int sub = (t / per) & 3;
+        int o = t / (4 * per);
+        int i = kk / npl, r = kk % npl, j = r >> 2, e = r & 3;
+        dst[t] = src[o * 3 * n_app + i * n_app + 16 * j + 4 * sub + e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__global__ void k_normalize_coord(FieldDev f, const float* __restrict__ xyz, int64_t n, float* __restrict__ out) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float p[3] = {xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2]}, q[3];
+        field_normalize(f, p, q);
+        out[3 * t] = q[0]; out[3 * t + 1] = q[1]; out[3 * t + 2] = q[2];
+    }
+}
+
+__global__ void k_mask_sample(FieldDev f, const float* __restrict__ xyz, int64_t n, float* __restrict__ out) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float p[3] = {xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2]};
+        out[t] = f.mask ? mask_value(f, p) : 1.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K1
+// mode 0: compute_densityfeature(xn) -> feature ; mode 1: compute_alpha(xyz, length) -> alpha
+template <int MODE>
+__global__ void __launch_bounds__(256) k1_point_density(FieldDev f, const float* __restrict__ pts, int64_t n, float length,
+                                                        float* __restrict__ out) {
+    int64_t nt = n * 4;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the trip count is wave-uniform (nt is a multiple of 4 and waves start on multiples of 64)
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ((nt + 63) & ~(int64_t)63); t += stride) {
+        bool live = t < nt;
+        int64_t pi = live ? (t >> 2) : 0;
+        int sub = (int)(t & 3);
+        float p[3] = {pts[3 * pi], pts[3 * pi + 1], pts[3 * pi + 2]};
+        float xn[3];
+        bool valid = live;
+        if (MODE == 1) {
+            if (f.mask) valid = valid && (mask_value(f, p) > 0.0f);
+            field_normalize(f, p, xn);
+        } else {
+            xn[0] = p[0]; xn[1] = p[1]; xn[2] = p[2];
+        }
+        float part = 0.0f;
+        if (valid) part = density_partial(f, xn, sub);
+        float feat = sum4(part);
+        if (live && sub == 0) {
+            if (MODE == 0) {
+                out[pi] = feat;
+            } else {
+                float sigma = valid ? feature2density(f, feat) : 0.0f;
+                out[pi] = 1.0f - expf(-sigma * length);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ app feature / K2
+// mode 0: compute_appfeature(xn) -> [n, app_dim]; mode 1: samples_points_normals(xyz) -> [n,3]
+template <int MODE, int NPL, int APP>
+__global__ void __launch_bounds__(256) k2_point_app(FieldDev f, const float* __restrict__ pts, int64_t n,
+                                                    float* __restrict__ out) {
+    const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
+    int64_t nt = n * 4;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ((nt + 63) & ~(int64_t)63); t += stride) {
+        bool live = t < nt;
+        int64_t pi = live ? (t >> 2) : 0;
+        int sub = (int)(t & 3);
+        float p[3] = {pts[3 * pi], pts[3 * pi + 1], pts[3 * pi + 2]};
+        float xn[3];
+        if (MODE == 1) field_normalize(f, p, xn);
+        else { xn[0] = p[0]; xn[1] = p[1]; xn[2] = p[2]; }
+        float prod[3 * NPL];
+        app_products_slice<NPL>(f, xn, sub, prod);
+        float F[APP];
+        const float* bl = f.basis_l + sub * (3 * NPL);
+#pragma unroll
+        for (int o = 0; o < APP; ++o) {
+            float a = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 3 * NPL; ++kk) a = fmaf(bl[o * 4 * 3 * NPL + kk], prod[kk], a);
+            F[o] = sum4(a);
+        }
+        if (!live) continue;
+        if (MODE == 0) {
+            for (int o = sub; o < APP; o += 4) out[pi * APP + o] = F[o];
+        } else if (sub == 0) {
+            // Ref.compute_normals = -normal_mlp(F) = +normalise(W F + b)   (models/ref.py:85-89,154-155)
+            float nr[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < APP; ++k) a = fmaf(f.head[ho.normal_w + o * APP + k], F[k], a);
+                nr[o] = a + f.head[ho.normal_b + o];
+            }
+            float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
+            out[3 * pi] = nr[0] / nn; out[3 * pi + 1] = nr[1] / nn; out[3 * pi + 2] = nr[2] / nn;
+        }
+    }
+}
+
+// Ref.forward for explicit (viewdirs, features): 16 lanes per row
+template <int APP>
+__global__ void __launch_bounds__(256) k_ref_shade(FieldDev f, const float* __restrict__ dirs, const float* __restrict__ feat,
+                                                   int64_t n, float* __restrict__ rgb) {
+    const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
+    int64_t nt = n * 16;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ((nt + 63) & ~(int64_t)63); t += stride) {
+        bool live = t < nt;
+        int64_t ri = live ? (t >> 4) : 0;
+        int l16 = (int)(t & 15);
+        float F[APP], d[3] = {dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]}, c[3];
+#pragma unroll
+        for (int k = 0; k < APP; ++k) F[k] = feat[ri * APP + k];
+        ref_shade_group16<APP>(f.head, ho, f.feature_c, F, d, l16, c);
+        if (live && l16 == 0) { rgb[3 * ri] = c[0]; rgb[3 * ri + 1] = c[1]; rgb[3 * ri + 2] = c[2]; }
+    }
+}
+
+// Ref.compute_normals(features) = +normalise(W F + b)   (models/ref.py:85-89,154-155)
+template <int APP>
+__global__ void k_ref_normals(FieldDev f, const float* __restrict__ feat, int64_t n, float* __restrict__ out) {
+    const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float nr[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < APP; ++k) a = fmaf(f.head[ho.normal_w + o * APP + k], feat[t * APP + k], a);
+            nr[o] = a + f.head[ho.normal_b + o];
+        }
+        float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
+        out[3 * t] = nr[0] / nn; out[3 * t + 1] = nr[1] / nn; out[3 * t + 2] = nr[2] / nn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline int grid_for(int64_t threads, int block = 256, int cap = 256 * 8) {
+    int64_t g = (threads + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+hipError_t launch_k0_channels_last(const float* src, float* dst, int C, int64_t HW, hipStream_t s) {
+    hipLaunchKernelGGL(k0_channels_last, dim3(grid_for((int64_t)C * HW)), dim3(256), 0, s, src, dst, C, HW);
+    return hipGetLastError();
+}
+hipError_t launch_k0_mask_bytes(const float* src, uint8_t* dst, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k0_mask_bytes, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_k0_basis_slices(const float* src, float* dst, int app_dim, int n_app, hipStream_t s) {
+    hipLaunchKernelGGL(k0_basis_slices, dim3(grid_for(app_dim * 3 * n_app)), dim3(256), 0, s, src, dst, app_dim, n_app);
+    return hipGetLastError();
+}
+hipError_t launch_normalize_coord(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_normalize_coord, dim3(grid_for(n)), dim3(256), 0, s, f, xyz, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_mask_sample(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_sample, dim3(grid_for(n)), dim3(256), 0, s, f, xyz, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_density_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k1_point_density<0>, dim3(grid_for(n * 4)), dim3(256), 0, s, f, xn, n, 1.0f, out);
+    return hipGetLastError();
+}
+hipError_t launch_point_alpha(const FieldDev& f, const float* xyz, int64_t n, float length, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k1_point_density<1>, dim3(grid_for(n * 4)), dim3(256), 0, s, f, xyz, n, length, out);
+    return hipGetLastError();
+}
+hipError_t launch_app_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL((k2_point_app<0, 12, 27>), dim3(grid_for(n * 4)), dim3(256), 0, s, f, xn, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_point_normals(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL((k2_point_app<1, 12, 27>), dim3(grid_for(n * 4)), dim3(256), 0, s, f, xyz, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_ref_shade(const FieldDev& f, const float* dirs, const float* feat, int64_t n, float* rgb, hipStream_t s) {
+    hipLaunchKernelGGL((k_ref_shade<27>), dim3(grid_for(n * 16)), dim3(256), 0, s, f, dirs, feat, n, rgb);
+    return hipGetLastError();
+}
+hipError_t launch_ref_normals(const FieldDev& f, const float* feat, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL((k_ref_normals<27>), dim3(grid_for(n)), dim3(256), 0, s, f, feat, n, out);
+    return hipGetLastError();
+}

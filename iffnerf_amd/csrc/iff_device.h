@@ -1,0 +1,353 @@
+// iff_device.h -- device-side view of a field handle and the lookup primitives shared by the kernels.
+// gfx950 only (wave64).  Compiled with -ffp-contract=off: every fused multiply-add below is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IFF_WAVE 64
+
+// VM index conventions of the reference: models/tensorBase.py:311-312
+//   plane i spans axes (a,b) = matMode[i] = (0,1),(0,2),(1,2) with W<->a, H<->b ; line i runs along vecMode[i] = 2,1,0
+__host__ __device__ constexpr int mat_a(int i) { return i == 2 ? 1 : 0; }
+__host__ __device__ constexpr int mat_b(int i) { return i == 0 ? 1 : 2; }
+__host__ __device__ constexpr int vec_ax(int i) { return 2 - i; }
+
+struct FieldDev {
+    // channels-last tables built by K0 (field_relayout): plane i [G_b][G_a][C], line i [G_v][C]
+    const float* dplane[3];
+    const float* dline[3];
+    const float* aplane[3];
+    const float* aline[3];
+    const float* basis_l;       // basis_mat re-laid [app_dim][4][3*n_app/4] (lane-slice major), see field_kernels.hip
+    const float* basis;         // basis_mat as given [app_dim][3*n_app]
+    const uint8_t* mask;        // [D][H][W] bytes in {0,1}, or nullptr
+    const float* head;          // packed Ref head, offsets below
+    int grid[3];
+    int mask_dims[3];           // D,H,W
+    float aabb_lo[3], aabb_hi[3], inv_aabb[3];        // inv_aabb = 2/size   (tensorBase.py:358)
+    float mask_lo[3], mask_hi[3], mask_inv[3];        // mask_inv = (1/size)*2 (tensorBase.py:59)
+    float density_shift, distance_scale, weight_thres, step_size, near, far;
+    int n_samples, softplus, unisphere;
+    int n_density, n_app, app_dim, feature_c;
+};
+
+// Ref head packing (floats): all nn.Linear weights row-major [out][in]
+struct HeadOff {
+    int normal_w, normal_b, tint_w, tint_b, rough_w, rough_b, diffuse_w, diffuse_b, bott_w, bott_b, spec_w, spec_b,
+        ide_mat, total;
+};
+__host__ __device__ inline HeadOff head_offsets(int app_dim, int feature_c) {
+    HeadOff o;
+    int p = 0;
+    o.normal_w = p; p += 3 * app_dim; o.normal_b = p; p += 3; p = (p + 3) & ~3;
+    o.tint_w = p; p += 3 * app_dim; o.tint_b = p; p += 3; p = (p + 3) & ~3;
+    o.rough_w = p; p += app_dim; o.rough_b = p; p += 1; p = (p + 3) & ~3;
+    o.diffuse_w = p; p += 3 * app_dim; o.diffuse_b = p; p += 3; p = (p + 3) & ~3;
+    o.bott_w = p; p += feature_c * app_dim; o.bott_b = p; p += feature_c; p = (p + 3) & ~3;
+    o.spec_w = p; p += 3 * (feature_c + 39); o.spec_b = p; p += 3; p = (p + 3) & ~3;
+    o.ide_mat = p; p += 9 * 19; p = (p + 3) & ~3;
+    o.total = p;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------- coordinates
+// utils.py:139-146 power_transformation(x, alpha=-1.5): sign(x) * (2.5/-1.5) * ((|x|/2.5 + 1)^-1.5 - 1)
+__device__ inline float contract_power(float x) {
+    const float na = 2.5f, alpha = -1.5f;
+    float m = fabsf(x);
+    float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    return sgn * (na / alpha) * (powf((m / na) + 1.0f, alpha) - 1.0f);
+}
+
+// TensorBase.normalize_coord, tensorBase.py:389-397
+__device__ inline void field_normalize(const FieldDev& f, const float p[3], float out[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (f.unisphere) {
+            float c = (f.aabb_lo[a] + f.aabb_hi[a]) / 2.0f;
+            out[a] = contract_power(p[a] - c);
+        } else {
+            out[a] = (p[a] - f.aabb_lo[a]) * f.inv_aabb[a] - 1.0f;
+        }
+    }
+}
+
+// AlphaGridMask.normalize_coord, tensorBase.py:74-83
+__device__ inline void mask_normalize(const FieldDev& f, const float p[3], float out[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (f.unisphere) {
+            float c = (f.mask_lo[a] + f.mask_hi[a]) / 2.0f;
+            out[a] = contract_power(p[a] - c);
+        } else {
+            out[a] = (p[a] - f.mask_lo[a]) * f.mask_inv[a] - 1.0f;
+        }
+    }
+}
+
+__device__ inline bool inside_aabb(const FieldDev& f, const float p[3]) {
+    // tensorBase.py:634-636: outside = (aabb[0] > p) | (p > aabb[1]) on any axis
+    bool out = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out = out || (f.aabb_lo[a] > p[a]) || (p[a] > f.aabb_hi[a]);
+    return !out;
+}
+
+// align_corners=True un-normalisation of F.grid_sample: ((c + 1) / 2) * (size - 1)
+__device__ inline float unnorm(float c, int size) { return ((c + 1.0f) / 2.0f) * (float)(size - 1); }
+
+// 3-D trilinear read of the {0,1} occupancy bytes with zero padding: the value F.grid_sample returns for
+// tensorBase.py:66-72 (corner order and weight products as ATen's grid_sampler_3d).
+__device__ inline float mask_value(const FieldDev& f, const float p[3]) {
+    float g[3];
+    mask_normalize(f, p, g);
+    const int W = f.mask_dims[2], H = f.mask_dims[1], D = f.mask_dims[0];
+    float ix = unnorm(g[0], W), iy = unnorm(g[1], H), iz = unnorm(g[2], D);
+    float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    // weights of the low corner: (i0 + 1 - i), of the high corner: (i - i0)
+    float wx[2] = {(fx + 1.0f) - ix, ix - fx};
+    float wy[2] = {(fy + 1.0f) - iy, iy - fy};
+    float wz[2] = {(fz + 1.0f) - iz, iz - fz};
+    // NaN / huge coordinates: every corner is out of range -> 0
+    if (!(ix > -2.0f && ix < (float)(W + 1) && iy > -2.0f && iy < (float)(H + 1) && iz > -2.0f && iz < (float)(D + 1)))
+        return 0.0f;
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    float acc = 0.0f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+                bool in = (x >= 0) && (x < W) && (y >= 0) && (y < H) && (z >= 0) && (z < D);
+                float v = 0.0f;
+                if (in) v = (float)f.mask[((size_t)z * H + y) * W + x];
+                acc = acc + v * (wx[dx] * wy[dy] * wz[dz]);
+            }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------- VM addressing
+// Bilinear tap set of one plane (align_corners=True, zero padding): 4 texel offsets (clamped) + weights
+// (zeroed when the corner is out of range), and the 2-tap linear set of the matching line.
+struct Taps {
+    int   p_off[4];   // texel index (y*W + x) of nw, ne, sw, se
+    float p_w[4];
+    int   l_off[2];   // line texel index
+    float l_w[2];
+};
+
+__device__ inline void make_taps(const FieldDev& f, const float xn[3], int i, Taps& t) {
+    const int a = mat_a(i), b = mat_b(i), v = vec_ax(i);
+    const int W = f.grid[a], H = f.grid[b], L = f.grid[v];
+    float x = unnorm(xn[a], W), y = unnorm(xn[b], H), z = unnorm(xn[v], L);
+    float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    float wx1 = x - fx, wy1 = y - fy, wz1 = z - fz;
+    float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1, wz0 = 1.0f - wz1;
+    // keep int conversions defined for NaN / far-out coordinates (all taps get weight 0 there)
+    bool ok = (x > -2.0f) && (x < (float)(W + 1)) && (y > -2.0f) && (y < (float)(H + 1));
+    int x0 = ok ? (int)fx : -2, y0 = ok ? (int)fy : -2;
+    bool okz = (z > -2.0f) && (z < (float)(L + 1));
+    int z0 = okz ? (int)fz : -2;
+    float wxs[2] = {wx0, wx1}, wys[2] = {wy0, wy1};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            int xx = x0 + dx, yy = y0 + dy;
+            bool in = (xx >= 0) && (xx < W) && (yy >= 0) && (yy < H);
+            t.p_off[dy * 2 + dx] = in ? (yy * W + xx) : 0;
+            t.p_w[dy * 2 + dx] = in ? (wys[dy] * wxs[dx]) : 0.0f;
+        }
+    // the line is a width-1 image sampled at x = 0 (tensoRF.py:225): x tap 0 has weight 1, tap 1 is out of range
+    float wzs[2] = {wz0, wz1};
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz) {
+        int zz = z0 + dz;
+        bool in = (zz >= 0) && (zz < L);
+        t.l_off[dz] = in ? zz : 0;
+        t.l_w[dz] = in ? wzs[dz] : 0.0f;
+    }
+}
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int ch) {
+    float4 nw = ld4(tab + (size_t)t.p_off[0] * C + ch), ne = ld4(tab + (size_t)t.p_off[1] * C + ch);
+    float4 sw = ld4(tab + (size_t)t.p_off[2] * C + ch), se = ld4(tab + (size_t)t.p_off[3] * C + ch);
+    float4 r;
+    r.x = nw.x * t.p_w[0] + ne.x * t.p_w[1] + sw.x * t.p_w[2] + se.x * t.p_w[3];
+    r.y = nw.y * t.p_w[0] + ne.y * t.p_w[1] + sw.y * t.p_w[2] + se.y * t.p_w[3];
+    r.z = nw.z * t.p_w[0] + ne.z * t.p_w[1] + sw.z * t.p_w[2] + se.z * t.p_w[3];
+    r.w = nw.w * t.p_w[0] + ne.w * t.p_w[1] + sw.w * t.p_w[2] + se.w * t.p_w[3];
+    return r;
+}
+
+__device__ inline float4 lerp_line4(const float* tab, int C, const Taps& t, int ch) {
+    float4 lo = ld4(tab + (size_t)t.l_off[0] * C + ch), hi = ld4(tab + (size_t)t.l_off[1] * C + ch);
+    float4 r;
+    r.x = lo.x * t.l_w[0] + hi.x * t.l_w[1];
+    r.y = lo.y * t.l_w[0] + hi.y * t.l_w[1];
+    r.z = lo.z * t.l_w[0] + hi.z * t.l_w[1];
+    r.w = lo.w * t.l_w[0] + hi.w * t.l_w[1];
+    return r;
+}
+
+// Partial density feature of one point for the calling lane's channel slice.
+// `sub` in [0,4): the lane owns channels {4*sub + 16*j + e}; with n_density == 16 that is one float4 per texel,
+// so the 4 lanes of a point read one contiguous 64-B texel per tap.  Sum over the 4 lanes = the feature.
+__device__ inline float density_partial(const FieldDev& f, const float xn[3], int sub) {
+    float acc = 0.0f;
+    const int C = f.n_density;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Taps t;
+        make_taps(f, xn, i, t);
+        for (int ch = 4 * sub; ch < C; ch += 16) {
+            float4 p = lerp_plane4(f.dplane[i], C, t, ch);
+            float4 l = lerp_line4(f.dline[i], C, t, ch);
+            acc = acc + (p.x * l.x + p.y * l.y + p.z * l.z + p.w * l.w);
+        }
+    }
+    return acc;
+}
+
+// xor-butterfly sum over the 4 lanes that share a point (lanes 4k..4k+3)
+__device__ inline float sum4(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+}
+
+// tensorBase.py:750-754 ; torch softplus: beta 1, threshold 20
+__device__ inline float feature2density(const FieldDev& f, float feat) {
+    if (f.softplus) {
+        float x = feat + f.density_shift;
+        return (x > 20.0f) ? x : log1pf(expf(x));
+    }
+    return fmaxf(feat, 0.0f);
+}
+
+// Appearance plane*line products of one point for the calling lane's channel slice:
+// prod[i*(C/4) + 4*j + e] = plane_i[ch] * line_i[ch], ch = 16*j + 4*sub + e  (tensoRF.py:248-256 before basis_mat).
+// NPL = n_app / 4 products per plane per lane (12 for n_app = 48).
+template <int NPL>
+__device__ inline void app_products_slice(const FieldDev& f, const float xn[3], int sub, float* prod) {
+    const int C = f.n_app;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Taps t;
+        make_taps(f, xn, i, t);
+#pragma unroll
+        for (int j = 0; j < NPL / 4; ++j) {
+            int ch = 16 * j + 4 * sub;
+            float4 p = lerp_plane4(f.aplane[i], C, t, ch);
+            float4 l = lerp_line4(f.aline[i], C, t, ch);
+            prod[i * NPL + 4 * j + 0] = p.x * l.x;
+            prod[i * NPL + 4 * j + 1] = p.y * l.y;
+            prod[i * NPL + 4 * j + 2] = p.z * l.z;
+            prod[i * NPL + 4 * j + 3] = p.w * l.w;
+        }
+    }
+}
+
+__device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ inline float softplusf_(float x) { return (x > 20.0f) ? x : log1pf(expf(x)); }
+
+// models/image.py:6-13 linear_to_srgb (eps = float32 machine epsilon)
+__device__ inline float srgbf_(float lin) {
+    float lo = 12.92f * lin;
+    float hi = (211.0f * powf(fmaxf(lin, 1.1920928955078125e-07f), 0.4166666567325592f) - 11.0f) / 200.0f;
+    return (lin <= 0.0031308f) ? lo : hi;
+}
+
+__device__ inline float sum16(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// Ref.forward (models/ref.py:103-152, normals=None) evaluated by a group of 16 consecutive lanes for one ray.
+// Every lane passes the same F[27] and d[3]; `l16` is the lane's index in the group; `head` is the packed head
+// (LDS or global).  All 16 lanes return the rgb triple.  APP = app_dim (27).
+template <int APP>
+__device__ inline void ref_shade_group16(const float* head, const HeadOff& ho, int feature_c, const float* F,
+                                         const float d[3], int l16, float rgb[3]) {
+    // small heads, computed redundantly by every lane
+    float nr[3], tint[3], diff[3], rough;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+        for (int k = 0; k < APP; ++k) {
+            a = fmaf(head[ho.normal_w + o * APP + k], F[k], a);
+            b = fmaf(head[ho.tint_w + o * APP + k], F[k], b);
+            c = fmaf(head[ho.diffuse_w + o * APP + k], F[k], c);
+        }
+        nr[o] = a + head[ho.normal_b + o];
+        tint[o] = sigmoidf_(b + head[ho.tint_b + o]);
+        diff[o] = sigmoidf_((c + head[ho.diffuse_b + o]) + -1.0986122886681098f);
+    }
+    {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < APP; ++k) a = fmaf(head[ho.rough_w + k], F[k], a);
+        rough = softplusf_((a + head[ho.rough_b]) + -1.0f);
+    }
+    float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
+    float n[3] = {-(nr[0] / nn), -(nr[1] / nn), -(nr[2] / nn)};   // normal_mlp: normalise then * -1
+    float v[3] = {-d[0], -d[1], -d[2]};
+    float ndv = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
+    float r[3] = {2.0f * ndv * n[0] - v[0], 2.0f * ndv * n[1] - v[1], 2.0f * ndv * n[2] - v[2]};   // ref_utils.py:18
+    float dot = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+    const int K = feature_c + 39;
+    float part[3] = {0.f, 0.f, 0.f};
+    // integrated directional encoding (ref_utils.py:82-112): pairs i = l16, l16 + 16
+    float zp[9];
+    zp[0] = 1.0f;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) zp[k] = zp[k - 1] * r[2];
+    for (int i = l16; i < 19; i += 16) {
+        // (m, l) of pair i: l = 1,2,4,8 with m = 0..l  -> offsets 0,2,5,10
+        int l = (i < 2) ? 1 : (i < 5) ? 2 : (i < 10) ? 4 : 8;
+        int m = i - ((i < 2) ? 0 : (i < 5) ? 2 : (i < 10) ? 5 : 10);
+        float pr = 1.0f, pi = 0.0f;
+        for (int q = 0; q < m; ++q) {
+            float t = pr * r[0] - pi * r[1];
+            pi = pr * r[1] + pi * r[0];
+            pr = t;
+        }
+        float poly = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) poly = fmaf(zp[k], head[ho.ide_mat + k * 19 + i], poly);
+        float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
+        float re = pr * poly * att, im = pi * poly * att;
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            part[o] = fmaf(head[ho.spec_w + o * K + feature_c + 2 * i], re,
+                           fmaf(head[ho.spec_w + o * K + feature_c + 2 * i + 1], im, part[o]));
+    }
+    // bottleneck slice j = l16 + 16 t
+    for (int j = l16; j < feature_c; j += 16) {
+        float b = 0.f;
+#pragma unroll
+        for (int k = 0; k < APP; ++k) b = fmaf(head[ho.bott_w + j * APP + k], F[k], b);
+        b += head[ho.bott_b + j];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * K + j], b, part[o]);
+    }
+    if (l16 == 0) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * K + K - 1], dot, part[o]) + head[ho.spec_b + o];
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float s = sigmoidf_(sum16(part[o]));
+        float c = srgbf_(tint[o] * s + diff[o]);
+        c = fminf(fmaxf(c, 0.0f), 1.0f);
+        rgb[o] = c * 1.002f - 0.001f;
+    }
+}

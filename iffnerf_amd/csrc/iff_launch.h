@@ -1,0 +1,59 @@
+// iff_launch.h -- host-side launcher prototypes shared between the kernel translation units and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "iff_device.h"
+
+// field_kernels.hip
+hipError_t launch_k0_channels_last(const float* src, float* dst, int C, int64_t HW, hipStream_t s);
+hipError_t launch_k0_mask_bytes(const float* src, uint8_t* dst, int64_t n, hipStream_t s);
+hipError_t launch_k0_basis_slices(const float* src, float* dst, int app_dim, int n_app, hipStream_t s);
+hipError_t launch_normalize_coord(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
+hipError_t launch_mask_sample(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
+hipError_t launch_density_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s);
+hipError_t launch_point_alpha(const FieldDev& f, const float* xyz, int64_t n, float length, float* out, hipStream_t s);
+hipError_t launch_app_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s);
+hipError_t launch_point_normals(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
+hipError_t launch_ref_normals(const FieldDev& f, const float* feat, int64_t n, float* out, hipStream_t s);
+hipError_t launch_ref_shade(const FieldDev& f, const float* dirs, const float* feat, int64_t n, float* rgb, hipStream_t s);
+
+// march_kernels.hip
+hipError_t launch_isocell_emit(const float* cells27x3_host, const float* pts, const float* nrm, int64_t P, float* ori,
+                               float* dirs, hipStream_t s);
+hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
+                        float* rgb, float* depth, float* acc, float* alpha, int* counts, hipStream_t s);
+
+// sampler_kernels.hip
+size_t sampler_workspace_bytes(int64_t P);
+hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int64_t P, int n_epochs,
+                                     int max_iterations, uint64_t seed, float rho, float* samples, float* alpha, int* stats,
+                                     void* ws, size_t ws_bytes, int n_cus, hipStream_t s);
+
+// identify_kernels.hip
+struct IdNetDev {
+    // weights transposed to [in][out] (k-major) and zero-padded so every GEMM has K % 4 == 0, N % 128 == 0
+    const float* w1; const float* b1;   // [144][256]   (141 inputs padded to 144)
+    const float* w2; const float* b2;   // [256][256]
+    const float* w3; const float* b3;   // [400][256]   rows 0..255 <- h, rows 256..396 <- x (141), 3 zero rows
+    const float* w4; const float* b4;   // [256][384]
+    const float* wk; const float* bk;   // [384][384]
+    const float* wq; const float* bq;   // [400][384]   (398 inputs padded to 400)
+    int feature_c, fea, img_fea;
+};
+size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N);
+hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* feat,
+                             float* kout, void* ws, size_t ws_bytes, hipStream_t s);
+hipError_t launch_q_proj(const IdNetDev& n, const float* img, int M, float* q, void* scratch, hipStream_t s);
+hipError_t launch_transpose_pad(const float* w_out_in, float* dst_in_out, int out_f, int in_f, int in_pad, int row_off,
+                                hipStream_t s);
+hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, int D, float scale, float* logits,
+                              float* row_max, float* row_sumexp, hipStream_t s);
+hipError_t launch_attn_colsum(float* logits, int M, int64_t N, const float* row_max, const float* row_sumexp,
+                              int write_attention, float* score, hipStream_t s);
+size_t topk_workspace_bytes(int64_t N, int k);
+hipError_t launch_topk(const float* score, int64_t N, int k, int64_t* idx, float* val, void* ws, size_t ws_bytes,
+                       hipStream_t s);
+
+// pose_kernels.hip
+hipError_t launch_pose(const int64_t* idx, const float* val, int k, const float* rays_o, const float* rays_d, int64_t N,
+                       const float* up3, float* c2w, float* parts, hipStream_t s);

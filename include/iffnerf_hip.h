@@ -1,0 +1,198 @@
+/*
+ * iffnerf_hip.h -- C ABI of libiffnerf_hip.so: the MI355X (gfx950) implementation of IFFNeRF's
+ * per-query inference hot path.
+ *
+ * This is the drop-in boundary.  The reference is pure Python/PyTorch and has no
+ * FFI of its own; each entry point below replaces the aten-op chain of the reference function it cites
+ * (paths relative to the upstream repository), and is what the Python classes that keep the reference's
+ * module paths and signatures (iffnerf_amd/models, iffnerf_amd/pose_estimation) bind through ctypes.
+ * INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers (HBM) unless a parameter says "host".  fp32, C-contiguous.
+ *   - The caller allocates and owns every input, output and workspace buffer.  Outputs are fully
+ *     overwritten.  Functions never allocate except inside *_create, never free except in *_destroy.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on it.
+ *   - Return value: 0 on success, non-zero on error (a hipError_t, or IFF_ERR_* below); the message is
+ *     available from iff_last_error() (thread-local).  Numerical degeneracies are values (NaN / identity
+ *     pose), never errors, exactly as in the reference.
+ *   - No torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef IFFNERF_HIP_H
+#define IFFNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFF_ABI_VERSION 1
+
+#define IFF_ERR_INVALID_ARGUMENT 1001
+#define IFF_ERR_UNSUPPORTED      1002
+#define IFF_ERR_WORKSPACE        1003
+
+#define IFF_MARCH_POINT_CENTRED 0   /* sampler = TensorBase.sample_point_color (models/tensorBase.py:623-638) */
+#define IFF_MARCH_SLAB          1   /* sampler = TensorBase.sample_ray, is_train=False (models/tensorBase.py:494-536) */
+
+#define IFF_ISOCELL_DIRS 27         /* pose_estimation/sampling.py:229-234, isocell.py:6-68 (27 targets, N0=3) */
+#define IFF_RAY_FEATURES 384        /* DINOv2 ViT-S/14 width: pose_estimation/backbone.py:12-14 */
+#define IFF_RAY_INPUT    141        /* pose_estimation/ray_preprocessor.py:8 (3*3 + 2*3*(8+8+6)) */
+
+const char* iff_last_error(void);
+int iff_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------ field
+ * A tensorial radiance field (TensorVMSplit + AlphaGridMask + Ref head) re-laid-out for the kernels.
+ * Replaces: the parameter tensors of models/tensoRF.py:155-170, models/tensorBase.py:50-64,
+ * models/ref.py:48-101 as consumed by the lookups below.  Source tensors are read once by
+ * iff_field_create (device pointers, reference layouts) and are not retained.
+ */
+typedef struct iff_field iff_field;
+
+typedef struct iff_field_desc {
+    int32_t grid[3];                 /* gridSize (x, y, z): kwargs["gridSize"], tensorBase.py:405 */
+    float   aabb[6];                 /* aabb[0] xyz, aabb[1] xyz */
+    int32_t n_density;               /* channels per density plane/line (16) */
+    int32_t n_app;                   /* channels per appearance plane/line (48) */
+    int32_t app_dim;                 /* 27 */
+    int32_t feature_c;               /* Ref bottleneck width (128) */
+    const float* density_plane[3];   /* [n_density, G_b, G_a], (a,b) = matMode[i]  (tensoRF.py:166)  */
+    const float* density_line[3];    /* [n_density, G_v],      v = vecMode[i]      (tensoRF.py:168)  */
+    const float* app_plane[3];       /* [n_app, G_b, G_a] */
+    const float* app_line[3];        /* [n_app, G_v] */
+    const float* basis;              /* basis_mat.weight [app_dim, 3*n_app] (tensoRF.py:158) */
+    const float* mask_volume;        /* AlphaGridMask.alpha_volume [D,H,W] in {0,1}, or NULL (tensorBase.py:60) */
+    int32_t mask_dims[3];            /* D, H, W */
+    float   mask_aabb[6];
+    float   density_shift;           /* tensorBase.py:296 */
+    float   distance_scale;          /* tensorBase.py:298 */
+    float   weight_thres;            /* rayMarch_weight_thres, tensorBase.py:299 */
+    float   step_size;               /* self.stepSize as computed by the host mirror (tensorBase.py:366) */
+    int32_t n_samples;               /* self.nSamples (tensorBase.py:368) */
+    float   near_far[2];
+    int32_t softplus;                /* 1: fea2denseAct == "softplus", 0: relu (tensorBase.py:750-754) */
+    int32_t unisphere;               /* 1: contraction_type == "unisphere" (tensorBase.py:390-396) */
+    /* Ref head, models/ref.py:69-101 (nn.Linear layouts [out,in]) */
+    const float* normal_w;  const float* normal_b;    /* [3,app_dim],[3] */
+    const float* tint_w;    const float* tint_b;      /* [3,app_dim],[3] */
+    const float* rough_w;   const float* rough_b;     /* [1,app_dim],[1] */
+    const float* diffuse_w; const float* diffuse_b;   /* [3,app_dim],[3] */
+    const float* bottleneck_w; const float* bottleneck_b; /* [feature_c,app_dim],[feature_c] */
+    const float* specular_w;   const float* specular_b;   /* [3,feature_c+39],[3] */
+    const float* ide_mat;            /* dir_enc_fn.mat [9,19] (models/ref_utils.py:72-80) */
+} iff_field_desc;
+
+int  iff_field_create(const iff_field_desc* desc, void* stream, iff_field** out);
+void iff_field_destroy(iff_field* f);
+/* bytes of HBM the handle's tables occupy (for DESIGN.md / roofline bookkeeping) */
+size_t iff_field_table_bytes(const iff_field* f);
+
+/* TensorBase.normalize_coord, models/tensorBase.py:389-397.  xyz,out: [n,3] */
+int iff_normalize_coord(const iff_field* f, const float* xyz, int64_t n, float* out, void* stream);
+/* AlphaGridMask.sample_alpha, models/tensorBase.py:66-72.  xyz [n,3] world -> value [n] */
+int iff_mask_sample(const iff_field* f, const float* xyz, int64_t n, float* out, void* stream);
+/* TensorVMSplit.compute_densityfeature, models/tensoRF.py:216-235.  xn [n,3] normalised -> [n] */
+int iff_density_feature(const iff_field* f, const float* xn, int64_t n, float* out, void* stream);
+/* TensorVMSplit.compute_appfeature, models/tensoRF.py:237-256.  xn [n,3] normalised -> [n,app_dim] */
+int iff_app_feature(const iff_field* f, const float* xn, int64_t n, float* out, void* stream);
+/* TensorBase.compute_alpha, models/tensorBase.py:756-773.  xyz [n,3] world -> alpha [n] */
+int iff_point_alpha(const iff_field* f, const float* xyz, int64_t n, float length, float* alpha, void* stream);
+/* samples_points_normals, pose_estimation/sampling.py:535-541 (+ Ref.compute_normals, models/ref.py:154).
+ * xyz [n,3] world -> normals [n,3] */
+int iff_point_normals(const iff_field* f, const float* xyz, int64_t n, float* normals, void* stream);
+/* Ref.forward, models/ref.py:103-152 (normals=None).  viewdirs [n,3], features [n,app_dim] -> rgb [n,3] */
+int iff_ref_shade(const iff_field* f, const float* viewdirs, const float* features, int64_t n, float* rgb,
+                  void* stream);
+
+/* Ref.compute_normals, models/ref.py:154-155.  features [n,app_dim] -> normals [n,3] */
+int iff_ref_normals(const iff_field* f, const float* features, int64_t n, float* normals, void* stream);
+
+/* rotate_isocell + renormalise + origin broadcast: pose_estimation/isocell.py:144-171,
+ * pose_estimation/sampling.py:449-461.  cells_host [27,3] = isocell_distribution(27) (host floats, isocell.py:6-68);
+ * points,normals [P,3] -> ori,dirs [27*P,3] (point-major, 27 directions contiguous). */
+int iff_isocell_emit(const float* cells_host, const float* points, const float* normals, int64_t P, float* ori, float* dirs,
+                     void* stream);
+
+/* TensorBase.forward, models/tensorBase.py:775-917 (is_train=False, ndc_ray=False).
+ *   rays [R, ray_cols] (ray_cols 6 or 7: o, d, [radius]); mode IFF_MARCH_*; n_samples <= 0 -> default
+ *   (20 for point-centred, field n_samples for slab); bg [3] host floats.
+ *   rgb [R,3], depth [R], acc [R] required; alpha [R,S] and counts [R,2] (valid, shaded samples) optional.
+ * Also what renderer.OctreeRender_trilinear_fast (renderer.py:12-25) calls per chunk. */
+int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                    int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
+                    float* alpha_opt, int32_t* counts_opt, void* stream);
+
+/* ------------------------------------------------------------------------------------- surface sampler
+ * iterative_surface_sampling_process, pose_estimation/sampling.py:509-532 (+ :78-116,131-213,35-67):
+ * P seeds in occupied mask voxels, then n_epochs epochs of "jitter <= 5P candidates, accept alpha >
+ * quantile_0.6, pick one uniformly".  Device-side counter-based RNG (Philox4x32-10) keyed by `seed`;
+ * no host synchronisation.  rho = jitter scale (sampling.py:518-523, computed by the caller).  samples [P,3],
+ * alpha [P]; stats [n_epochs,4] int32 = (iterations run, samples left invalid, float bits of the threshold, last
+ * candidates-per-sample); stats[3] == -1 reports an in-kernel barrier timeout.
+ * Workspace: iff_surface_sample_workspace(P). */
+size_t iff_surface_sample_workspace(int64_t P);
+int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t max_iterations, uint64_t seed,
+                       float rho, float* samples, float* alpha, int32_t* stats, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------ identification
+ * Ray encoder + attention projections (weights of id_module.th, nn.Linear layouts [out,in]).
+ * Replaces pose_estimation/ray_preprocessor.py:4-39 and multihead_attention.py:44-45. */
+typedef struct iff_idnet iff_idnet;
+
+typedef struct iff_idnet_desc {
+    int32_t feature_c;              /* 256 (identification_module.py:66-68) */
+    int32_t fea;                    /* 384 */
+    int32_t img_fea;                /* 398 = 384 + 14 */
+    const float* l1_w; const float* l1_b;   /* ray_preprocessor.mlp.0   [feature_c,141] */
+    const float* l2_w; const float* l2_b;   /* ray_preprocessor.mlp.2   [feature_c,feature_c] */
+    const float* l3_w; const float* l3_b;   /* ray_preprocessor.mlp2.0  [feature_c,feature_c+141] */
+    const float* l4_w; const float* l4_b;   /* ray_preprocessor.mlp2.2  [fea,feature_c] */
+    const float* q_w;  const float* q_b;    /* attention.q_proj [fea,img_fea] */
+    const float* k_w;  const float* k_b;    /* attention.k_proj [fea,fea] */
+} iff_idnet_desc;
+
+int  iff_idnet_create(const iff_idnet_desc* desc, void* stream, iff_idnet** out);
+void iff_idnet_destroy(iff_idnet* net);
+
+/* RayPreprocessor.forward (ray_preprocessor.py:29-39) and, when k_out != NULL, k_proj
+ * (multihead_attention.py:61).  o,d,rgb [N,3] -> feat_opt [N,fea] (nullable), k_out [N,fea] (nullable). */
+size_t iff_ray_encode_workspace(const iff_idnet* net, int64_t N);
+int iff_ray_encode(const iff_idnet* net, const float* o, const float* d, const float* rgb, int64_t N,
+                   float* feat_opt, float* k_out, void* workspace, size_t workspace_bytes, void* stream);
+/* q_proj (multihead_attention.py:60).  img [M,img_fea] -> q [M,fea].  Workspace: iff_q_proj_workspace(net, M). */
+size_t iff_q_proj_workspace(const iff_idnet* net, int32_t M);
+int iff_q_proj(const iff_idnet* net, const float* img, int32_t M, float* q, void* workspace, size_t workspace_bytes,
+               void* stream);
+
+/* scaled_attention_product (multihead_attention.py:4-12, mask=None), split so that ray shards on several
+ * GPUs can exchange row statistics between the two halves:
+ *   iff_attn_logits: logits[M,N] = q k^T / divisor (divisor = sqrt(d_k)), row_max[M], row_sumexp[M]
+ *                    (= sum_j exp(l_ij - row_max_i)); the two statistics are optional (both or neither)
+ *   iff_attn_colsum: attention = exp(l - row_max)/row_sumexp written in place when write_attention != 0,
+ *                    score[N] = sum_i attention_ij   (identification_module.py:167) */
+int iff_attn_logits(const float* q, const float* k, int32_t M, int64_t N, int32_t D, float divisor, float* logits,
+                    float* row_max, float* row_sumexp, void* stream);
+int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const float* row_max, const float* row_sumexp,
+                    int32_t write_attention, float* score, void* stream);
+
+/* torch.topk(scores, k) (identification_module.py:207): values descending, ties by lower index first.
+ * idx [k] int64, val [k].  Workspace: iff_topk_workspace(N, k). */
+size_t iff_topk_workspace(int64_t N, int32_t k);
+int iff_topk(const float* score, int64_t N, int32_t k, int64_t* idx, float* val, void* workspace,
+             size_t workspace_bytes, void* stream);
+
+/* Per-image pose solve, pose_estimation/test.py:133-174,192-194 with pose_geometry.py:42-95,175-204:
+ * unique-origin filter, LS line intersection, negative exclusion, look-at rotation, NaN/singular -> identity.
+ * idx [k] (indices into rays), val [k]; rays_o, rays_d [N,3]; up_host[3] (normalised inside, test.py:29).
+ * c2w [16] row-major; parts_opt [8 + k] = centre(3), watch(3), n_kept, spare, weights[k] (nullable). */
+int iff_pose_from_topk(const int64_t* idx, const float* val, int32_t k, const float* rays_o, const float* rays_d,
+                       int64_t N, const float* up_host, float* c2w, float* parts_opt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IFFNERF_HIP_H */

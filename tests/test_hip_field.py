@@ -1,0 +1,156 @@
+"""GPU parity: field lookups, Ref head, iso-cell emission and the march, HIP (through the C ABI) vs oracle/golden.
+
+Tolerances (fp32 path; the kernels sum taps and channels in a different order than aten and use the GPU's
+expf/log1pf/powf/sinf): absolute unless noted.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL_FEATURE = 3e-5     # density / appearance features (magnitude up to ~30 -> ~1e-6 relative)
+TOL_ALPHA = 2e-6
+TOL_RGB = 2e-5
+TOL_UNIT = 2e-6        # unit vectors
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def tiny(dev):
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    return field_handle_from_ckpt(util.ckpt("tiny"), dev)
+
+
+@pytest.fixture(scope="module")
+def small(dev):
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    return field_handle_from_ckpt(util.ckpt("small"), dev)
+
+
+def close(got, want, atol, rtol=0.0, what=""):
+    got = torch.as_tensor(got).detach().cpu().float()
+    want = torch.as_tensor(want).float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    torch.testing.assert_close(got, want, atol=atol, rtol=rtol, equal_nan=True, msg=lambda m: f"{what}: {m}")
+
+
+def test_g1_point_lookups(golden, tiny, dev):
+    g = golden["g1_field_points"]
+    x = golden.t("g1_field_points", "xyz").to(dev)
+    xn = tiny.normalize_coord(x)
+    close(xn, g["xn"], 1e-6, what="normalize_coord")
+    xn_ref = golden.t("g1_field_points", "xn").to(dev)
+    close(tiny.density_feature(xn_ref), g["density_feature"], TOL_FEATURE, 2e-6, "density_feature")
+    close(tiny.app_feature(xn_ref), g["app_feature"], TOL_FEATURE, 2e-6, "app_feature")
+    close(tiny.mask_sample(x), g["mask_value"], 1e-6, what="mask")
+    # the boolean the kernels branch on must be identical
+    assert np.array_equal(tiny.mask_sample(x).cpu().numpy() > 0, g["mask_value"] > 0)
+    close(tiny.point_alpha(x, 1.0), g["alpha_len1"], TOL_ALPHA, 2e-6, "alpha(length=1)")
+    close(tiny.point_alpha(x, float(g["step_size"])), g["alpha_len_step"], TOL_ALPHA, 2e-6, "alpha(length=step)")
+
+
+def test_g11_unisphere(golden, dev):
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    g = golden["g11_unisphere"]
+    h = field_handle_from_ckpt(util.ckpt("tiny", contraction_type="unisphere", density_shift=0.0, peak=6.0), dev)
+    x = golden.t("g11_unisphere", "xyz").to(dev)
+    close(h.normalize_coord(x), g["xn"], 2e-6, what="unisphere normalize")
+    close(h.point_alpha(x), g["alpha"], 5e-6, 5e-6, "unisphere alpha")
+    assert np.array_equal(h.mask_sample(x).cpu().numpy() > 0, g["mask_value"] > 0)
+
+
+def test_g3_ref_head(golden, tiny, dev):
+    g = golden["g3_ref_head"]
+    rgb = tiny.ref_shade(golden.t("g3_ref_head", "dirs").to(dev), golden.t("g3_ref_head", "feat").to(dev))
+    close(rgb, g["rgb"], TOL_RGB, what="Ref.forward")
+    close(tiny.head_normals(golden.t("g3_ref_head", "feat").to(dev)), g["normals"], TOL_UNIT, what="compute_normals")
+
+
+def test_g4_g5_emit(golden, small, dev):
+    from iffnerf_amd.hip_field import isocell_emit
+    g4, g5 = golden["g4_isocell"], golden["g5_emit"]
+    iso = golden.t("g4_isocell", "iso")
+    n4 = golden.t("g4_isocell", "normals").to(dev)
+    ori, dirs = isocell_emit(iso, torch.zeros_like(n4), n4)
+    rot = torch.from_numpy(g4["rotated"])
+    want = rot / torch.linalg.norm(rot, dim=-1, keepdim=True)      # sampling.py:455-457 renormalises
+    close(dirs.view(-1, 27, 3)[2:], want[2:], TOL_UNIT, what="rotate_isocell")
+    assert torch.isnan(dirs.view(-1, 27, 3)[0]).all()                 # -normal == +z: the reference yields NaN too
+    # normals and the 27-ray fan on fixed surface samples
+    s = golden.t("g5_emit", "samples").to(dev)
+    nrm = small.point_normals(s)
+    close(nrm, g5["normals"], TOL_UNIT * 5, what="samples_points_normals")
+    ori, dirs = isocell_emit(iso, s, golden.t("g5_emit", "normals").to(dev))
+    close(ori, g5["ori"], 0.0, what="origins")
+    close(dirs, g5["dirs"], TOL_UNIT, what="dirs")
+    rgb, _, _, _, _, _ = small.march(torch.cat([golden.t("g5_emit", "ori"), golden.t("g5_emit", "dirs")], -1).to(dev), 0, 20)
+    close(rgb, g5["rgb"], TOL_RGB, what="ray rgb")
+
+
+def test_g2_march_point(golden, small, dev):
+    g = golden["g2_march_point"]
+    rays = golden.t("g2_march_point", "rays").to(dev)
+    rgb, depth, acc, alpha, counts, S = small.march(rays, 0, 20, want_alpha=True, want_counts=True)
+    assert S == 20
+    close(alpha, g["alpha"], TOL_ALPHA * 5, 5e-6, "alpha")
+    close(acc, g["acc"], 5e-6, what="acc")
+    close(depth, g["depth"], 5e-6, what="depth")
+    close(rgb, g["rgb"], TOL_RGB, what="rgb")
+    # counters agree with the oracle's (valid, shaded) sample counts
+    from oracle import field as ofield
+    f = ofield.field_from_ckpt(util.ckpt("small"))
+    want_counts = ofield.march(f, golden.t("g2_march_point", "rays"), "point", 20)[-1]
+    assert torch.equal(counts.cpu().long(), want_counts.long())
+
+
+def test_g10_march_slab(golden, dev):
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    g = golden["g10_march_slab"]
+    ck = dict(util.ckpt("small"))
+    ck["kwargs"] = dict(ck["kwargs"], near_far=[float(v) for v in g["near_far"]])
+    h = field_handle_from_ckpt(ck, dev)
+    rays = golden.t("g10_march_slab", "rays").to(dev)
+    rgb, depth, acc, alpha, _, S = h.march(rays, 1, -1, want_alpha=True)
+    assert S == int(g["n_samples"])
+    close(acc, g["acc"], 2e-5, what="slab acc")
+    close(depth, g["depth"], 1e-4, what="slab depth")
+    close(alpha.sum(-1), g["alpha_sum"], 1e-4, 1e-5, "slab alpha sum")
+    close(rgb, g["rgb"], 5e-5, what="slab rgb")
+    close(h.march(rays, 1, -1, bg=(1.0, 1.0, 1.0))[0], g["rgb_white"], 5e-5, what="slab rgb white bg")
+
+
+def test_march_edge_cases(small, dev):
+    # empty batch, rays entirely outside, NaN directions (what rotate_isocell emits for normals along z)
+    rgb, depth, acc, alpha, _, _ = small.march(torch.zeros(0, 6, device=dev), 0, 20)
+    assert rgb.shape == (0, 3) and alpha.shape == (0, 20)
+    rays = torch.tensor([[9.0, 9.0, 9.0, 0.0, 0.0, 1.0], [0.0, 0.0, 0.0, float("nan"), float("nan"), float("nan")]], device=dev)
+    rgb, depth, acc, alpha, counts, _ = small.march(rays, 0, 20, want_counts=True)
+    assert torch.equal(rgb.cpu(), torch.zeros(2, 3)) and torch.equal(acc.cpu(), torch.zeros(2))
+    assert torch.equal(counts.cpu(), torch.zeros(2, 2, dtype=torch.int32))
+    # ragged tile sizes (not a multiple of the 16-ray tile) give the same per-ray answers
+    g = torch.Generator().manual_seed(5)
+    r = torch.cat([torch.randn(37, 3, generator=g) * 0.3, torch.nn.functional.normalize(torch.randn(37, 3, generator=g), dim=-1)], -1).to(dev)
+    full = small.march(r, 0, 20)[0]
+    part = small.march(r[:21].contiguous(), 0, 20)[0]
+    assert torch.equal(full[:21], part)
+    with pytest.raises(RuntimeError):
+        small.march(torch.zeros(4, 5, device=dev), 0, 20)
+    with pytest.raises(RuntimeError):
+        small.march(torch.zeros(4, 6), 0, 20)    # CPU tensor: no fallback
+
+
+def test_determinism(small, dev):
+    g = torch.Generator().manual_seed(9)
+    r = torch.cat([torch.randn(5000, 3, generator=g) * 0.4, torch.nn.functional.normalize(torch.randn(5000, 3, generator=g), dim=-1)], -1).to(dev)
+    a = small.march(r, 0, 20)
+    b = small.march(r, 0, 20)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
