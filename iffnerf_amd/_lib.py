@@ -66,6 +66,7 @@ SIGNATURES = {
     "iff_idnet_destroy": (None, [_VP]),
     "iff_ray_encode_workspace": (_SZ, [_VP, _I64]),
     "iff_ray_encode": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ, _VP]),
+    "iff_k_proj": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_q_proj_workspace": (_SZ, [_VP, _I32]),
     "iff_q_proj": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _SZ, _VP]),
     "iff_attn_logits": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _F, _VP, _VP, _VP, _VP]),

@@ -337,6 +337,14 @@ extern "C" int iff_ray_encode(const iff_idnet* n, const float* o, const float* d
     return 0;
 }
 
+extern "C" int iff_k_proj(const iff_idnet* n, const float* ray_features, int64_t N, float* k_out, void* stream) {
+    IFF_REQUIRE(n && N >= 0, "iff_k_proj: bad argument");
+    if (N == 0) return 0;
+    IFF_REQUIRE(ray_features && k_out, "iff_k_proj: null buffer");
+    IFF_HIP(launch_k_proj(n->dev, ray_features, N, k_out, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" size_t iff_q_proj_workspace(const iff_idnet* n, int32_t M) {
     if (!n || M <= 0) return 0;
     return (size_t)M * ((n->dev.img_fea + 15) / 16 * 16) * sizeof(float);

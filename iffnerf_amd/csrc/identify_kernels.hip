@@ -201,6 +201,11 @@ hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, 
     return hipSuccess;
 }
 
+hipError_t launch_k_proj(const IdNetDev& n, const float* feat, int64_t N, float* kout, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    return gemm_nn<false>(feat, n.fea, n.fea, nullptr, 0, 0, n.wk, n.fea, n.bk, kout, n.fea, N, s);
+}
+
 // q_proj: img [M][img_fea=398] -> pad K to 400 through a scratch copy [M][400]
 __global__ void k_pad_rows(const float* __restrict__ src, int cols, float* __restrict__ dst, int cols_pad, int64_t rows) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < rows * cols_pad; t += (int64_t)gridDim.x * blockDim.x) {

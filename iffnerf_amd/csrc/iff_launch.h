@@ -43,6 +43,7 @@ struct IdNetDev {
 size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N);
 hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* feat,
                              float* kout, void* ws, size_t ws_bytes, hipStream_t s);
+hipError_t launch_k_proj(const IdNetDev& n, const float* feat, int64_t N, float* kout, hipStream_t s);
 hipError_t launch_q_proj(const IdNetDev& n, const float* img, int M, float* q, void* scratch, hipStream_t s);
 hipError_t launch_transpose_pad(const float* w_out_in, float* dst_in_out, int out_f, int in_f, int in_pad, int row_off,
                                 hipStream_t s);

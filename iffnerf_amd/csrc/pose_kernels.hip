@@ -7,6 +7,7 @@
 // 3x3 determinant / solve / inverse use LU with partial pivoting like the LAPACK routines behind torch.linalg.
 #include "iff_device.h"
 #include "iff_launch.h"
+#include <cmath>
 
 constexpr int PK_MAX = 1024;
 
@@ -45,8 +46,8 @@ __device__ inline void lu3_solve(const Lu3& f, const float b[3], float x[3]) {
 
 __global__ void __launch_bounds__(256) k_pose(const int64_t* __restrict__ idx, const float* __restrict__ val, int k,
                                               const float* __restrict__ rays_o, const float* __restrict__ rays_d, int64_t N,
-                                              float up0, float up1, float up2, float* __restrict__ c2w,
-                                              float* __restrict__ parts) {
+                                              float up0, float up1, float up2, int isin_direct_limit,
+                                              float* __restrict__ c2w, float* __restrict__ parts) {
     __shared__ float so[PK_MAX][3], sd[PK_MAX][3], sw[PK_MAX];
     __shared__ unsigned char once[PK_MAX], keep[PK_MAX];
     __shared__ float red[256][12];
@@ -68,13 +69,29 @@ __global__ void __launch_bounds__(256) k_pose(const int64_t* __restrict__ idx, c
         once[i] = (cnt == 1);
     }
     __syncthreads();
-    // torch.isin(origins, scalars of once-rows).any(dim=1)
+    // torch.isin(origins, scalars of once-rows, assume_unique=True).any(dim=1), test.py:134-136.
+    // aten picks between two algorithms (TensorCompare.cpp isin_Tensor_Tensor_out): a direct membership test when the
+    // test set is small, else a stable-sort scan that -- because assume_unique=True is passed although the 3k scalars
+    // are NOT unique -- also flags every scalar that has an equal scalar LATER in the flattened [k,3] array.  Both
+    // behaviours are reproduced so the kept set equals the reference's.
+    __shared__ int n_once_s;
+    if (tid == 0) {
+        int c = 0;
+        for (int j = 0; j < k; ++j) c += once[j];
+        n_once_s = c;
+    }
+    __syncthreads();
+    const bool sort_mode = !(3 * n_once_s < isin_direct_limit);
     for (int i = tid; i < k; i += 256) {
         bool hit = false;
-        for (int j = 0; j < k && !hit; ++j) {
-            if (!once[j]) continue;
-            for (int c = 0; c < 3; ++c)
-                for (int e = 0; e < 3; ++e) hit = hit || (so[i][c] == so[j][e]);
+        for (int c = 0; c < 3 && !hit; ++c) {
+            const float v = so[i][c];
+            for (int j = 0; j < k && !hit; ++j) {
+                if (once[j]) hit = (v == so[j][0]) || (v == so[j][1]) || (v == so[j][2]);
+                if (sort_mode && !hit) {
+                    for (int e = 0; e < 3; ++e) hit = hit || ((3 * j + e > 3 * i + c) && (v == so[j][e]));
+                }
+            }
         }
         keep[i] = hit;
     }
@@ -200,6 +217,8 @@ __global__ void __launch_bounds__(256) k_pose(const int64_t* __restrict__ idx, c
 hipError_t launch_pose(const int64_t* idx, const float* val, int k, const float* rays_o, const float* rays_d, int64_t N,
                        const float* up3, float* c2w, float* parts, hipStream_t s) {
     if (k < 1 || k > PK_MAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_pose, dim3(1), dim3(256), 0, s, idx, val, k, rays_o, rays_d, N, up3[0], up3[1], up3[2], c2w, parts);
+    // aten's heuristic (taken from numpy): direct membership test iff n_test < 10 * n_elements^0.145
+    const int lim = (int)(int64_t)(10.0f * std::pow((double)(3 * k), 0.145));
+    hipLaunchKernelGGL(k_pose, dim3(1), dim3(256), 0, s, idx, val, k, rays_o, rays_d, N, up3[0], up3[1], up3[2], lim, c2w, parts);
     return hipGetLastError();
 }

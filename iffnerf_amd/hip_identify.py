@@ -1,0 +1,155 @@
+"""Python owner of an ``iff_idnet`` handle (ray encoder + q/k projections) and wrappers for stage C.
+
+Tensor allocation and streams come from PyTorch-ROCm; the arithmetic (fp32 MFMA GEMMs, softmax statistics,
+column sums, top-k, pose solve) happens in libiffnerf_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, fvec, stream_ptr
+
+_KEYS = (("l1", "ray_preprocessor.mlp.0"), ("l2", "ray_preprocessor.mlp.2"), ("l3", "ray_preprocessor.mlp2.0"),
+         ("l4", "ray_preprocessor.mlp2.2"), ("q", "attention.q_proj"), ("k", "attention.k_proj"))
+
+
+def _gpu(t: torch.Tensor, name: str, cols: Optional[int] = None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); libiffnerf_hip has no CPU path")
+    t = t.detach().to(torch.float32)
+    if cols is not None:
+        t = t.reshape(-1, cols)
+    return t.contiguous()
+
+
+class IdNetHandle:
+    """Weights of RayPreprocessor + MultiHeadAttention, transposed/padded once for the MFMA GEMMs."""
+
+    def __init__(self, weights: Dict[str, torch.Tensor], device):
+        self._h = None
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"IdNetHandle needs a GPU device (got {device}); libiffnerf_hip has no CPU path")
+        self.device = device
+        d = _lib.IdNetDesc()
+        keep = []
+        for short, key in _KEYS:
+            for suffix, field in ((".weight", "_w"), (".bias", "_b")):
+                t = weights[key + suffix].detach().to(device=device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                setattr(d, short + field, t.data_ptr())
+        self.feature_c = int(weights["ray_preprocessor.mlp.0.weight"].shape[0])
+        self.fea = int(weights["ray_preprocessor.mlp2.2.weight"].shape[0])
+        self.img_fea = int(weights["attention.q_proj.weight"].shape[1])
+        if int(weights["ray_preprocessor.mlp.0.weight"].shape[1]) != 141:
+            raise RuntimeError("ray encoder input width must be 141 (pospe=8, viewpe=8, rgbpe=6)")
+        d.feature_c, d.fea, d.img_fea = self.feature_c, self.fea, self.img_fea
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            check(_lib.lib().iff_idnet_create(C.byref(d), stream_ptr(device), C.byref(out)), "iff_idnet_create")
+        self._h = out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().iff_idnet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ K5
+    def ray_encode(self, o, d, rgb, want_features: bool = True, want_k: bool = False):
+        """RayPreprocessor.forward (+ k_proj when want_k) -> (features|None, k|None)."""
+        o, d, rgb = _gpu(o, "rays_ori", 3), _gpu(d, "rays_dir", 3), _gpu(rgb, "rays_rgb", 3)
+        N = o.shape[0]
+        if d.shape[0] != N or rgb.shape[0] != N:
+            raise RuntimeError("rays_ori / rays_dir / rays_rgb must have the same number of rows")
+        L = _lib.lib()
+        feat = o.new_empty(N, self.fea) if want_features else None
+        k = o.new_empty(N, self.fea) if want_k else None
+        ws_bytes = int(L.iff_ray_encode_workspace(self._h, N))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=o.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_ray_encode(self._h, dptr(o), dptr(d), dptr(rgb), N, dptr(feat), dptr(k), ws.data_ptr(), ws_bytes,
+                                   stream_ptr(self.device)), "iff_ray_encode")
+        return feat, k
+
+    def k_proj(self, ray_features):
+        """k_proj alone, for MultiHeadAttention called with already-encoded rays."""
+        x = _gpu(ray_features, "ray_features", self.fea)
+        k = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().iff_k_proj(self._h, dptr(x), x.shape[0], dptr(k), stream_ptr(self.device)), "iff_k_proj")
+        return k
+
+    def q_proj(self, img_features):
+        x = _gpu(img_features, "img_features", self.img_fea)
+        M = x.shape[0]
+        L = _lib.lib()
+        q = x.new_empty(M, self.fea)
+        ws_bytes = int(L.iff_q_proj_workspace(self._h, M))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_q_proj(self._h, dptr(x), M, dptr(q), ws.data_ptr(), ws_bytes, stream_ptr(self.device)), "iff_q_proj")
+        return q
+
+
+def attn_logits(q: torch.Tensor, k: torch.Tensor, want_stats: bool = True):
+    """logits = q k^T / sqrt(d) and the per-row softmax statistics (max, sum exp)."""
+    q, k = _gpu(q, "q"), _gpu(k, "k")
+    M, D = q.shape
+    N = k.shape[0]
+    logits = q.new_empty(M, N)
+    rmax = q.new_empty(M) if want_stats else None
+    rsum = q.new_empty(M) if want_stats else None
+    with torch.cuda.device(q.device):
+        check(_lib.lib().iff_attn_logits(dptr(q), dptr(k), M, N, D, float(math.sqrt(D)), dptr(logits), dptr(rmax), dptr(rsum),
+                                         stream_ptr(q.device)), "iff_attn_logits")
+    return logits, rmax, rsum
+
+
+def attn_colsum(logits: torch.Tensor, row_max: torch.Tensor, row_sumexp: torch.Tensor, write_attention: bool = True):
+    """In place: logits -> attention (when write_attention); returns score[N] = column sums of the attention."""
+    M, N = logits.shape
+    score = logits.new_empty(N)
+    with torch.cuda.device(logits.device):
+        check(_lib.lib().iff_attn_colsum(dptr(logits), M, N, dptr(row_max), dptr(row_sumexp), int(write_attention),
+                                         dptr(score), stream_ptr(logits.device)), "iff_attn_colsum")
+    return score
+
+
+def topk(score: torch.Tensor, k: int):
+    s = _gpu(score, "scores").reshape(-1)
+    N = s.shape[0]
+    if k > N:
+        raise RuntimeError(f"selected index k out of range (k={k}, N={N})")   # torch.topk raises RuntimeError too
+    idx = torch.empty(k, dtype=torch.int64, device=s.device)
+    val = s.new_empty(k)
+    with torch.cuda.device(s.device):
+        check(_lib.lib().iff_topk(dptr(s), N, k, dptr(idx, torch.int64), dptr(val), None, 0, stream_ptr(s.device)), "iff_topk")
+    return idx, val
+
+
+def pose_from_topk(idx, val, rays_o, rays_d, model_up, want_parts: bool = False):
+    """Per-image pose solve of pose_estimation/test.py:133-174 on the GPU -> c2w [4,4] (device tensor)."""
+    idx = idx.detach().to(torch.int64).contiguous()
+    val = _gpu(val, "weights").reshape(-1)
+    o, d = _gpu(rays_o, "rays_ori", 3), _gpu(rays_d, "rays_dirs", 3)
+    if not idx.is_cuda:
+        raise RuntimeError("idx must live on the GPU; libiffnerf_hip has no CPU path")
+    k = idx.shape[0]
+    c2w = o.new_empty(4, 4)
+    parts = o.new_empty(8 + k) if want_parts else None
+    up = fvec(torch.as_tensor(model_up).detach().cpu().reshape(-1).tolist())
+    with torch.cuda.device(o.device):
+        check(_lib.lib().iff_pose_from_topk(dptr(idx, torch.int64), dptr(val), k, dptr(o), dptr(d), o.shape[0], up, dptr(c2w),
+                                            dptr(parts), stream_ptr(o.device)), "iff_pose_from_topk")
+    return (c2w, parts) if want_parts else c2w

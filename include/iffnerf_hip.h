@@ -163,6 +163,8 @@ void iff_idnet_destroy(iff_idnet* net);
 size_t iff_ray_encode_workspace(const iff_idnet* net, int64_t N);
 int iff_ray_encode(const iff_idnet* net, const float* o, const float* d, const float* rgb, int64_t N,
                    float* feat_opt, float* k_out, void* workspace, size_t workspace_bytes, void* stream);
+/* k_proj alone (multihead_attention.py:61), for callers that hold encoded rays.  ray_features [N,fea] -> k [N,fea] */
+int iff_k_proj(const iff_idnet* net, const float* ray_features, int64_t N, float* k_out, void* stream);
 /* q_proj (multihead_attention.py:60).  img [M,img_fea] -> q [M,fea].  Workspace: iff_q_proj_workspace(net, M). */
 size_t iff_q_proj_workspace(const iff_idnet* net, int32_t M);
 int iff_q_proj(const iff_idnet* net, const float* img, int32_t M, float* q, void* workspace, size_t workspace_bytes,
