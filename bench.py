@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- poses/sec of the IFFNeRF per-query hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1: plain process; N > 1: launched by torch.distributed.run)
+
+Step = one pass of the hot path over one batch of synthetic queries, COLD: every step re-runs stage A (device-side
+surface sampler + normals + 27-ray fans), stage B (20-sample VM march + Ref shading of every ray) and stage C (ray
+encoder + k_proj, q_proj, softmax over rays, column-sum score, top-100, closed-form pose).  Nothing is cached between
+steps except the model tables; the ray encoder is recomputed per step as the reference does per image
+(pose_estimation/identification_module.py:164).  Workload at N = 1 is BASELINE.json configs[1]: "lego 800x800, 16k
+candidate rays": a synthetic lego-shaped TensorVMSplit (300^3 grid, 16/48 components, 180^3 mask), gen_points = 593 ->
+16 011 rays, one query of M = 256 image tokens (the 800x800 image only feeds the out-of-path DINOv2 front end).
+At N > 1 the same ray set is sharded over the ranks (contiguous blocks of surface points) and each step processes N
+queries (weak scaling: one more query per step per GPU), with the two RCCL all_gathers of iffnerf_amd/distributed.py.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel (measured live
+with events on the launch stream) and `cpu_baseline` (the oracle, i.e. the reference's PyTorch-CPU op chain, timed on
+this box's host cores on a bounded sample: one cold pose at the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GEN_POINTS = 593          # -> 16 011 rays (27 per surface point)
+M_TOKENS = 256
+TOPK = 100
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# march: algorithmic bytes per ray = 36 + valid*1184 + shaded*3456
+B_RAY, B_VALID, B_APP = 36, 32 + 1152, 3456
+
+
+def build_inputs(device):
+    from iffnerf_amd import synthetic
+    from iffnerf_amd.pipeline import PosePipeline
+    ck = synthetic.make_field_ckpt(grid=(300, 300, 300), mask_res=(180, 180, 180), seed=1234, step_ratio=0.5, peak=20.0)
+    idw = synthetic.make_id_weights(seed=99)
+    pipe = PosePipeline.from_checkpoints(ck, idw, device, model_up=(0.0, 0.0, 1.0))
+    return ck, idw, pipe
+
+
+def cpu_baseline(ck, idw, tokens_cpu, max_seconds=40.0):
+    """Reference CPU path (oracle = the reference's op chain on torch-CPU) on ONE cold pose of the same workload."""
+    from oracle import emit as oemit, field as ofield, identify as oid, pose as opose
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    f = ofield.field_from_ckpt(ck)
+    torch.manual_seed(55176280)
+    t0 = time.perf_counter()
+    n = 0
+    stage = {}
+    while True:
+        ta = time.perf_counter()
+        o, d, c = oemit.explore_model(f, gen_points=GEN_POINTS)
+        tb = time.perf_counter()
+        idx, val, _, _ = oid.test_image(idw, tokens_cpu, o, d, c, TOPK)
+        opose.pose_from_topk(idx, val, o, d, torch.tensor([0.0, 0.0, 1.0]))
+        tc = time.perf_counter()
+        n += 1
+        stage = {"emit_s": tb - ta, "identify_pose_s": tc - tb}
+        if tc - t0 > 10.0 or n >= 3 or (tc - t0) + (tc - ta) > max_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "poses/s", "cores": threads, "kind": "port",
+            "sample": f"{n} cold pose(s) of the same workload (gen_points={GEN_POINTS}, 16011 rays, M={M_TOKENS}); "
+                      f"last: emission {stage['emit_s']:.2f} s, identification+pose {stage['identify_pose_s']:.3f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world_size})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from iffnerf_amd import synthetic
+    ck, idw, pipe = build_inputs(device)
+    Q = world_size
+    tokens = torch.stack([synthetic.make_tokens(M_TOKENS, 384, seed=7 + q) for q in range(Q)]).to(device)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    def step(i):
+        if world_size == 1:
+            return pipe.query(tokens[0], GEN_POINTS, seed=1000 + i, k=TOPK)[0]
+        return pipe.query_sharded(tokens, GEN_POINTS, seed=1000 + i, k=TOPK)[0]
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world_size > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out).all()
+
+    result = None
+    if rank == 0:
+        # ---- per-stage and dominant-kernel timing with events on the launch stream (outside the timed region)
+        ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+        n_rep = 20
+        stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "encode_kproj": 0.0, "attention_topk_pose": 0.0}
+        march_bytes = 0.0
+        from iffnerf_amd import hip_identify as H
+        from iffnerf_amd.hip_field import isocell_emit
+        for r in range(n_rep):
+            e = [ev() for _ in range(6)]
+            e[0].record()
+            samples, _, _ = pipe.field.surface_sample(GEN_POINTS, pipe.rho, 4, 200, seed=5000 + r)
+            e[1].record()
+            normals = pipe.field.point_normals(samples)
+            ori, dirs = isocell_emit(pipe.cells, samples, normals)
+            rays = torch.cat((ori, dirs), dim=-1)
+            e[2].record()
+            rgb = pipe.field.march(rays, 0, 20, want_alpha=False)[0]
+            e[3].record()
+            _, kmat = pipe.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
+            e[4].record()
+            logits, rmax, rsum = H.attn_logits(pipe.idnet.q_proj(tokens[0]), kmat)
+            score = H.attn_colsum(logits, rmax, rsum, write_attention=True)
+            idx, val = H.topk(score, TOPK)
+            H.pose_from_topk(idx, val, ori, dirs, pipe.model_up)
+            e[5].record()
+            torch.cuda.synchronize(device)
+            for name, a, b in zip(stage_ms, e[:-1], e[1:]):
+                stage_ms[name] += a.elapsed_time(b) / n_rep
+            counts = pipe.field.march(rays, 0, 20, want_alpha=False, want_counts=True)[4].double().sum(0)
+            march_bytes += (rays.shape[0] * B_RAY + counts[0].item() * B_VALID + counts[1].item() * B_APP) / n_rep
+        march_gbs = march_bytes / (stage_ms["march"] * 1e-3) / 1e9
+        roofline = {"kernel": "k4_march (march_composite_shade)", "bound": "hbm", "achieved": round(march_gbs, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(march_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": round(march_bytes), "avg_launch_ms": round(stage_ms["march"], 4)}
+        # warm path (rays resident, the reference's eval semantics): stage C only
+        ori, dirs, rgb = pipe.emit(GEN_POINTS, seed=42)
+        for _ in range(5):
+            pipe.identify(tokens[0], ori, dirs, rgb, TOPK)
+        torch.cuda.synchronize(device)
+        tw = time.perf_counter()
+        for _ in range(50):
+            pipe.identify(tokens[0], ori, dirs, rgb, TOPK)
+        torch.cuda.synchronize(device)
+        warm = 50 / (time.perf_counter() - tw)
+        result = {
+            "metric": "poses/sec (800x800 query, lego TensoRF)", "value": round(Q * args.steps / dt, 3), "unit": "poses/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "lego-shaped TensorVMSplit 300^3 (16/48 comps, 180^3 mask), gen_points=593 -> 16011 rays, "
+                                   "M=256 tokens, top-100, cold path (A+B+C every step)",
+                       "queries_per_step": Q, "rays_total": GEN_POINTS * 27,
+                       "parallelism": "single GPU" if world_size == 1 else f"rays sharded over {world_size} ranks + 2 all_gathers"},
+            "warm_poses_per_s": round(warm, 2),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": roofline,
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(ck, idw, tokens[0].cpu())
+        else:
+            result["cpu_baseline"] = None
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+"""iffnerf_amd -- MI355X-native implementation of IFFNeRF's per-query inference hot path.
+
+Layout
+  csrc/ + libiffnerf_hip.so   hand-written HIP kernels for gfx950 behind the C ABI of include/iffnerf_hip.h
+  _lib.py, hip_field.py, hip_identify.py   ctypes binding and handle owners (PyTorch-ROCm supplies memory/streams)
+  models/, pose_estimation/, renderer.py   host-side mirror of the reference's module paths and call signatures
+  synthetic.py                seeded synthetic checkpoints (no pretrained weights are available offline)
+  distributed.py              ray sharding over torch.distributed (RCCL) for multi-GPU runs
+
+``install()`` registers the mirror under the reference's top-level module names (``models``, ``renderer``,
+``pose_estimation``) so the reference driver imports it unchanged; see INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+
+__version__ = "0.1.0"
+
+_ALIASES = {
+    "models": "iffnerf_amd.models",
+    "models.tensorBase": "iffnerf_amd.models.tensorBase",
+    "models.tensoRF": "iffnerf_amd.models.tensoRF",
+    "models.ref": "iffnerf_amd.models.ref",
+    "renderer": "iffnerf_amd.renderer",
+    "pose_estimation": "iffnerf_amd.pose_estimation",
+    "pose_estimation.model_utils": "iffnerf_amd.pose_estimation.model_utils",
+    "pose_estimation.sampling": "iffnerf_amd.pose_estimation.sampling",
+    "pose_estimation.isocell": "iffnerf_amd.pose_estimation.isocell",
+    "pose_estimation.ray_preprocessor": "iffnerf_amd.pose_estimation.ray_preprocessor",
+    "pose_estimation.multihead_attention": "iffnerf_amd.pose_estimation.multihead_attention",
+    "pose_estimation.identification_module": "iffnerf_amd.pose_estimation.identification_module",
+    "pose_estimation.backbone": "iffnerf_amd.pose_estimation.backbone",
+    "pose_estimation.pose_geometry": "iffnerf_amd.pose_estimation.pose_geometry",
+    "pose_estimation.errors": "iffnerf_amd.pose_estimation.errors",
+    "pose_estimation.test": "iffnerf_amd.pose_estimation.test",
+}
+
+
+def install(force: bool = False) -> None:
+    """Make ``import models.tensoRF`` / ``import pose_estimation.sampling`` ... resolve to this package."""
+    for alias, target in _ALIASES.items():
+        if alias in sys.modules and not force:
+            continue
+        sys.modules[alias] = importlib.import_module(target)

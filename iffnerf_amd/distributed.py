@@ -1,0 +1,88 @@
+"""Ray sharding across GPUs: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+The reference is single-process.  Rays are independent everywhere except in the softmax over
+the ray axis and the global top-k, so each rank keeps a contiguous block of the surface points (hence of 27-ray fans)
+and the path needs exactly two small exchanges per batch of queries:
+
+  1. per-row softmax statistics (max, sum-exp): ``all_gather`` of [Q*M, 2] floats per rank, merged in rank order
+     (deterministic) -- after it every rank normalises its own logits columns with the GLOBAL statistics, so its
+     column-sum scores are exactly the scores the single-GPU path gives those rays;
+  2. per-query local top-k (value, global ray index, origin, direction): ``all_gather`` of [Q, k, 8] floats per rank,
+     reduced to the global top-k with the single-GPU tie rule (higher value first, lower index on ties).
+
+Both messages are a few KB: latency-bound, no bandwidth tuning needed.  The functions below contain only the exchange
+and merge logic on small tensors and are device-agnostic, so the world_size-2 ``gloo`` tests on CPU exercise the very
+code the GPU ranks run; the heavy local work is passed in by the caller (HIP on the GPU, the oracle in those tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_points(n_points: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of surface points owned by ``rank`` (sizes differ by at most one)."""
+    base, extra = divmod(n_points, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
+    rank, ws = world(group)
+    if ws == 1:
+        return t[None]
+    out = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return torch.stack(out)
+
+
+def merge_row_stats(row_max: torch.Tensor, row_sumexp: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Local (max_i, sum_j exp(l_ij - max_i)) over this rank's columns -> the same statistics over all columns."""
+    both = _all_gather_stack(torch.stack((row_max, row_sumexp), dim=-1), group)      # [G, R, 2]
+    gmax = both[..., 0].max(dim=0).values
+    gsum = torch.zeros_like(gmax)
+    for r in range(both.shape[0]):                                                    # fixed rank order: reproducible
+        gsum = gsum + both[r, :, 1] * torch.exp(both[r, :, 0] - gmax)
+    return gmax, gsum
+
+
+def merge_topk(local_val: torch.Tensor, local_idx: torch.Tensor, payload: torch.Tensor, k: int, group=None):
+    """Per-rank candidates -> global top-k.
+
+    local_val [Q,kl] scores (pad with -inf), local_idx [Q,kl] GLOBAL ray indices (int64), payload [Q,kl,C] per-ray data
+    that must travel with the winners (origin, direction).  Returns (val [Q,k], idx [Q,k], payload [Q,k,C]) ordered by
+    value descending, lower global index first on ties -- the order ``iff_topk`` produces on one GPU.
+    """
+    vals = _all_gather_stack(local_val, group)                     # [G,Q,kl]
+    idxs = _all_gather_stack(local_idx, group)
+    pays = _all_gather_stack(payload, group)                       # [G,Q,kl,C]
+    G, Q, kl = vals.shape
+    vals = vals.permute(1, 0, 2).reshape(Q, G * kl)
+    idxs = idxs.permute(1, 0, 2).reshape(Q, G * kl)
+    pays = pays.permute(1, 0, 2, 3).reshape(Q, G * kl, -1)
+    by_idx = torch.argsort(idxs, dim=1, stable=True)               # secondary key first ...
+    v1 = torch.gather(vals, 1, by_idx)
+    by_val = torch.argsort(v1, dim=1, descending=True, stable=True)    # ... then the stable primary sort
+    order = torch.gather(by_idx, 1, by_val)[:, :k]
+    return (torch.gather(vals, 1, order), torch.gather(idxs, 1, order),
+            torch.gather(pays, 1, order[..., None].expand(-1, -1, pays.shape[-1])))
+
+
+def gather_scores(local_score: torch.Tensor, counts, group=None) -> torch.Tensor:
+    """Optional: the full score vector [Q, N_total] on every rank (what the reference returns as ``scores``)."""
+    rank, ws = world(group)
+    if ws == 1:
+        return local_score
+    width = max(counts)
+    padded = local_score.new_zeros(local_score.shape[0], width)
+    padded[:, :local_score.shape[1]] = local_score
+    allp = _all_gather_stack(padded, group)
+    return torch.cat([allp[r, :, :counts[r]] for r in range(ws)], dim=1)

@@ -1,0 +1,96 @@
+"""The per-query hot path as one object: emission (A+B) and identification + pose (C) over the C ABI.
+
+``PosePipeline`` is what ``bench.py``, ``__graft_entry__.smoke()`` and the multi-GPU path drive.  It is the same
+sequence the mirrored reference API runs (``explore_model`` -> ``IdentificationModule.test_image`` ->
+``test_pose_estimation`` body), without the nn.Module wrappers: handles in, device tensors out, no host
+synchronisation anywhere in ``emit`` / ``identify`` / ``query``.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import hip_identify as H
+from .hip_field import FieldHandle, field_handle_from_ckpt, isocell_emit
+from .pose_estimation.isocell import isocell_distribution
+
+
+def jitter_scale_from_kwargs(kw: dict) -> float:
+    """rho of reference pose_estimation/sampling.py:518-521 from checkpoint kwargs (mask present)."""
+    g = torch.tensor([int(v) for v in kw["gridSize"]], dtype=torch.long)
+    aabb = torch.as_tensor(kw["aabb"]).float().cpu()
+    return float((torch.max(g) * 0.1) * torch.max((aabb[1] - aabb[0]) / g))
+
+
+class PosePipeline:
+    def __init__(self, field: FieldHandle, idnet: H.IdNetHandle, rho: float, model_up=(0.0, 0.0, 1.0)):
+        self.field, self.idnet, self.rho = field, idnet, float(rho)
+        self.model_up = torch.as_tensor(model_up, dtype=torch.float32).cpu()
+        self.cells = isocell_distribution(27, torch.float32, "cpu")
+        self.device = field.device
+
+    @classmethod
+    def from_checkpoints(cls, field_ckpt: dict, id_weights: Dict[str, torch.Tensor], device, model_up=(0.0, 0.0, 1.0)):
+        return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device),
+                   jitter_scale_from_kwargs(field_ckpt["kwargs"]), model_up)
+
+    # ------------------------------------------------------------------ stage A + B  (explore_model)
+    def emit(self, gen_points: int, seed: int, point_range: Optional[Tuple[int, int]] = None):
+        """-> (ori [27P,3], dirs [27P,3], rgb [27P,3]).  ``point_range`` keeps a contiguous block of the surface points
+        (ray sharding across GPUs: every rank draws the same samples from the same seed and colours only its block)."""
+        samples, _, stats = self.field.surface_sample(gen_points, self.rho, n_epochs=4, max_iterations=200, seed=seed)
+        if point_range is not None:
+            samples = samples[point_range[0]:point_range[1]].contiguous()
+        normals = self.field.point_normals(samples)
+        ori, dirs = isocell_emit(self.cells, samples, normals)
+        rgb = self.field.march(torch.cat((ori, dirs), dim=-1), 0, 20, want_alpha=False)[0]
+        self.last_sampler_stats = stats
+        return ori, dirs, rgb
+
+    # ------------------------------------------------------------------ stage C  (test_image + pose solve)
+    def scores(self, tokens, ori, dirs, rgb, materialize_map: bool = True):
+        _, k = self.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
+        logits, rmax, rsum = H.attn_logits(self.idnet.q_proj(tokens), k)
+        score = H.attn_colsum(logits, rmax, rsum, write_attention=materialize_map)
+        return score, logits
+
+    def identify(self, tokens, ori, dirs, rgb, k: int = 100, materialize_map: bool = True):
+        score, _ = self.scores(tokens, ori, dirs, rgb, materialize_map)
+        idx, val = H.topk(score, k)
+        return H.pose_from_topk(idx, val, ori, dirs, self.model_up), idx, val
+
+    def query(self, tokens, gen_points: int, seed: int, k: int = 100):
+        """Cold per-query path: emission + identification + pose."""
+        ori, dirs, rgb = self.emit(gen_points, seed)
+        return self.identify(tokens, ori, dirs, rgb, k)
+
+    # ------------------------------------------------------------------ ray-sharded batch of queries (multi-GPU)
+    def query_sharded(self, tokens, gen_points: int, seed: int, k: int = 100, group=None, materialize_map: bool = True):
+        """``tokens`` [Q,M,C+14]: Q query images against ONE emitted ray set whose surface points are sharded over the
+        ranks of ``group``.  Every rank returns the Q poses [Q,4,4] (identical on all ranks) and the global top-k
+        (values [Q,k], global ray indices [Q,k]).  With one rank this is ``query`` for each image."""
+        from . import distributed as D
+        rank, ws = D.world(group)
+        Q, M, C = tokens.shape
+        lo, hi = D.shard_points(gen_points, rank, ws)
+        ori, dirs, rgb = self.emit(gen_points, seed, (lo, hi) if ws > 1 else None)
+        n_local = ori.shape[0]
+        _, kmat = self.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
+        logits, rmax, rsum = H.attn_logits(self.idnet.q_proj(tokens.reshape(Q * M, C)), kmat)
+        gmax, gsum = D.merge_row_stats(rmax, rsum, group)
+        kl = min(k, n_local)
+        lval = ori.new_full((Q, k), float("-inf"))
+        lidx = torch.full((Q, k), 2 ** 62, dtype=torch.int64, device=ori.device)
+        pay = ori.new_zeros(Q, k, 6)
+        for q in range(Q):
+            sl = slice(q * M, (q + 1) * M)
+            score = H.attn_colsum(logits[sl], gmax[sl].contiguous(), gsum[sl].contiguous(), write_attention=materialize_map)
+            i, v = H.topk(score, kl)
+            lval[q, :kl], lidx[q, :kl] = v, i + lo * 27
+            pay[q, :kl, :3], pay[q, :kl, 3:] = ori[i], dirs[i]
+        val, idx, pay = D.merge_topk(lval, lidx, pay, k, group)
+        ar = torch.arange(k, device=ori.device)
+        poses = torch.stack([H.pose_from_topk(ar, val[q].contiguous(), pay[q, :, :3].contiguous(),
+                                              pay[q, :, 3:].contiguous(), self.model_up) for q in range(Q)])
+        return poses, val, idx
