@@ -50,7 +50,9 @@ def build_inputs(device):
 def cpu_baseline(ck, idw, tokens_cpu, max_seconds=40.0):
     """Reference CPU path (oracle = the reference's op chain on torch-CPU) on ONE cold pose of the same workload."""
     from oracle import emit as oemit, field as ofield, identify as oid, pose as opose
-    threads = os.cpu_count() or 1
+    # the box's CPU share for one GPU is 16 cores; torch with one thread per *visible* core (256 here) is an order of
+    # magnitude slower on this op mix (thread fan-out on small tensors), which would flatter the GPU number
+    threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     f = ofield.field_from_ckpt(ck)
     torch.manual_seed(55176280)

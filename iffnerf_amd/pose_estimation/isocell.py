@@ -16,17 +16,16 @@ def isocell_distribution(ray_target, dtype, device, N0=3, isrand=-1, int_dtype=t
         raise RuntimeError("isocell_distribution: only the deterministic layout (isrand=-1) is on the IFFNeRF path "
                            "(pose_estimation/sampling.py:229-234)")
     n = int(math.ceil(math.sqrt(ray_target / N0)))
-    xs, ys = [], []
-    for ring in range(1, n + 1):
-        cells = N0 * (2 * ring - 1)
-        dth = torch.tensor(2 * math.pi, dtype=dtype) / torch.tensor(float(cells), dtype=dtype)
-        k = torch.arange(cells, dtype=dtype)
-        theta = k * dth + dth / 2
-        radius = torch.tensor(ring, dtype=torch.int64) * (1 / n) - (1 / n) / 2
-        xs.append(radius * torch.cos(theta))
-        ys.append(radius * torch.sin(theta))
-    x, y = torch.cat(xs), torch.cat(ys)
-    z = torch.sqrt(torch.clamp(1 - x * x - y * y, min=0.0))
+    # one entry per cell: its ring (1-based), the ring's cell count and the cell's position inside the ring.
+    # Tensor ops (not per-ring Python scalars) so the float32 roundings equal the reference's table bit for bit.
+    ring = torch.cat([torch.full((N0 * (2 * r - 1),), r, dtype=int_dtype) for r in range(1, n + 1)])
+    count = N0 * (2 * ring - 1)
+    within = torch.cat([torch.arange(N0 * (2 * r - 1), dtype=int_dtype) for r in range(1, n + 1)]).to(dtype)
+    step = 2 * math.pi / count.to(dtype)
+    theta = (0 + within * step) + step / 2
+    radius = ring * (1 / n) - (1 / n) / 2
+    x, y = radius * torch.cos(theta), radius * torch.sin(theta)
+    z = torch.real(torch.sqrt(1 - torch.square(x.to(torch.complex64)) - torch.square(y.to(torch.complex64))))
     return torch.stack((x, y, z), dim=1).to(device=device, dtype=dtype)
 
 

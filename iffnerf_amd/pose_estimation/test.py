@@ -16,11 +16,12 @@ from .errors import compute_angular_error, compute_translation_error
 
 
 def estimate_pose(id_module, obs_img, mask_img, rays_ori, rays_dirs, rays_rgb, model_up, rays_to_output=100):
-    """One query image -> (c2w [4,4] on the GPU, top-k indices, top-k values, scores)."""
+    """One query image -> (c2w [4,4] on the GPU, solver internals, top-k indices, top-k values, scores)."""
     from .. import hip_identify as H
     idx, weights, scores, _ = id_module.test_image(obs_img, mask_img, rays_ori, rays_dirs, rays_rgb,
                                                    rays_to_output=rays_to_output)
-    return H.pose_from_topk(idx, weights, rays_ori, rays_dirs, model_up), idx, weights, scores
+    c2w, parts = H.pose_from_topk(idx, weights, rays_ori, rays_dirs, model_up, want_parts=True)
+    return c2w, parts, idx, weights, scores
 
 
 def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id="", loss_fn=None,
@@ -41,12 +42,13 @@ def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, mode
             obs = obs[..., :3] * obs[..., -1:] + (1 - obs[..., -1:])
         else:
             mask_img = torch.ones_like(obs[..., -1], dtype=torch.bool)
-        c2w, idx, weights, _ = estimate_pose(id_module, obs, mask_img, rays_ori, rays_dirs, rays_rgb, model_up)
+        c2w, parts, idx, weights, _ = estimate_pose(id_module, obs, mask_img, rays_ori, rays_dirs, rays_rgb, model_up)
         translation_errors.append(compute_translation_error(pose[:3, 3], c2w[:3, 3]).item())
         angular_errors.append(compute_angular_error(pose[:3, :3], c2w[:3, :3]).item())
+        kept = parts[8:][parts[8:] >= 0]           # weights after exclusion of the rays that survived the origin filter
         results.append({
             "sequence_id": sequence_id, "category_name": "id_net", "frame_id": img_idx,
-            "loss": float("nan"), "scores_loss": -1.0, "recall": -1.0, "total_optimization_time_in_ms": 0.0,
+            "loss": kept.mean().item(), "scores_loss": -1.0, "recall": -1.0, "total_optimization_time_in_ms": 0.0,
             "pred_c2w": c2w.cpu().tolist(), "gt_c2w": pose.cpu().tolist(),
         })
     per_image = (time.time() - start) / max(n_images, 1)

@@ -1,0 +1,79 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/iffnerf_hip.h declares, and fails loudly.
+
+No compute call is made here (there is no GPU in the authoring container).
+"""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "iffnerf_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(iff_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from iffnerf_amd import _lib, build
+    build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/iffnerf_hip.h but not exported"
+    # the ctypes table binds exactly the declared surface
+    assert sorted(_lib.SIGNATURES) == names
+    bound = _lib.lib()
+    assert bound.iff_abi_version() == 1
+    assert bound.iff_last_error() == b""
+
+
+def test_header_cites_the_reference_for_every_entry_point():
+    text = open(HEADER).read()
+    for name in declared_functions():
+        if name in ("iff_last_error", "iff_abi_version", "iff_field_destroy", "iff_idnet_destroy", "iff_field_table_bytes",
+                    "iff_surface_sample_workspace", "iff_ray_encode_workspace", "iff_q_proj_workspace", "iff_topk_workspace"):
+            continue
+        pos = text.index(name + "(")
+        block = text[max(0, pos - 1500):pos]
+        assert re.search(r"\.py:\d+", block), f"{name}: no reference file:line citation above its declaration"
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from iffnerf_amd import _lib
+    L = _lib.lib()
+    assert L.iff_topk(None, 10, 3, None, None, None, 0, None) != 0
+    assert b"null" in L.iff_last_error()
+    assert L.iff_march_shade(None, None, 6, 4, 0, 20, None, None, None, None, None, None, None) != 0
+    with pytest.raises(RuntimeError):
+        _lib.check(L.iff_attn_logits(None, None, 4, 4, 7, 1.0, None, None, None, None), "iff_attn_logits")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from iffnerf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libiffnerf_hip.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_rejected_not_served():
+    """There is no CPU path: handing the product CPU tensors raises instead of silently computing on the host."""
+    import torch
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.hip_field import FieldHandle, isocell_emit
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        H.attn_logits(torch.zeros(2, 16), torch.zeros(3, 16))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        H.topk(torch.zeros(8), 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        isocell_emit(torch.zeros(27, 3), torch.zeros(2, 3), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FieldHandle.head_only({}, "cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        H.IdNetHandle({}, "cpu")

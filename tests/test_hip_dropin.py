@@ -1,0 +1,114 @@
+"""GPU: the mirrored reference API end to end (module paths, classes and call order of train_eval_pose_est.py).
+
+load_model -> explore_model -> IdentificationModule.test_image -> test_pose_estimation, with a fake backbone standing in
+for DINOv2 exactly as the golden harness did when it ran the real reference (tests/golden/make_golden.py, G8).
+"""
+import numpy as np
+import pytest
+import torch
+
+from iffnerf_amd import synthetic
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _install():
+    import iffnerf_amd
+    iffnerf_amd.install(force=True)
+
+
+def test_reference_module_paths_run_on_the_gpu(golden, dev, tmp_path, monkeypatch):
+    _install()
+    from models.tensoRF import TensorVMSplit                       # noqa: F401  (the reference's import lines)
+    from pose_estimation.model_utils import explore_model, load_model
+    from pose_estimation import identification_module as im
+    from pose_estimation.test import test_pose_estimation
+    import renderer
+
+    ck = util.ckpt("small")
+    path = tmp_path / "tensorf_small_VM.th"
+    torch.save(ck, str(path))
+    model = load_model(str(path), dev)
+    assert not any(p.requires_grad for p in model.parameters())
+
+    # field API parity through the module (same checks as test_hip_field, one call each)
+    g2 = golden["g2_march_point"]
+    rays = golden.t("g2_march_point", "rays").to(dev)
+    rgb, depth, acc, alpha, z_vals, dists = model(rays, N_samples=20, sample_func=model.sample_point_color)
+    torch.testing.assert_close(rgb.cpu(), torch.from_numpy(g2["rgb"]), atol=2e-5, rtol=0)
+    torch.testing.assert_close(alpha.cpu(), torch.from_numpy(g2["alpha"]), atol=1e-5, rtol=5e-6)
+    assert torch.equal(z_vals.cpu(), torch.from_numpy(g2["z_vals"])) and torch.equal(dists.cpu(), torch.from_numpy(g2["dists"]))
+    g10 = golden["g10_march_slab"]
+    model.near_far = [float(v) for v in g10["near_far"]]
+    model.invalidate_tables()
+    rgb_s, _, depth_s, _, _ = renderer.OctreeRender_trilinear_fast(golden.t("g10_march_slab", "rays"), model, device=dev)
+    torch.testing.assert_close(rgb_s.cpu(), torch.from_numpy(g10["rgb"]), atol=5e-5, rtol=0)
+    torch.testing.assert_close(depth_s.cpu(), torch.from_numpy(g10["depth"]), atol=1e-4, rtol=0)
+    x = golden.t("g5_emit", "samples").to(dev)
+    from oracle import field as ofield
+    want_alpha = ofield.compute_alpha(ofield.field_from_ckpt(ck), x.cpu())
+    torch.testing.assert_close(model.compute_alpha(x).cpu(), want_alpha, atol=2e-6, rtol=2e-6)
+    with pytest.raises(RuntimeError):
+        model(rays, sample_func=lambda *a, **k: None)
+
+    # stage A+B through explore_model: shapes, determinism under torch.manual_seed, colours consistent with the march
+    torch.manual_seed(66)
+    o, d, c = explore_model(model, gen_points=75)
+    assert o.shape == d.shape == c.shape == (2025, 3) and o.is_cuda
+    torch.manual_seed(66)
+    o2, d2, c2 = explore_model(model, gen_points=75)
+    assert torch.equal(o, o2) and torch.equal(d, d2) and torch.equal(c, c2)
+    assert torch.equal(o.view(75, 27, 3)[:, 0], o.view(75, 27, 3)[:, 26])          # 27 rays share each origin
+    assert torch.allclose(torch.linalg.norm(d, dim=-1), torch.ones(2025, device=dev), atol=1e-5)
+
+    # stage C through the module, on the golden rays, with the golden harness's fake backbone
+    tok8 = golden.t("g8_end_to_end", "tokens").to(dev)
+
+    class FakeBackbone(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def forward_features(self, x):
+            self.calls += 1
+            return {"x_norm_patchtokens": (tok8 * (1.0 + 0.05 * self.calls))[None]}
+
+    monkeypatch.setattr(im, "create_backbone", lambda type="dino", pretrained=False, **k: (FakeBackbone(), (16, 16), 384))
+    idm = im.IdentificationModule("dino")
+    idm.load_state_dict({**idm.state_dict(), **synthetic.make_id_weights(seed=99)})
+    idm = idm.to(dev).eval()
+    # the golden harness used identity image transforms on 16x16 inputs; do the same here
+    idm.transformations = lambda x: x
+    idm.mask_transformations = lambda x: x
+
+    class Dataset:
+        pass
+
+    g8 = golden["g8_end_to_end"]
+    ds = Dataset()
+    ds.all_rgbs = golden.t("g8_end_to_end", "imgs").clone()
+    ds.K = torch.eye(3)[None]
+    ds.all_rays = torch.zeros(2, 4, 6)
+    ds.poses = golden.t("g8_end_to_end", "poses").clone()
+    ro, rd, rc = (golden.t("g6_identify", k).to(dev) for k in ("ori", "dirs", "rgb"))
+    res, te, ae, _, _ = test_pose_estimation(ds, idm, ro, rd, rc, golden.t("g8_end_to_end", "model_up").to(dev))
+    pred = torch.tensor([r["pred_c2w"] for r in res])
+    torch.testing.assert_close(pred, torch.from_numpy(g8["pred_c2w"]), atol=1e-4, rtol=0)
+    assert abs(te - float(g8["avg_translation_error"])) < 1e-4 and abs(ae - float(g8["avg_angular_error"])) < 1e-2
+    # test_image returns the reference's 4-tuple; the attention map rows are softmaxes over the rays
+    idx, val, scores, amap = idm.test_image(ds.all_rgbs[0, ..., :3].to(dev), ds.all_rgbs[0, ..., 3].to(dev), ro, rd, rc)
+    assert idx.shape == (100,) and idx.dtype == torch.int64 and scores.shape == (2025,) and amap.shape[1] == 2025
+    assert torch.allclose(amap.sum(-1), torch.ones(amap.shape[0], device=dev), atol=1e-4)
+    assert torch.equal(scores[idx], val)
+    # grad mode with trainable parameters is refused (training is out of scope), not silently served
+    for p in idm.attention.parameters():
+        p.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        idm(ds.all_rgbs[0, ..., :3].to(dev), ds.all_rgbs[0, ..., 3].to(dev), ro, rd, rc)

