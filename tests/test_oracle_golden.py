@@ -155,3 +155,27 @@ def test_g11_unisphere(golden):
     _eq(field.normalize_coord(f, x), g["xn"]); _eq(field.compute_alpha(f, x), g["alpha"])
     _eq(field.mask_sample(f, x), g["mask_value"])
     assert float(f.step_size) == float(g["step_size"]) and f.n_samples == int(g["n_samples"])
+
+
+def test_gridsample_restatement(golden):
+    """The explicit-index restatement of F.grid_sample agrees with the operator and with the reference's outputs."""
+    import torch.nn.functional as F
+    from oracle import gridsample_np as gs
+    rng = np.random.default_rng(4)
+    img = rng.standard_normal((5, 7, 9)).astype(np.float32)
+    xy = (rng.random((400, 2)).astype(np.float32) * 2.4 - 1.2)
+    xy[:6] = [[-1, -1], [1, 1], [1, -1], [0, 0], [1.0000001, 0.3], [-1.2, 2.0]]
+    want = F.grid_sample(torch.from_numpy(img)[None], torch.from_numpy(xy).view(1, -1, 1, 2), align_corners=True).view(5, -1)
+    np.testing.assert_allclose(gs.grid_sample_2d(img, xy), want.numpy(), rtol=0, atol=2e-6)
+    vol = (rng.random((1, 6, 5, 8)) > 0.5).astype(np.float32)
+    xyz = (rng.random((400, 3)).astype(np.float32) * 2.4 - 1.2)
+    xyz[:3] = [[-1, -1, -1], [1, 1, 1], [0.2, -1, 1]]
+    want3 = F.grid_sample(torch.from_numpy(vol)[None], torch.from_numpy(xyz).view(1, -1, 1, 1, 3), align_corners=True).view(1, -1)
+    got3 = gs.grid_sample_3d(vol, xyz)
+    np.testing.assert_allclose(got3, want3.numpy(), rtol=0, atol=2e-6)
+    assert np.array_equal(got3 > 0, want3.numpy() > 0)
+    # and the whole VM density lookup against the reference's own output (G1)
+    g = golden["g1_field_points"]
+    planes = [g[f"sd.density_plane.{i}"][0] for i in range(3)]
+    lines = [g[f"sd.density_line.{i}"][0, :, :, 0] for i in range(3)]
+    np.testing.assert_allclose(gs.vm_density_feature(planes, lines, g["xn"]), g["density_feature"], rtol=2e-6, atol=2e-5)
