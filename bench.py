@@ -144,8 +144,7 @@ def main():
             samples, _, _ = pipe.field.surface_sample(GEN_POINTS, pipe.rho, 4, 200, seed=5000 + r)
             e[1].record()
             normals = pipe.field.point_normals(samples)
-            ori, dirs = isocell_emit(pipe.cells, samples, normals)
-            rays = torch.cat((ori, dirs), dim=-1)
+            ori, dirs, rays = isocell_emit(pipe.cells, samples, normals, want_rays6=True)
             e[2].record()
             rgb = pipe.field.march(rays, 0, 20, want_alpha=False)[0]
             e[3].record()

@@ -90,6 +90,7 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     }
     size_t o_basis = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
     size_t o_basis_l = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
+    size_t o_basis_l12 = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
     size_t o_head = off; off = up256(off + (size_t)ho.total * 4);
     size_t n_mask = d->mask_volume ? (size_t)d->mask_dims[0] * d->mask_dims[1] * d->mask_dims[2] : 0;
     size_t o_mask = off; off = up256(off + n_mask);
@@ -116,18 +117,21 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     IFF_CREATE_HIP(launch_k0_basis_slices(d->basis, (float*)(base + o_basis_l), d->app_dim, d->n_app, s));
     v.basis = (const float*)(base + o_basis);
     v.basis_l = (const float*)(base + o_basis_l);
+    IFF_CREATE_HIP(launch_k0_basis_lanes(d->basis, (float*)(base + o_basis_l12), d->app_dim, d->n_app, s));
+    v.basis_l12 = (const float*)(base + o_basis_l12);
     {
         float* h = (float*)(base + o_head);
-        struct { const float* src; int off; int n; } parts[] = {
-            {d->normal_w, ho.normal_w, 3 * d->app_dim}, {d->normal_b, ho.normal_b, 3},
-            {d->tint_w, ho.tint_w, 3 * d->app_dim}, {d->tint_b, ho.tint_b, 3},
-            {d->rough_w, ho.rough_w, d->app_dim}, {d->rough_b, ho.rough_b, 1},
-            {d->diffuse_w, ho.diffuse_w, 3 * d->app_dim}, {d->diffuse_b, ho.diffuse_b, 3},
-            {d->bottleneck_w, ho.bott_w, d->feature_c * d->app_dim}, {d->bottleneck_b, ho.bott_b, d->feature_c},
-            {d->specular_w, ho.spec_w, 3 * (d->feature_c + 39)}, {d->specular_b, ho.spec_b, 3},
-            {d->ide_mat, ho.ide_mat, 9 * 19}};
-        for (auto& p : parts)
-            IFF_CREATE_HIP(hipMemcpyAsync(h + p.off, p.src, (size_t)p.n * 4, hipMemcpyDeviceToDevice, s));
+        struct { const float* src; int off; int rows; int cols; int ld; } parts[] = {
+            {d->normal_w, ho.normal_w, 3, d->app_dim, ho.ld}, {d->normal_b, ho.normal_b, 1, 3, 4},
+            {d->tint_w, ho.tint_w, 3, d->app_dim, ho.ld}, {d->tint_b, ho.tint_b, 1, 3, 4},
+            {d->rough_w, ho.rough_w, 1, d->app_dim, ho.ld}, {d->rough_b, ho.rough_b, 1, 1, 4},
+            {d->diffuse_w, ho.diffuse_w, 3, d->app_dim, ho.ld}, {d->diffuse_b, ho.diffuse_b, 1, 3, 4},
+            {d->bottleneck_w, ho.bott_w, d->feature_c, d->app_dim, ho.ld}, {d->bottleneck_b, ho.bott_b, 1, d->feature_c, d->feature_c},
+            {d->specular_w, ho.spec_w, 3, d->feature_c + 39, ho.spec_ld}, {d->specular_b, ho.spec_b, 1, 3, 4},
+            {d->ide_mat, ho.ide_mat, 1, 9 * 19, 9 * 19}};
+        for (auto& p : parts)   // rows are zero-padded to `ld` floats (the slab was memset to 0)
+            IFF_CREATE_HIP(hipMemcpy2DAsync(h + p.off, (size_t)p.ld * 4, p.src, (size_t)p.cols * 4, (size_t)p.cols * 4,
+                                            (size_t)p.rows, hipMemcpyDeviceToDevice, s));
         v.head = h;
     }
     if (d->mask_volume) {
@@ -223,28 +227,40 @@ extern "C" int iff_ref_normals(const iff_field* f, const float* features, int64_
 }
 
 extern "C" int iff_isocell_emit(const float* cells_host, const float* points, const float* normals, int64_t P, float* ori,
-                                float* dirs, void* stream) {
+                                float* dirs, float* rays6_opt, void* stream) {
     IFF_REQUIRE(P >= 0, "iff_isocell_emit: negative P");
     if (P == 0) return 0;
     IFF_REQUIRE(cells_host && points && normals && ori && dirs, "iff_isocell_emit: null buffer");
-    IFF_HIP(launch_isocell_emit(cells_host, points, normals, P, ori, dirs, (hipStream_t)stream));
+    IFF_HIP(launch_isocell_emit(cells_host, points, normals, P, ori, dirs, rays6_opt, (hipStream_t)stream));
     return 0;
+}
+
+static int march_samples(const iff_field* f, int32_t mode, int32_t n_samples) {
+    return n_samples > 0 ? n_samples : (mode == IFF_MARCH_POINT_CENTRED ? 20 : f->dev.n_samples);
+}
+
+extern "C" size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples) {
+    if (!f || R <= 0) return 0;
+    return march_workspace_bytes(R, march_samples(f, mode, n_samples));
 }
 
 extern "C" int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                                int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc, float* alpha_opt,
-                               int32_t* counts_opt, void* stream) {
+                               int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream) {
     IFF_REQUIRE(f != nullptr && R >= 0, "iff_march_shade: bad argument");
     if (R == 0) return 0;
     IFF_REQUIRE(rays && rgb && depth && acc && bg_host, "iff_march_shade: null buffer");
     IFF_REQUIRE(ray_cols == 6 || ray_cols == 7, "iff_march_shade: rays must have 6 or 7 columns (got %d)", ray_cols);
     IFF_REQUIRE(mode == IFF_MARCH_POINT_CENTRED || mode == IFF_MARCH_SLAB, "iff_march_shade: unknown mode %d", mode);
-    int S = n_samples > 0 ? n_samples : (mode == IFF_MARCH_POINT_CENTRED ? 20 : f->dev.n_samples);
+    int S = march_samples(f, mode, n_samples);
     IFF_REQUIRE(S >= 1 && S <= (1 << 20), "iff_march_shade: n_samples = %d out of range", S);
+    if (!workspace || workspace_bytes < march_workspace_bytes(R, S))
+        return fail(IFF_ERR_WORKSPACE, "iff_march_shade: workspace %zu < %zu bytes", workspace_bytes, march_workspace_bytes(R, S));
     if (mode == IFF_MARCH_SLAB && f->dev.unisphere)
         return fail(IFF_ERR_UNSUPPORTED, "slab sampler with contraction_type='unisphere' is not built "
                                          "(the reference's own branch is unfinished: models/tensorBase.py:511-525)");
-    IFF_HIP(launch_march(f->dev, rays, ray_cols, R, mode, S, bg_host, rgb, depth, acc, alpha_opt, counts_opt, (hipStream_t)stream));
+    IFF_HIP(launch_march(f->dev, rays, ray_cols, R, mode, S, bg_host, rgb, depth, acc, alpha_opt, counts_opt, workspace,
+                         workspace_bytes, (hipStream_t)stream));
     return 0;
 }
 

@@ -36,6 +36,18 @@ __global__ void k0_basis_slices(const float* __restrict__ src, float* __restrict
     }
 }
 
+// basis_mat [app_dim][3*n_app] -> [app_dim][n_app/4][12]: lane c holds, in order (plane i, e), the weights of channels
+// 4c+e -- the order app_products_lane() produces them in.
+__global__ void k0_basis_lanes(const float* __restrict__ src, float* __restrict__ dst, int app_dim, int n_app) {
+    int nl = n_app / 4;
+    int n = app_dim * nl * 12;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        int kk = t % 12, c = (t / 12) % nl, o = t / (12 * nl);
+        int i = kk >> 2, e = kk & 3;
+        dst[t] = src[o * 3 * n_app + i * n_app + 4 * c + e];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ elementwise
 __global__ void k_normalize_coord(FieldDev f, const float* __restrict__ xyz, int64_t n, float* __restrict__ out) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
@@ -124,7 +136,7 @@ __global__ void __launch_bounds__(256) k2_point_app(FieldDev f, const float* __r
             for (int o = 0; o < 3; ++o) {
                 float a = 0.f;
 #pragma unroll
-                for (int k = 0; k < APP; ++k) a = fmaf(f.head[ho.normal_w + o * APP + k], F[k], a);
+                for (int k = 0; k < APP; ++k) a = fmaf(f.head[ho.normal_w + o * ho.ld + k], F[k], a);
                 nr[o] = a + f.head[ho.normal_b + o];
             }
             float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
@@ -133,22 +145,49 @@ __global__ void __launch_bounds__(256) k2_point_app(FieldDev f, const float* __r
     }
 }
 
-// Ref.forward for explicit (viewdirs, features): 16 lanes per row
-template <int APP>
-__global__ void __launch_bounds__(256) k_ref_shade(FieldDev f, const float* __restrict__ dirs, const float* __restrict__ feat,
-                                                   int64_t n, float* __restrict__ rgb) {
+// Ref.forward for explicit (viewdirs, features): 16 lanes per row.  With BLEND it is also the march epilogue (K4c,
+// tensorBase.py:886-908): features come with a row stride and a "has shaded samples" flag in column APP, and the colour
+// is blended with the background by the accumulated opacity.
+struct ShadeArgs {
+    const float* dirs; int dir_stride;     // viewdirs: row r at dirs + r * dir_stride
+    const float* feat; int feat_stride;    // features: row r at feat + r * feat_stride
+    const float* acc;                      // [n] (BLEND only)
+    float bg[3];
+    int64_t n;
+    float* rgb;
+};
+template <int APP, bool BLEND>
+__global__ void __launch_bounds__(256) k_ref_shade(FieldDev f, ShadeArgs a) {
     const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
-    int64_t nt = n * 16;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ((nt + 63) & ~(int64_t)63); t += stride) {
+    // No grid-stride loop on purpose: inside one, the ~5 k head weights are loop-invariant and LLVM hoists their loads out
+    // of the loop (300+ live registers, one wave per SIMD).  One (ray, lane) item per thread, exact grid.
+    int64_t nt = a.n * 16;
+    {
+        int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
         bool live = t < nt;
         int64_t ri = live ? (t >> 4) : 0;
         int l16 = (int)(t & 15);
-        float F[APP], d[3] = {dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]}, c[3];
+        constexpr int LD = (APP + 3) & ~3;
+        const float* dp = a.dirs + ri * a.dir_stride;
+        const float* fp = a.feat + ri * a.feat_stride;
+        float F[LD], d[3] = {dp[0], dp[1], dp[2]}, c[3];
 #pragma unroll
-        for (int k = 0; k < APP; ++k) F[k] = feat[ri * APP + k];
-        ref_shade_group16<APP>(f.head, ho, f.feature_c, F, d, l16, c);
-        if (live && l16 == 0) { rgb[3 * ri] = c[0]; rgb[3 * ri + 1] = c[1]; rgb[3 * ri + 2] = c[2]; }
+        for (int k = 0; k < LD; ++k) F[k] = (k < APP) ? fp[k] : 0.0f;
+        ref_shade_group16<LD>(f.head, ho, f.feature_c, F, d, l16, c);
+        if (live && l16 == 0) {
+            if (BLEND) {
+                const bool any = fp[APP] != 0.0f;
+                const float acc = a.acc[ri];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float v = any ? c[ch] : 0.0f;
+                    v = v * acc + a.bg[ch] * (1.0f - acc);
+                    a.rgb[3 * ri + ch] = fminf(fmaxf(v, 0.0f), 1.0f);
+                }
+            } else {
+                a.rgb[3 * ri] = c[0]; a.rgb[3 * ri + 1] = c[1]; a.rgb[3 * ri + 2] = c[2];
+            }
+        }
     }
 }
 
@@ -162,7 +201,7 @@ __global__ void k_ref_normals(FieldDev f, const float* __restrict__ feat, int64_
         for (int o = 0; o < 3; ++o) {
             float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < APP; ++k) a = fmaf(f.head[ho.normal_w + o * APP + k], feat[t * APP + k], a);
+            for (int k = 0; k < APP; ++k) a = fmaf(f.head[ho.normal_w + o * ho.ld + k], feat[t * APP + k], a);
             nr[o] = a + f.head[ho.normal_b + o];
         }
         float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
@@ -190,6 +229,10 @@ hipError_t launch_k0_basis_slices(const float* src, float* dst, int app_dim, int
     hipLaunchKernelGGL(k0_basis_slices, dim3(grid_for(app_dim * 3 * n_app)), dim3(256), 0, s, src, dst, app_dim, n_app);
     return hipGetLastError();
 }
+hipError_t launch_k0_basis_lanes(const float* src, float* dst, int app_dim, int n_app, hipStream_t s) {
+    hipLaunchKernelGGL(k0_basis_lanes, dim3(grid_for(app_dim * 3 * n_app)), dim3(256), 0, s, src, dst, app_dim, n_app);
+    return hipGetLastError();
+}
 hipError_t launch_normalize_coord(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_normalize_coord, dim3(grid_for(n)), dim3(256), 0, s, f, xyz, n, out);
     return hipGetLastError();
@@ -215,7 +258,18 @@ hipError_t launch_point_normals(const FieldDev& f, const float* xyz, int64_t n, 
     return hipGetLastError();
 }
 hipError_t launch_ref_shade(const FieldDev& f, const float* dirs, const float* feat, int64_t n, float* rgb, hipStream_t s) {
-    hipLaunchKernelGGL((k_ref_shade<27>), dim3(grid_for(n * 16)), dim3(256), 0, s, f, dirs, feat, n, rgb);
+    ShadeArgs a;
+    a.dirs = dirs; a.dir_stride = 3; a.feat = feat; a.feat_stride = f.app_dim; a.acc = nullptr;
+    a.bg[0] = a.bg[1] = a.bg[2] = 0.0f; a.n = n; a.rgb = rgb;
+    hipLaunchKernelGGL((k_ref_shade<27, false>), dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, f, a);
+    return hipGetLastError();
+}
+hipError_t launch_shade_blend(const FieldDev& f, const float* rays, int ray_cols, const float* feat28, const float* acc,
+                              const float* bg, int64_t n, float* rgb, hipStream_t s) {
+    ShadeArgs a;
+    a.dirs = rays + 3; a.dir_stride = ray_cols; a.feat = feat28; a.feat_stride = 28; a.acc = acc;
+    a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2]; a.n = n; a.rgb = rgb;
+    hipLaunchKernelGGL((k_ref_shade<27, true>), dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, f, a);
     return hipGetLastError();
 }
 hipError_t launch_ref_normals(const FieldDev& f, const float* feat, int64_t n, float* out, hipStream_t s) {

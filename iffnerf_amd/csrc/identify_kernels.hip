@@ -4,6 +4,7 @@
 // of the reference and the top-k set is the reference's.
 #include "iff_device.h"
 #include "iff_launch.h"
+#include "iff_select.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -58,43 +59,54 @@ __global__ void k5_ray_input(const float* __restrict__ o, const float* __restric
 // Wt [K1+K2][Nout] k-major.  K1, K2 multiples of BK.  Tile 128x128x16, 4 waves each 64x64 (2x2 MFMA 32x32 blocks).
 // NT variant (B_IS_ROWS): B operand given as rows Bm [Nout][ldb] (k contiguous), i.e. Y = A * Bm^T -- the attention
 // logits; there `divisor` divides the product (multihead_attention.py:6-7) and bias is not applied.
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BN = 128, BK = 16;
 
-template <bool RELU, bool B_IS_ROWS>
+// MT = 32-row MFMA blocks per wave in M: MT = 2 -> 128-row tile, MT = 1 -> 64-row tile (twice the workgroups: 2-3 are
+// co-resident per CU and cover each other's barrier / LDS-latency bubbles, and 384-wide outputs balance over 256 CUs).
+template <bool RELU, bool B_IS_ROWS, int MT>
 __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A1, int lda1, int K1,
                                                   const float* __restrict__ A2, int lda2, int K2,
                                                   const float* __restrict__ B, int ldb, const float* __restrict__ bias,
                                                   float* __restrict__ Y, int64_t ldy, int64_t M, int64_t Nout, float divisor) {
-    __shared__ float As[2][BK][BM + 4];
-    __shared__ float Bs[2][BK][BN + 4];
+    constexpr int BM = 64 * MT;
+    constexpr int A_LD = BM + 4, B_LD = BN + 4;
+    __shared__ float As[2][BK][A_LD];
+    __shared__ float Bs[2][BK][B_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int64_t col0 = (int64_t)blockIdx.y * BN;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int wr = (wave >> 1) * 32 * MT, wc = (wave & 1) * 64;
     const int K = K1 + K2;
     const int nk = K / BK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // staging registers: A tile 128 rows x 16 k = 512 float4 -> 2 per thread (row = f>>2, kq = f&3)
-    float4 ra[2], rb[2];
-    auto load_tile = [&](int kt) {
+    // staging registers: A tile BM rows x 16 k = BM*4 float4 -> MT per thread (row = f>>2, kq = (f&3)*4); B 512 float4 -> 2.
+    // Two register sets: global loads run TWO k-tiles ahead of the MFMAs (one tile of MFMAs is shorter than an L2/HBM
+    // round trip), LDS is double-buffered one tile ahead.
+    float4 raA[MT], rbA[2], raB[MT], rbB[2];
+    auto load_tile = [&](int kt, float4* ra, float4* rb) {
         const int k0 = kt * BK;
         const float* Asrc; int lda, kk;
         if (k0 < K1) { Asrc = A1; lda = lda1; kk = k0; } else { Asrc = A2; lda = lda2; kk = k0 - K1; }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < MT; ++u) {
             int f = tid + u * 256;
             int r = f >> 2, kq = (f & 3) * 4;
             int64_t gr = row0 + r;
             ra[u] = (gr < M) ? ld4(Asrc + gr * lda + kk + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int f = tid + u * 256;
             if (B_IS_ROWS) {
+                int r = f >> 2, kq = (f & 3) * 4;
                 int64_t gc = col0 + r;
                 rb[u] = (gc < Nout) ? ld4(B + gc * ldb + k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
@@ -104,13 +116,18 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A1, 
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const float4* ra, const float4* rb) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < MT; ++u) {
             int f = tid + u * 256;
             int r = f >> 2, kq = (f & 3) * 4;
             As[buf][kq + 0][r] = ra[u].x; As[buf][kq + 1][r] = ra[u].y; As[buf][kq + 2][r] = ra[u].z; As[buf][kq + 3][r] = ra[u].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int f = tid + u * 256;
             if (B_IS_ROWS) {
+                int r = f >> 2, kq = (f & 3) * 4;
                 Bs[buf][kq + 0][r] = rb[u].x; Bs[buf][kq + 1][r] = rb[u].y; Bs[buf][kq + 2][r] = rb[u].z; Bs[buf][kq + 3][r] = rb[u].w;
             } else {
                 int kr = f >> 5, cq = (f & 31) * 4;
@@ -118,29 +135,51 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A1, 
             }
         }
     };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const int li = lane & 31, lk = lane >> 5;
+    const int li = lane & 31, lk = lane >> 5;
+    auto compute_tile = [&](int buf) {
+        // operand reads run one k-step ahead of the MFMAs that consume them
+        float a_cur[MT], b_cur[2], a_nxt[MT], b_nxt[2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a_cur[i] = As[buf][lk][wr + 32 * i + li];
+        b_cur[0] = Bs[buf][lk][wc + li]; b_cur[1] = Bs[buf][lk][wc + 32 + li];
 #pragma unroll
         for (int k2 = 0; k2 < BK; k2 += 2) {
-            float a0 = As[buf][k2 + lk][wr + li], a1 = As[buf][k2 + lk][wr + 32 + li];
-            float b0 = Bs[buf][k2 + lk][wc + li], b1 = Bs[buf][k2 + lk][wc + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (k2 + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a_nxt[i] = As[buf][k2 + 2 + lk][wr + 32 * i + li];
+                b_nxt[0] = Bs[buf][k2 + 2 + lk][wc + li]; b_nxt[1] = Bs[buf][k2 + 2 + lk][wc + 32 + li];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[1], acc[i][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
+            b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    load_tile(0, raA, rbA);
+    store_tile(0, raA, rbA);
+    if (nk > 1) load_tile(1, raA, rbA);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even tile: LDS buffer 0; set A holds tile kt+1 (in flight since the previous phase); fetch tile kt+2 into set B
+        if (kt + 2 < nk) load_tile(kt + 2, raB, rbB);
+        compute_tile(0);
+        if (kt + 1 < nk) store_tile(1, raA, rbA);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd tile: LDS buffer 1; set B holds tile kt+2; fetch tile kt+3 into set A
+        if (kt + 3 < nk) load_tile(kt + 3, raA, rbA);
+        compute_tile(1);
+        if (kt + 2 < nk) store_tile(0, raB, rbB);
         __syncthreads();
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int64_t gc = col0 + wc + j * 32 + (lane & 31);
@@ -160,12 +199,15 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A1, 
         }
 }
 
+constexpr int GEMM_MT = 1;
+
 template <bool RELU>
 static hipError_t gemm_nn(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const float* Wt, int Nout,
                           const float* bias, float* Y, int64_t ldy, int64_t M, hipStream_t s) {
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((Nout + BN - 1) / BN));
-    hipLaunchKernelGGL((k_gemm_f32<RELU, false>), grid, dim3(256), 0, s, A1, lda1, K1, A2, lda2, K2, Wt, Nout, bias, Y, ldy, M,
-                       (int64_t)Nout, 1.0f);
+    constexpr int BMv = 64 * GEMM_MT;
+    dim3 grid((unsigned)((M + BMv - 1) / BMv), (unsigned)((Nout + BN - 1) / BN));
+    hipLaunchKernelGGL((k_gemm_f32<RELU, false, GEMM_MT>), grid, dim3(256), 0, s, A1, lda1, K1, A2, lda2, K2, Wt, Nout, bias, Y,
+                       ldy, M, (int64_t)Nout, 1.0f);
     return hipGetLastError();
 }
 
@@ -206,49 +248,83 @@ hipError_t launch_k_proj(const IdNetDev& n, const float* feat, int64_t N, float*
     return gemm_nn<false>(feat, n.fea, n.fea, nullptr, 0, 0, n.wk, n.fea, n.bk, kout, n.fea, N, s);
 }
 
-// q_proj: img [M][img_fea=398] -> pad K to 400 through a scratch copy [M][400]
-__global__ void k_pad_rows(const float* __restrict__ src, int cols, float* __restrict__ dst, int cols_pad, int64_t rows) {
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < rows * cols_pad; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = t / cols_pad;
-        int c = (int)(t - r * cols_pad);
-        dst[t] = (c < cols) ? src[r * cols + c] : 0.0f;
+// q_proj: M <= 256 token rows -- far too few rows for the 128-row tile.  One wave per 16x16 output tile on
+// v_mfma_f32_16x16x4_f32, operands straight from L2 (A [M][K] row-major, unpadded; Wt [K_pad][N] k-major with zero rows
+// beyond K), 4 waves = a 16 x 64 strip per workgroup: 96 workgroups for 256 x 384.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A, int K, int K_pad, const float* __restrict__ Wt,
+                                                    int Nout, const float* __restrict__ bias, float* __restrict__ Y, int M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * 4 + wave) * 16;
+    if (n0 >= Nout) return;
+    const int r = lane & 15, kk = lane >> 4;
+    const bool row_ok = (m0 + r) < M;
+    const float* arow = A + (size_t)(m0 + r) * K;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    // 16 k-steps (64 k) per trip: all 32 operand loads are issued before the first MFMA consumes one, so the L2
+    // latency is paid once per trip instead of once per step
+    for (; k < K_pad; k += 64) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            int ka = k + 4 * u + kk;
+            av[u] = (row_ok && ka < K) ? arow[ka] : 0.0f;
+            bv[u] = (ka < K_pad) ? Wt[(size_t)ka * Nout + n0 + r] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
+        }
+    }
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+    const float bv = bias ? bias[n0 + r] : 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int row = m0 + 4 * (lane >> 4) + g;
+        if (row < M) Y[(size_t)row * Nout + n0 + r] = (acc0[g] + acc1[g]) + bv;
     }
 }
+
 hipError_t launch_q_proj(const IdNetDev& n, const float* img, int M, float* q, void* scratch, hipStream_t s) {
+    (void)scratch;
     if (M == 0) return hipSuccess;
     int kp = (n.img_fea + 15) / 16 * 16;
-    float* xp = (float*)scratch;
-    int grid = (int)(((int64_t)M * kp + 255) / 256);
-    hipLaunchKernelGGL(k_pad_rows, dim3(grid), dim3(256), 0, s, img, n.img_fea, xp, kp, (int64_t)M);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return gemm_nn<false>(xp, kp, kp, nullptr, 0, 0, n.wq, n.fea, n.bq, q, n.fea, M, s);
+    dim3 grid((unsigned)((M + 15) / 16), (unsigned)((n.fea + 63) / 64));
+    hipLaunchKernelGGL(k_gemm_small, grid, dim3(256), 0, s, img, n.img_fea, kp, n.wq, n.fea, n.bq, q, M);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ K6
-// one workgroup per image token row: row_max, row_sumexp = sum_j exp(l_ij - row_max)   (softmax denominators)
+// one workgroup per image token row: row_max, row_sumexp = sum_j exp(l_ij - row_max), in ONE pass over the row
+// (running maximum with rescale per thread, then a fixed-order merge of the 256 (max, sum) pairs)
 __global__ void __launch_bounds__(256) k6_row_stats(const float* __restrict__ logits, int64_t N, float* __restrict__ row_max,
                                                     float* __restrict__ row_sumexp) {
-    __shared__ float red[4];
+    __shared__ float red_m[4], red_s[4];
     const float* row = logits + (int64_t)blockIdx.x * N;
     const int tid = threadIdx.x;
-    float m = -INFINITY;
-    for (int64_t j = tid; j < N; j += 256) m = fmaxf(m, row[j]);
+    float m = -INFINITY, s = 0.0f;
+    for (int64_t j = tid; j < N; j += 256) {
+        float x = row[j];
+        if (x > m) { s = s * expf(m - x); m = x; }       // exp(-inf) = 0 on the first element
+        s += expf(x - m);
+    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float sum = 0.0f;
-    for (int64_t j = tid; j < N; j += 256) sum += expf(row[j] - m);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    for (int off = 32; off >= 1; off >>= 1) {
+        float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
+        float mm = fmaxf(m, m2);
+        s = ((m == -INFINITY) ? 0.0f : s * expf(m - mm)) + ((m2 == -INFINITY) ? 0.0f : s2 * expf(m2 - mm));
+        m = mm;
+    }
+    if ((tid & 63) == 0) { red_m[tid >> 6] = m; red_s[tid >> 6] = s; }
     __syncthreads();
     if (tid == 0) {
-        row_max[blockIdx.x] = m;
-        row_sumexp[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        float mm = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+        float ss = 0.0f;
+        for (int w = 0; w < 4; ++w) ss += (red_m[w] == -INFINITY) ? 0.0f : red_s[w] * expf(red_m[w] - mm);
+        row_max[blockIdx.x] = mm;
+        row_sumexp[blockIdx.x] = ss;
     }
 }
 
@@ -256,8 +332,9 @@ hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, 
                               float* row_max, float* row_sumexp, hipStream_t s) {
     if (M == 0 || N == 0) return hipSuccess;
     if (D % BK != 0) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, dim3(256), 0, s, q, D, D, (const float*)nullptr, 0, 0, k, D,
+    constexpr int MTL = 1;
+    dim3 grid((unsigned)((M + 64 * MTL - 1) / (64 * MTL)), (unsigned)((N + BN - 1) / BN));
+    hipLaunchKernelGGL((k_gemm_f32<false, true, MTL>), grid, dim3(256), 0, s, q, D, D, (const float*)nullptr, 0, 0, k, D,
                        (const float*)nullptr, logits, N, (int64_t)M, N, divisor);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -268,143 +345,131 @@ hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, 
     return e;
 }
 
-// one lane per ray column: attention_ij = exp(l_ij - max_i) / sumexp_i ; score_j = sum_i attention_ij (row order)
-__global__ void __launch_bounds__(64) k6_colsum(float* __restrict__ logits, int M, int64_t N, const float* __restrict__ row_max,
-                                                const float* __restrict__ row_sumexp, int write_attention,
-                                                float* __restrict__ score) {
-    extern __shared__ float s_stats[];   // [2][M]
-    for (int i = threadIdx.x; i < M; i += 64) { s_stats[i] = row_max[i]; s_stats[M + i] = row_sumexp[i]; }
+// attention_ij = exp(l_ij - max_i) / sumexp_i ; score_j = sum_i attention_ij.  A 256-thread workgroup owns 64 ray columns;
+// wave g sums the rows of its quarter of the token rows in order, the 4 partial sums are added in fixed order
+// (deterministic).  Each wave-instruction reads one 256-B row segment.
+__global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int M, int64_t N, const float* __restrict__ row_max,
+                                                 const float* __restrict__ row_sumexp, int write_attention,
+                                                 float* __restrict__ score) {
+    extern __shared__ float s_stats[];   // [2][M] then [4][64] partials
+    float* s_part = s_stats + 2 * M;
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    for (int i = tid; i < M; i += 256) { s_stats[i] = row_max[i]; s_stats[M + i] = row_sumexp[i]; }
     __syncthreads();
-    int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (j >= N) return;
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+    const int per = (M + 3) / 4;
+    const int r0 = g * per, r1 = min(M, r0 + per);
     float acc = 0.0f;
+    if (j < N) {
 #pragma unroll 8
-    for (int i = 0; i < M; ++i) {
-        float a = expf(logits[(int64_t)i * N + j] - s_stats[i]) / s_stats[M + i];
-        if (write_attention) logits[(int64_t)i * N + j] = a;
-        acc += a;
+        for (int i = r0; i < r1; ++i) {
+            float a = expf(logits[(int64_t)i * N + j] - s_stats[i]) / s_stats[M + i];
+            if (write_attention) logits[(int64_t)i * N + j] = a;
+            acc += a;
+        }
     }
-    score[j] = acc;
+    s_part[g * 64 + lane] = acc;
+    __syncthreads();
+    if (g == 0 && j < N) score[j] = (s_part[lane] + s_part[64 + lane]) + (s_part[128 + lane] + s_part[192 + lane]);
 }
 
 hipError_t launch_attn_colsum(float* logits, int M, int64_t N, const float* row_max, const float* row_sumexp,
                               int write_attention, float* score, hipStream_t s) {
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(k6_colsum, dim3((unsigned)((N + 63) / 64)), dim3(64), 2 * (size_t)M * sizeof(float), s, logits, M, N,
-                       row_max, row_sumexp, write_attention, score);
+    hipLaunchKernelGGL(k6_colsum, dim3((unsigned)((N + 63) / 64)), dim3(256), (2 * (size_t)M + 256) * sizeof(float), s, logits,
+                       M, N, row_max, row_sumexp, write_attention, score);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ K7
-// torch.topk(score, k): single-workgroup radix select on order-preserving keys, ordered gather, bitonic sort.
-__device__ inline uint32_t order_key(float v) {
-    uint32_t u = __float_as_uint(v);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // larger float <-> larger key ; NaN sorts above +inf like torch
-}
-
+// torch.topk(score, k): one workgroup.  (1) radix-select the key T of the k-th largest score (iff_select.h);
+// (2) one sweep gathers everything above T (any order) and the indices of the scores equal to T; (3) ties at T are taken
+// lowest index first (sorted only when there are more ties than free slots; more than 1024 ties fall back to an ordered
+// sweep); (4) bitonic sort of the next power of two >= k slots by (value desc, index asc).
 constexpr int TK_THREADS = 1024;
 
-// k-th largest key (k >= 1) of n values; all threads of the workgroup call it; result broadcast.  hist: 256 + 2 ints of LDS
-__device__ uint32_t wg_kth_largest_key(const float* __restrict__ v, int64_t n, int64_t k, int* hist) {
-    uint32_t prefix = 0, mask = 0;
-    int64_t remaining = k;
-    for (int pass = 3; pass >= 0; --pass) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        const int shift = pass * 8;
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-            uint32_t key = order_key(v[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t rem = remaining;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (hist[b] >= rem) break;
-                rem -= hist[b];
-            }
-            hist[256] = b;
-            hist[257] = (int)rem;
-        }
-        __syncthreads();
-        int b = hist[256];
-        remaining = hist[257];
-        prefix |= ((uint32_t)b) << shift;
-        mask |= 255u << shift;
-        __syncthreads();
-    }
-    return prefix;
+__device__ inline bool tk_before(float va, int ia, float vb, int ib) {
+    uint32_t ka = iff_order_key(va), kb = iff_order_key(vb);
+    return (ka > kb) || (ka == kb && ia < ib);
 }
 
 __global__ void __launch_bounds__(TK_THREADS) k7_topk(const float* __restrict__ score, int64_t N, int k, int64_t* __restrict__ idx,
                                                       float* __restrict__ val) {
-    __shared__ int hist[258];
-    __shared__ int scan[TK_THREADS];
+    __shared__ int hist[264];
     __shared__ float s_val[1024];
     __shared__ int s_idx[1024];
-    __shared__ int base_gt, base_eq;
+    __shared__ int s_eq[1024];
+    __shared__ int n_gt, n_eq, eq_base;
+    __shared__ int scan[TK_THREADS];
     const int tid = threadIdx.x;
-    const uint32_t T = wg_kth_largest_key(score, N, k, hist);
-    // count strictly greater to know how many ties at T we may take (lowest indices first)
-    if (tid == 0) { base_gt = 0; base_eq = 0; }
-    for (int i = tid; i < 1024; i += TK_THREADS) { s_val[i] = -INFINITY; s_idx[i] = 0x7fffffff; }
+    const uint32_t T = iff_wg_select_key<true>(score, N, k, hist);
+    if (tid == 0) { n_gt = 0; n_eq = 0; eq_base = 0; }
+    s_val[tid] = -INFINITY; s_idx[tid] = 0x7fffffff; s_eq[tid] = 0x7fffffff;
     __syncthreads();
-    // ordered sweep: chunk by chunk so equal keys are taken in index order
-    int n_gt_total = 0;
-    {
-        int c = 0;
-        for (int64_t i = tid; i < N; i += TK_THREADS) c += (order_key(score[i]) > T) ? 1 : 0;
-        scan[tid] = c;
+    for (int64_t i = tid; i < N; i += TK_THREADS) {
+        float v = score[i];
+        uint32_t key = iff_order_key(v);
+        if (key > T) {
+            int p = atomicAdd(&n_gt, 1);          // fewer than k elements are above the k-th largest
+            s_val[p] = v; s_idx[p] = (int)i;
+        } else if (key == T) {
+            int p = atomicAdd(&n_eq, 1);
+            if (p < 1024) s_eq[p] = (int)i;
+        }
+    }
+    __syncthreads();
+    const int gt = n_gt, eq = n_eq, need = k - gt;
+    const float vT = iff_order_key_inv(T);
+    if (eq <= 1024) {
+        if (eq > need) {
+            // more ties than slots: ascending bitonic sort of the tie indices, keep the lowest `need`
+            for (int size = 2; size <= 1024; size <<= 1)
+                for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                    int j = tid ^ stride;
+                    if (j > tid) {
+                        bool up = ((tid & size) == 0);
+                        int a = s_eq[tid], b = s_eq[j];
+                        if ((a < b) != up) { s_eq[tid] = b; s_eq[j] = a; }
+                    }
+                    __syncthreads();
+                }
+        }
+        if (tid < need) { s_val[gt + tid] = vT; s_idx[gt + tid] = s_eq[tid]; }
         __syncthreads();
-        for (int off = TK_THREADS / 2; off >= 1; off >>= 1) {
-            if (tid < off) scan[tid] += scan[tid + off];
+    } else {
+        // pathological tie count: ordered sweep, chunk by chunk, taking the first `need` equal elements
+        for (int64_t c0 = 0; c0 < N && eq_base < need; c0 += TK_THREADS) {
+            int64_t i = c0 + tid;
+            bool e = (i < N) && iff_order_key(score[i]) == T;
+            scan[tid] = e ? 1 : 0;
+            __syncthreads();
+            for (int off = 1; off < TK_THREADS; off <<= 1) {
+                int v = (tid >= off) ? scan[tid - off] : 0;
+                __syncthreads();
+                scan[tid] += v;
+                __syncthreads();
+            }
+            int pos = eq_base + scan[tid] - (e ? 1 : 0);
+            if (e && pos < need) { s_val[gt + pos] = vT; s_idx[gt + pos] = (int)i; }
+            __syncthreads();
+            if (tid == TK_THREADS - 1) eq_base += scan[tid];
             __syncthreads();
         }
-        n_gt_total = scan[0];
-        __syncthreads();
     }
-    const int need_eq = k - n_gt_total;
-    for (int64_t c0 = 0; c0 < N; c0 += TK_THREADS) {
-        int64_t i = c0 + tid;
-        uint32_t key = (i < N) ? order_key(score[i]) : 0u;
-        bool gt = (i < N) && key > T, eq = (i < N) && key == T;
-        // exclusive scans of both flags (packed: eq in the high half)
-        int packed = (gt ? 1 : 0) | ((eq ? 1 : 0) << 16);
-        scan[tid] = packed;
-        __syncthreads();
-        for (int off = 1; off < TK_THREADS; off <<= 1) {
-            int v = (tid >= off) ? scan[tid - off] : 0;
-            __syncthreads();
-            scan[tid] += v;
-            __syncthreads();
-        }
-        int incl = scan[tid];
-        int pos_gt = base_gt + (incl & 0xffff) - (gt ? 1 : 0);
-        int pos_eq = base_eq + (incl >> 16) - (eq ? 1 : 0);
-        if (gt) { s_val[pos_gt] = score[i]; s_idx[pos_gt] = (int)i; }
-        if (eq && pos_eq < need_eq) { s_val[n_gt_total + pos_eq] = score[i]; s_idx[n_gt_total + pos_eq] = (int)i; }
-        __syncthreads();
-        if (tid == TK_THREADS - 1) { base_gt += incl & 0xffff; base_eq += incl >> 16; }
-        __syncthreads();
-    }
-    // bitonic sort of 1024 slots: descending value, ascending index on ties (padding = -inf, idx max)
-    for (int size = 2; size <= 1024; size <<= 1) {
+    int slots = 1;
+    while (slots < k) slots <<= 1;
+    for (int size = 2; size <= slots; size <<= 1)
         for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            int i = tid;
-            int j = i ^ stride;
-            if (j > i) {
-                bool up = ((i & size) == 0);
-                float vi = s_val[i], vj = s_val[j];
-                int ii = s_idx[i], ij = s_idx[j];
-                uint32_t ki = order_key(vi), kj = order_key(vj);
-                bool i_first = (ki > kj) || (ki == kj && ii < ij);   // i should precede j in the final order
-                if (i_first != up) { s_val[i] = vj; s_val[j] = vi; s_idx[i] = ij; s_idx[j] = ii; }
+            int j = tid ^ stride;
+            if (tid < slots && j > tid) {
+                bool up = ((tid & size) == 0);
+                float vi = s_val[tid], vj = s_val[j];
+                int ii = s_idx[tid], ij = s_idx[j];
+                if (tk_before(vi, ii, vj, ij) != up) { s_val[tid] = vj; s_val[j] = vi; s_idx[tid] = ij; s_idx[j] = ii; }
             }
             __syncthreads();
         }
-    }
-    for (int i = tid; i < k; i += TK_THREADS) { idx[i] = (int64_t)s_idx[i]; val[i] = s_val[i]; }
+    if (tid < k) { idx[tid] = (int64_t)s_idx[tid]; val[tid] = s_val[tid]; }
 }
 
 size_t topk_workspace_bytes(int64_t N, int k) { (void)N; (void)k; return 256; }

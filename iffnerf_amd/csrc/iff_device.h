@@ -19,6 +19,7 @@ struct FieldDev {
     const float* aplane[3];
     const float* aline[3];
     const float* basis_l;       // basis_mat re-laid [app_dim][4][3*n_app/4] (lane-slice major), see field_kernels.hip
+    const float* basis_l12;     // basis_mat re-laid [app_dim][n_app/4][12] for the 12-lanes-per-point gather (K4b)
     const float* basis;         // basis_mat as given [app_dim][3*n_app]
     const uint8_t* mask;        // [D][H][W] bytes in {0,1}, or nullptr
     const float* head;          // packed Ref head, offsets below
@@ -31,21 +32,24 @@ struct FieldDev {
     int n_density, n_app, app_dim, feature_c;
 };
 
-// Ref head packing (floats): all nn.Linear weights row-major [out][in]
+// Ref head packing (floats): nn.Linear weights row-major [out][ld] with rows zero-padded to a multiple of 4 floats
+// (ld = 28 for app_dim 27, spec_ld = 168 for 128 + 39), every block 16-B aligned, so a row is read as float4s.
 struct HeadOff {
     int normal_w, normal_b, tint_w, tint_b, rough_w, rough_b, diffuse_w, diffuse_b, bott_w, bott_b, spec_w, spec_b,
-        ide_mat, total;
+        ide_mat, total, ld, spec_ld;
 };
 __host__ __device__ inline HeadOff head_offsets(int app_dim, int feature_c) {
     HeadOff o;
+    o.ld = (app_dim + 3) & ~3;
+    o.spec_ld = (feature_c + 39 + 3) & ~3;
     int p = 0;
-    o.normal_w = p; p += 3 * app_dim; o.normal_b = p; p += 3; p = (p + 3) & ~3;
-    o.tint_w = p; p += 3 * app_dim; o.tint_b = p; p += 3; p = (p + 3) & ~3;
-    o.rough_w = p; p += app_dim; o.rough_b = p; p += 1; p = (p + 3) & ~3;
-    o.diffuse_w = p; p += 3 * app_dim; o.diffuse_b = p; p += 3; p = (p + 3) & ~3;
-    o.bott_w = p; p += feature_c * app_dim; o.bott_b = p; p += feature_c; p = (p + 3) & ~3;
-    o.spec_w = p; p += 3 * (feature_c + 39); o.spec_b = p; p += 3; p = (p + 3) & ~3;
-    o.ide_mat = p; p += 9 * 19; p = (p + 3) & ~3;
+    o.normal_w = p; p += 3 * o.ld; o.normal_b = p; p += 4;
+    o.tint_w = p; p += 3 * o.ld; o.tint_b = p; p += 4;
+    o.rough_w = p; p += o.ld; o.rough_b = p; p += 4;
+    o.diffuse_w = p; p += 3 * o.ld; o.diffuse_b = p; p += 4;
+    o.bott_w = p; p += feature_c * o.ld; o.bott_b = p; p += (feature_c + 3) & ~3;
+    o.spec_w = p; p += 3 * o.spec_ld; o.spec_b = p; p += 4;
+    o.ide_mat = p; p += (9 * 19 + 3) & ~3;
     o.total = p;
     return o;
 }
@@ -252,6 +256,21 @@ __device__ inline void app_products_slice(const FieldDev& f, const float xn[3], 
     }
 }
 
+// Appearance products with one lane per 16-B texel quarter: lane c in [0, n_app/4) owns channels 4c..4c+3 of every
+// plane, so the n_app/4 lanes of a point read one contiguous 192-B texel per tap and each lane keeps only 12 products:
+// prod[4*i + e] = plane_i[4c+e] * line_i[4c+e].
+__device__ inline void app_products_lane(const FieldDev& f, const float xn[3], int c, float prod[12]) {
+    const int C = f.n_app;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Taps t;
+        make_taps(f, xn, i, t);
+        float4 p = lerp_plane4(f.aplane[i], C, t, 4 * c);
+        float4 l = lerp_line4(f.aline[i], C, t, 4 * c);
+        prod[4 * i + 0] = p.x * l.x; prod[4 * i + 1] = p.y * l.y; prod[4 * i + 2] = p.z * l.z; prod[4 * i + 3] = p.w * l.w;
+    }
+}
+
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ inline float softplusf_(float x) { return (x > 20.0f) ? x : log1pf(expf(x)); }
 
@@ -270,40 +289,39 @@ __device__ inline float sum16(float v) {
     return v;
 }
 
+// dot of one weight row with F.  Scalar indexing on purpose: rows whose address is wave-uniform (the small heads) are
+// then fetched with scalar loads into SGPRs and cost no vector registers; float4 reads of the same rows made the
+// scheduler keep every row in VGPRs at once (300+ registers, one wave per SIMD).
+template <int LD>
+__device__ inline float row_dot(const float* __restrict__ row, const float* F) {
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LD; ++k) a = fmaf(row[k], F[k], a);
+    return a;
+}
+
 // Ref.forward (models/ref.py:103-152, normals=None) evaluated by a group of 16 consecutive lanes for one ray.
-// Every lane passes the same F[27] and d[3]; `l16` is the lane's index in the group; `head` is the packed head
-// (LDS or global).  All 16 lanes return the rgb triple.  APP = app_dim (27).
-template <int APP>
+// Every lane passes the same F[LD] (app_dim features, zero padded to LD = 28) and d[3]; `l16` is the lane's index in the
+// group; `head` is the packed head (LDS or global).  All 16 lanes return the rgb triple.
+template <int LD>
 __device__ inline void ref_shade_group16(const float* head, const HeadOff& ho, int feature_c, const float* F,
                                          const float d[3], int l16, float rgb[3]) {
     // small heads, computed redundantly by every lane
     float nr[3], tint[3], diff[3], rough;
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-        float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll
-        for (int k = 0; k < APP; ++k) {
-            a = fmaf(head[ho.normal_w + o * APP + k], F[k], a);
-            b = fmaf(head[ho.tint_w + o * APP + k], F[k], b);
-            c = fmaf(head[ho.diffuse_w + o * APP + k], F[k], c);
-        }
-        nr[o] = a + head[ho.normal_b + o];
-        tint[o] = sigmoidf_(b + head[ho.tint_b + o]);
-        diff[o] = sigmoidf_((c + head[ho.diffuse_b + o]) + -1.0986122886681098f);
+        nr[o] = row_dot<LD>(head + ho.normal_w + o * LD, F) + head[ho.normal_b + o];
+        tint[o] = sigmoidf_(row_dot<LD>(head + ho.tint_w + o * LD, F) + head[ho.tint_b + o]);
+        diff[o] = sigmoidf_((row_dot<LD>(head + ho.diffuse_w + o * LD, F) + head[ho.diffuse_b + o]) + -1.0986122886681098f);
     }
-    {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < APP; ++k) a = fmaf(head[ho.rough_w + k], F[k], a);
-        rough = softplusf_((a + head[ho.rough_b]) + -1.0f);
-    }
+    rough = softplusf_((row_dot<LD>(head + ho.rough_w, F) + head[ho.rough_b]) + -1.0f);
     float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
     float n[3] = {-(nr[0] / nn), -(nr[1] / nn), -(nr[2] / nn)};   // normal_mlp: normalise then * -1
     float v[3] = {-d[0], -d[1], -d[2]};
     float ndv = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
     float r[3] = {2.0f * ndv * n[0] - v[0], 2.0f * ndv * n[1] - v[1], 2.0f * ndv * n[2] - v[2]};   // ref_utils.py:18
     float dot = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
-    const int K = feature_c + 39;
+    const int K = feature_c + 39, KL = ho.spec_ld;
     float part[3] = {0.f, 0.f, 0.f};
     // integrated directional encoding (ref_utils.py:82-112): pairs i = l16, l16 + 16
     float zp[9];
@@ -327,21 +345,18 @@ __device__ inline void ref_shade_group16(const float* head, const HeadOff& ho, i
         float re = pr * poly * att, im = pi * poly * att;
 #pragma unroll
         for (int o = 0; o < 3; ++o)
-            part[o] = fmaf(head[ho.spec_w + o * K + feature_c + 2 * i], re,
-                           fmaf(head[ho.spec_w + o * K + feature_c + 2 * i + 1], im, part[o]));
+            part[o] = fmaf(head[ho.spec_w + o * KL + feature_c + 2 * i], re,
+                           fmaf(head[ho.spec_w + o * KL + feature_c + 2 * i + 1], im, part[o]));
     }
     // bottleneck slice j = l16 + 16 t
     for (int j = l16; j < feature_c; j += 16) {
-        float b = 0.f;
+        float b = row_dot<LD>(head + ho.bott_w + j * LD, F) + head[ho.bott_b + j];
 #pragma unroll
-        for (int k = 0; k < APP; ++k) b = fmaf(head[ho.bott_w + j * APP + k], F[k], b);
-        b += head[ho.bott_b + j];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * K + j], b, part[o]);
+        for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * KL + j], b, part[o]);
     }
     if (l16 == 0) {
 #pragma unroll
-        for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * K + K - 1], dot, part[o]) + head[ho.spec_b + o];
+        for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * KL + K - 1], dot, part[o]) + head[ho.spec_b + o];
     }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {

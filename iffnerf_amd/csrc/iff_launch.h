@@ -8,6 +8,7 @@
 hipError_t launch_k0_channels_last(const float* src, float* dst, int C, int64_t HW, hipStream_t s);
 hipError_t launch_k0_mask_bytes(const float* src, uint8_t* dst, int64_t n, hipStream_t s);
 hipError_t launch_k0_basis_slices(const float* src, float* dst, int app_dim, int n_app, hipStream_t s);
+hipError_t launch_k0_basis_lanes(const float* src, float* dst, int app_dim, int n_app, hipStream_t s);
 hipError_t launch_normalize_coord(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
 hipError_t launch_mask_sample(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
 hipError_t launch_density_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s);
@@ -15,13 +16,17 @@ hipError_t launch_point_alpha(const FieldDev& f, const float* xyz, int64_t n, fl
 hipError_t launch_app_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s);
 hipError_t launch_point_normals(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
 hipError_t launch_ref_normals(const FieldDev& f, const float* feat, int64_t n, float* out, hipStream_t s);
+hipError_t launch_shade_blend(const FieldDev& f, const float* rays, int ray_cols, const float* feat28, const float* acc,
+                              const float* bg, int64_t n, float* rgb, hipStream_t s);
 hipError_t launch_ref_shade(const FieldDev& f, const float* dirs, const float* feat, int64_t n, float* rgb, hipStream_t s);
 
 // march_kernels.hip
 hipError_t launch_isocell_emit(const float* cells27x3_host, const float* pts, const float* nrm, int64_t P, float* ori,
-                               float* dirs, hipStream_t s);
+                               float* dirs, float* rays6, hipStream_t s);
+size_t march_workspace_bytes(int64_t R, int S);
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
-                        float* rgb, float* depth, float* acc, float* alpha, int* counts, hipStream_t s);
+                        float* rgb, float* depth, float* acc, float* alpha, int* counts, void* ws, size_t ws_bytes,
+                        hipStream_t s);
 
 // sampler_kernels.hip
 size_t sampler_workspace_bytes(int64_t P);

@@ -5,14 +5,21 @@
 //   epoch    :143-213 thresh = quantile(alpha, 0.6); while some samples are still "invalid": every invalid sample gets
 //            m = (5 P) // n_invalid jittered candidates (:35-67: uniform direction, |N(0,rho)| radius); those with
 //            alpha > thresh pass; one passing candidate per sample is picked uniformly and replaces the sample.
-// The reference does this with argsort/argwhere/scatter_reduce and two host syncs per iteration.  Here every candidate is
-// an independent (sample, j) work item with its own counter-based random stream (Philox4x32-10 keyed by
-// seed / epoch / iteration / sample / j), a passing candidate competes with a random 32-bit priority through a 64-bit
-// atomicMax (uniform pick, order independent => bitwise reproducible), and iterations are separated by an in-kernel
-// grid barrier (agent-scope release/acquire, bounded spins).  The random streams necessarily differ from torch's CPU
-// generator, so parity for this stage is distributional (tests/test_sampler.py), as SURVEY.md section 7.4 #2 records.
+// The reference does this with argsort/argwhere/scatter_reduce and two host syncs per iteration.  Here
+//   * every candidate is an independent (sample, j) work item with its own counter-based random stream (Philox4x32-10
+//     keyed by seed / epoch / iteration / sample / j) served by 4 lanes (one texel quarter each);
+//   * a passing candidate competes with a random 32-bit priority through a 64-bit atomicMax on its sample's slot: a
+//     uniform pick that is independent of execution order, so runs are bitwise reproducible;
+//   * the slot keeps (iteration, j) of the winner, so nothing but that one word crosses workgroups during an epoch:
+//     every workgroup rebuilds the (sorted) list of still-invalid samples in its own LDS from the slots, and the
+//     accepted positions are re-derived from the random stream when the epoch ends;
+//   * iterations are separated by a grid barrier that needs NO cache maintenance (only memory-side atomics were
+//     exchanged); one release/acquire barrier per epoch publishes the moved samples.  All spins are bounded.
+// torch's CPU generator cannot be reproduced on the device, so parity for this stage is distributional
+// (tests/test_hip_sampler.py), as SURVEY.md section 7.4 #2 records.
 #include "iff_device.h"
 #include "iff_launch.h"
+#include "iff_select.h"
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 struct U4 { uint32_t x, y, z, w; };
@@ -33,42 +40,32 @@ __device__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777
 
 // ------------------------------------------------------------------------------------------------ workspace layout
 constexpr int SAMPLER_MAX_EPOCHS = 64;
-constexpr int SAMPLER_MAX_ITERS = 4096;
+constexpr int SAMPLER_MAX_ITERS = 4095;
+constexpr int SAMPLER_MAX_POINTS = 32768;          // the invalid list lives in LDS (4 B per sample)
 struct SamplerWs {
     unsigned barrier_count;     // monotonic arrivals
     unsigned abort_flag;
-    float thresh[SAMPLER_MAX_EPOCHS];   // one slot per epoch: written once, never reused inside a launch
-    // followed by: left[n_epochs*max_iterations] (int; samples still invalid after each iteration, one slot each so
-    // no counter is ever reset while another workgroup may still read it), winners[P] (u64), list_a[P], list_b[P] (int),
-    // cand_pos[5P][3], cand_alpha[5P]
+    unsigned pad[62];
+    // followed by: winners[2][P] (u64, double-buffered by epoch parity)
 };
-
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-struct SamplerLayout { size_t left, winners, list_a, list_b, cand_pos, cand_alpha, total; };
-__host__ __device__ inline SamplerLayout sampler_layout(int64_t P) {
-    SamplerLayout L;
-    size_t p = align_up(sizeof(SamplerWs), 256);
-    L.left = p; p = align_up(p + (size_t)SAMPLER_MAX_EPOCHS * SAMPLER_MAX_ITERS / 16 * 4, 256);   // 16 Ki counters
-    L.winners = p; p = align_up(p + (size_t)P * 8, 256);
-    L.list_a = p; p = align_up(p + (size_t)P * 4, 256);
-    L.list_b = p; p = align_up(p + (size_t)P * 4, 256);
-    L.cand_pos = p; p = align_up(p + (size_t)5 * P * 3 * 4, 256);
-    L.cand_alpha = p; p = align_up(p + (size_t)5 * P * 4, 256);
-    L.total = p;
-    return L;
-}
-size_t sampler_workspace_bytes(int64_t P) { return sampler_layout(P).total; }
+size_t sampler_workspace_bytes(int64_t P) { return align_up(sizeof(SamplerWs), 256) + align_up((size_t)P * 16, 256); }
 
-// ------------------------------------------------------------------------------------------------ grid barrier
-// Placement-independent (cdna guide, Guideline 16): every wave drains its stores, workgroup barrier, lane 0 releases at
-// agent scope and arrives on a monotonic counter, polls it relaxed, acquires at agent scope, workgroup barrier.  Spins are
-// bounded: on timeout the abort flag is raised and every workgroup leaves at its next check.
+// ------------------------------------------------------------------------------------------------ grid barriers
+// Placement-independent (cdna guide, Guideline 16).  FENCED: every wave drains its stores, workgroup barrier, lane 0
+// releases at agent scope, arrives on a monotonic counter, polls it relaxed, acquires at agent scope, workgroup barrier
+// -- plain loads after it see every plain store before it.  Unfenced: same arrival protocol without the cache
+// maintenance; correct when the only cross-workgroup traffic since the last fenced barrier went through atomics.
+// Spins are bounded: on timeout the abort flag is raised and every workgroup leaves at its next check.
+template <bool FENCED>
 __device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores and no-return atomics of this wave are complete
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FENCED) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         generation += 1;
         const unsigned target = generation * gridDim.x;
         __hip_atomic_fetch_add(&ws->barrier_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -81,64 +78,26 @@ __device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation) {
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FENCED) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
     return __hip_atomic_load(&ws->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
-// alpha = compute_alpha(p, length=1) by the 4 lanes that share the point (all 4 return it)
+// alpha = compute_alpha(p, length=1) by the 4 lanes that share the point (all 4 return it).  The occupancy test and the
+// density taps are issued together (both are safe for any coordinate); the result is selected afterwards.
 __device__ inline float alpha4(const FieldDev& f, const float p[3], int sub, bool live) {
-    bool valid = live;
-    if (valid && f.mask) valid = mask_value(f, p) > 0.0f;
-    float part = 0.0f;
-    if (valid) {
-        float xn[3];
-        field_normalize(f, p, xn);
-        part = density_partial(f, xn, sub);
-    }
-    float feat = sum4(part);
+    float xn[3];
+    field_normalize(f, p, xn);
+    float mv = f.mask ? mask_value(f, p) : 1.0f;
+    float part = density_partial(f, xn, sub);
+    bool valid = live && (mv > 0.0f);
+    float feat = sum4(valid ? part : 0.0f);
     float sigma = valid ? feature2density(f, feat) : 0.0f;
     return 1.0f - expf(-sigma * 1.0f);
-}
-
-// order-preserving key and single-workgroup k-th smallest (radix select), used for torch.quantile
-__device__ inline uint32_t okey(float v) {
-    uint32_t u = __float_as_uint(v);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ inline float okey_inv(uint32_t k) {
-    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-__device__ float wg_kth_smallest(const float* v, int n, int k /*0-based*/, int* hist) {
-    uint32_t prefix = 0, mask = 0;
-    int remaining = k + 1;
-    for (int pass = 3; pass >= 0; --pass) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        const int shift = pass * 8;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            uint32_t key = okey(v[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int rem = remaining, b = 0;
-            for (; b < 255; ++b) {
-                if (hist[b] >= rem) break;
-                rem -= hist[b];
-            }
-            hist[256] = b; hist[257] = rem;
-        }
-        __syncthreads();
-        prefix |= ((uint32_t)hist[256]) << shift;
-        remaining = hist[257];
-        mask |= 255u << shift;
-        __syncthreads();
-    }
-    return okey_inv(prefix);
 }
 
 struct SamplerArgs {
@@ -154,21 +113,42 @@ struct SamplerArgs {
     int n_occ;
 };
 
+// jittered candidate j of sample i (sampling.py:38-66): theta = 2 pi u, phi = arccos(1 - 2u), radius |N(0, rho)|
+__device__ inline void candidate_position(const SamplerArgs& a, const float base[3], int i, int j, int epoch, int it,
+                                          float p[3], uint32_t& prio) {
+    U4 c0 = U4{(uint32_t)i, (uint32_t)j, (uint32_t)(epoch * 4096 + it), 0xA5u};
+    U4 r0 = philox4x32_10(c0, a.seed_lo, a.seed_hi);
+    float theta = 6.283185307179586f * u01(r0.x);
+    float phi = acosf(1.0f - 2.0f * u01(r0.y));
+    float sp = sinf(phi);
+    float dir[3] = {sp * cosf(theta), sp * sinf(theta), cosf(phi)};
+    float u1 = 1.0f - u01(r0.z);                       // (0,1]
+    float g = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u01(r0.w));
+    float dist = fabsf(g * a.rho);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = base[c] + dir[c] * dist;
+    c0.w = 0xA6u;
+    prio = philox4x32_10(c0, a.seed_lo, a.seed_hi).x;
+}
+
 __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs a) {
-    __shared__ int hist[258];
+    extern __shared__ int s_list[];               // [P] still-invalid sample ids, ascending
+    __shared__ int hist[264];
+    __shared__ int s_tot[4];
     SamplerWs* ws = (SamplerWs*)a.ws;
-    const SamplerLayout L = sampler_layout(a.P);
-    int* left = (int*)(a.ws + L.left);
-    unsigned long long* winners = (unsigned long long*)(a.ws + L.winners);
-    int* list_cur = (int*)(a.ws + L.list_a);
-    int* list_nxt = (int*)(a.ws + L.list_b);
-    float* cand_pos = (float*)(a.ws + L.cand_pos);
-    float* cand_alpha = (float*)(a.ws + L.cand_alpha);
+    unsigned long long* winners_base = (unsigned long long*)(a.ws + align_up(sizeof(SamplerWs), 256));
     const int P = (int)a.P;
-    const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + tid;
     const int64_t gthreads = (int64_t)gridDim.x * blockDim.x;
     unsigned generation = 0;
+#define IFF_SYNC_OR_ABORT(FENCED)                            \
+    if (!grid_sync<FENCED>(ws, generation)) {                \
+        if (gtid == 0) a.stats[3] = -1; /* timed out */      \
+        return;                                              \
+    }
 
+    for (int64_t t = gtid; t < 4 * (int64_t)a.n_epochs; t += gthreads) a.stats[t] = 0;
     // ---------------- seeds (sampling.py:78-116,131-140)
     {
         const int W = f.mask_dims[2], H = f.mask_dims[1], D = f.mask_dims[0];
@@ -196,93 +176,100 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
             if (live && sub == 0) {
                 a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
                 a.alpha[i] = al;
-                winners[i] = 0ull;
-                list_cur[i] = i;
             }
         }
     }
-#define IFF_SYNC_OR_ABORT()                                   \
-    if (!grid_sync(ws, generation)) {                        \
-        if (gtid == 0) a.stats[3] = -1; /* timed out */      \
-        return;                                              \
-    }
-    IFF_SYNC_OR_ABORT();
+    IFF_SYNC_OR_ABORT(true);
 
     for (int epoch = 0; epoch < a.n_epochs; ++epoch) {
-        // ---------------- threshold = torch.quantile(alpha, 0.6) (linear interpolation), workgroup 0
-        if (blockIdx.x == 0) {
+        unsigned long long* winners = winners_base + (size_t)(epoch & 1) * P;
+        unsigned long long* winners_next = winners_base + (size_t)((epoch + 1) & 1) * P;
+        // ---------------- threshold = torch.quantile(alpha, 0.6), linear interpolation; every workgroup computes it
+        float thresh;
+        {
             float pos = 0.6f * (float)(P - 1);
             int lo = (int)floorf(pos);
             int hi = min(lo + 1, P - 1);
             float frac = pos - (float)lo;
-            float vlo = wg_kth_smallest(a.alpha, P, lo, hist);
-            float vhi = wg_kth_smallest(a.alpha, P, hi, hist);
-            if (threadIdx.x == 0) {
-                // torch.lerp: lo + w (hi - lo) for w < 0.5, hi - (hi - lo)(1 - w) otherwise
-                ws->thresh[epoch] = (frac < 0.5f) ? (vlo + (vhi - vlo) * frac) : (vhi - (vhi - vlo) * (1.0f - frac));
-            }
+            float vlo = iff_order_key_inv(iff_wg_select_key<false>(a.alpha, P, lo + 1, hist));
+            float vhi = iff_order_key_inv(iff_wg_select_key<false>(a.alpha, P, hi + 1, hist));
+            // torch.lerp: lo + w (hi - lo) for w < 0.5, hi - (hi - lo)(1 - w) otherwise
+            thresh = (frac < 0.5f) ? (vlo + (vhi - vlo) * frac) : (vhi - (vhi - vlo) * (1.0f - frac));
         }
-        for (int64_t t = gtid; t < P; t += gthreads) list_cur[t] = (int)t;
-        IFF_SYNC_OR_ABORT();
-        const float thresh = ws->thresh[epoch];
+        for (int t = tid; t < P; t += 256) s_list[t] = t;
+        __syncthreads();
         int K = P, it = 0, m_last = 0;
         while (K != 0 && it < a.max_iterations) {
             // ---------------- candidates: m per invalid sample, 4 lanes each
             const int m = (5 * P) / K;
             m_last = m;
-            const int64_t n_slots = (int64_t)K * m;
-            const int64_t nt = n_slots * 4;
+            const int64_t nt = (int64_t)K * m * 4;
             for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
                 bool live = t < nt;
                 int64_t slot = live ? (t >> 2) : 0;
                 int sub = (int)(t & 3);
                 int li = (int)(slot / m), j = (int)(slot - (int64_t)li * m);
-                int i = list_cur[li];
-                U4 c0 = U4{(uint32_t)i, (uint32_t)j, (uint32_t)(epoch * 4096 + it), 0xA5u};
-                U4 r0 = philox4x32_10(c0, a.seed_lo, a.seed_hi);
-                c0.w = 0xA6u;
-                U4 r1 = philox4x32_10(c0, a.seed_lo, a.seed_hi);
-                // sampling.py:38-66: theta = 2 pi u, phi = arccos(1 - 2u), radius |N(0, rho)|
-                float theta = 6.283185307179586f * u01(r0.x);
-                float phi = acosf(1.0f - 2.0f * u01(r0.y));
-                float sp = sinf(phi);
-                float dir[3] = {sp * cosf(theta), sp * sinf(theta), cosf(phi)};
-                float u1 = 1.0f - u01(r0.z);                       // (0,1]
-                float g = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u01(r0.w));
-                float dist = fabsf(g * a.rho);
-                float p[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) p[c] = a.samples[3 * i + c] + dir[c] * dist;
+                int i = s_list[li];
+                float base[3] = {a.samples[3 * i], a.samples[3 * i + 1], a.samples[3 * i + 2]}, p[3];
+                uint32_t prio;
+                candidate_position(a, base, i, j, epoch, it, p, prio);
                 float al = alpha4(f, p, sub, live);
-                if (live && sub == 0) {
-                    cand_pos[3 * slot] = p[0]; cand_pos[3 * slot + 1] = p[1]; cand_pos[3 * slot + 2] = p[2];
-                    cand_alpha[slot] = al;
-                    if (al > thresh) {
-                        unsigned long long key = ((unsigned long long)r1.x << 32) | (unsigned long long)(unsigned)(j + 1);
-                        atomicMax(&winners[i], key);
-                    }
+                if (live && sub == 0 && al > thresh) {
+                    unsigned long long key = ((unsigned long long)prio << 32) | ((unsigned long long)it << 20) |
+                                             (unsigned long long)(unsigned)(j + 1);
+                    atomicMax(&winners[i], key);
                 }
             }
-            IFF_SYNC_OR_ABORT();
-            // ---------------- resolve: accepted samples move, the rest queue for the next iteration
-            for (int64_t li = gtid; li < K; li += gthreads) {
-                int i = list_cur[li];
-                unsigned long long wv = atomicExch(&winners[i], 0ull);   // memory-side read-and-clear
-                if (wv != 0ull) {
-                    int j = (int)(wv & 0xffffffffull) - 1;
-                    int64_t slot = (int64_t)li * m + j;
-                    a.samples[3 * i] = cand_pos[3 * slot]; a.samples[3 * i + 1] = cand_pos[3 * slot + 1];
-                    a.samples[3 * i + 2] = cand_pos[3 * slot + 2];
-                    a.alpha[i] = cand_alpha[slot];
-                } else {
-                    int pos = atomicAdd(&left[epoch * a.max_iterations + it], 1);
-                    list_nxt[pos] = i;
+            IFF_SYNC_OR_ABORT(false);
+            // ---------------- every workgroup drops the accepted samples from its own copy of the list (in place,
+            // order kept): chunk of 256 entries at a time, ballot prefix inside a wave, 4 wave totals through LDS
+            int kept = 0;
+            for (int c0 = 0; c0 < K; c0 += 256) {
+                int li = c0 + tid;
+                int i = (li < K) ? s_list[li] : -1;
+                bool stay = false;
+                if (i >= 0) {
+                    // a workgroup that is already one iteration ahead may have posted a key for iteration it+1 on a
+                    // slot that was empty at the barrier: such keys do not count yet (skew is bounded by one barrier)
+                    unsigned long long wv = __hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stay = (wv == 0ull) || ((int)((wv >> 20) & 0xfffull) > it);
                 }
+                unsigned long long bal = __ballot(stay);
+                int before = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) s_tot[wave] = __popcll(bal);
+                __syncthreads();                    // all reads of this chunk are done; totals visible
+                int base = kept;
+                for (int w = 0; w < wave; ++w) base += s_tot[w];
+                if (stay) s_list[base + before] = i;
+                kept += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+                __syncthreads();
             }
-            IFF_SYNC_OR_ABORT();
-            K = __hip_atomic_load(&left[epoch * a.max_iterations + it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            K = kept;
             it += 1;
-            int* tmp = list_cur; list_cur = list_nxt; list_nxt = tmp;
+        }
+        // ---------------- apply: the accepted samples move to their winning candidate (re-derived from the stream)
+        {
+            const int64_t nt = (int64_t)P * 4;
+            for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
+                bool live = t < nt;
+                int i = live ? (int)(t >> 2) : 0;
+                int sub = (int)(t & 3);
+                unsigned long long wv = live ? __hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                bool moved = wv != 0ull;
+                int j = (int)(wv & 0xfffffull) - 1, wit = (int)((wv >> 20) & 0xfffull);
+                float base[3] = {a.samples[3 * i], a.samples[3 * i + 1], a.samples[3 * i + 2]}, p[3];
+                uint32_t prio;
+                candidate_position(a, base, i, moved ? j : 0, epoch, wit, p, prio);
+                float al = alpha4(f, p, sub, live && moved);
+                if (live && sub == 0) {
+                    if (moved) {
+                        a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
+                        a.alpha[i] = al;
+                    }
+                    // the other parity's slots were last read one epoch ago: clear them for the next epoch
+                    __hip_atomic_store(&winners_next[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         if (gtid == 0) {
             a.stats[epoch * 4 + 0] = it;
@@ -290,28 +277,32 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
             a.stats[epoch * 4 + 2] = __float_as_int(thresh);
             a.stats[epoch * 4 + 3] = m_last;
         }
+        IFF_SYNC_OR_ABORT(true);
     }
 }
 
 hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int64_t P, int n_epochs,
                                      int max_iterations, uint64_t seed, float rho, float* samples, float* alpha, int* stats,
                                      void* ws, size_t ws_bytes, int n_cus, hipStream_t s) {
-    if (P < 1 || P > (1 << 24) || n_epochs < 0 || n_epochs > SAMPLER_MAX_EPOCHS || max_iterations < 0 ||
-        (int64_t)n_epochs * max_iterations > (int64_t)SAMPLER_MAX_EPOCHS * SAMPLER_MAX_ITERS / 16)
+    if (P < 1 || P > SAMPLER_MAX_POINTS || n_epochs < 0 || n_epochs > SAMPLER_MAX_EPOCHS || max_iterations < 0 ||
+        max_iterations > SAMPLER_MAX_ITERS)
         return hipErrorInvalidValue;
     if (ws_bytes < sampler_workspace_bytes(P)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(ws, 0, sampler_layout(P).winners, s);   // header + per-iteration counters
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(stats, 0, sizeof(int) * 4 * (size_t)n_epochs, s);
+    hipError_t e = hipMemsetAsync(ws, 0, sampler_workspace_bytes(P), s);   // barrier words + both winner buffers
     if (e != hipSuccess) return e;
     SamplerArgs a;
     a.P = P; a.n_epochs = n_epochs; a.max_iterations = max_iterations;
     a.seed_lo = (uint32_t)(seed & 0xffffffffu); a.seed_hi = (uint32_t)(seed >> 32);
     a.rho = rho; a.samples = samples; a.alpha = alpha; a.stats = stats; a.ws = (unsigned char*)ws;
     a.occ_list = occ_list; a.n_occ = n_occ;
-    // one workgroup per CU at most, so the grid is co-resident and the in-kernel barrier cannot deadlock
+    // one workgroup per CU at most, so the grid is co-resident and the in-kernel barriers cannot deadlock
     int64_t want = (5 * P * 4 + 255) / 256;
     int grid = (int)(want < 1 ? 1 : (want > n_cus ? n_cus : want));
-    hipLaunchKernelGGL(k_surface_sample, dim3(grid), dim3(256), 0, s, f, a);
+    const size_t lds = (size_t)P * sizeof(int);
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute((const void*)k_surface_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_surface_sample, dim3(grid), dim3(256), lds, s, f, a);
     return hipGetLastError();
 }

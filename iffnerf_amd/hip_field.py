@@ -193,9 +193,12 @@ class FieldHandle:
         acc = r.new_empty(R)
         alpha = r.new_empty(R, S) if want_alpha else None
         counts = torch.empty(R, 2, dtype=torch.int32, device=r.device) if want_counts else None
+        ws_bytes = int(_lib.lib().iff_march_workspace(self._h, R, mode, S)) if R > 0 else 0
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=r.device)   # weights + per-ray features
         with torch.cuda.device(self.device):
             check(_lib.lib().iff_march_shade(self._h, dptr(r), r.shape[1], R, mode, S, fvec(bg), dptr(rgb), dptr(depth),
-                                             dptr(acc), dptr(alpha), dptr(counts, torch.int32), stream_ptr(self.device)),
+                                             dptr(acc), dptr(alpha), dptr(counts, torch.int32), ws.data_ptr(),
+                                             ws.numel() * 4, stream_ptr(self.device)),
                   "iff_march_shade")
         return rgb, depth, acc, alpha, counts, S
 
@@ -215,8 +218,8 @@ class FieldHandle:
         return samples, alpha, stats
 
 
-def isocell_emit(cells: torch.Tensor, points: torch.Tensor, normals: torch.Tensor):
-    """rotate_isocell + renormalise + origin broadcast -> (ori [27P,3], dirs [27P,3])."""
+def isocell_emit(cells: torch.Tensor, points: torch.Tensor, normals: torch.Tensor, want_rays6: bool = False):
+    """rotate_isocell + renormalise + origin broadcast -> (ori [27P,3], dirs [27P,3]) (+ rays [27P,6] when asked)."""
     if not points.is_cuda:
         raise RuntimeError("points must live on the GPU; libiffnerf_hip has no CPU path")
     if cells.shape != (27, 3):
@@ -226,11 +229,12 @@ def isocell_emit(cells: torch.Tensor, points: torch.Tensor, normals: torch.Tenso
     P = p.shape[0]
     ori = p.new_empty(P * 27, 3)
     dirs = p.new_empty(P * 27, 3)
+    rays6 = p.new_empty(P * 27, 6) if want_rays6 else None
     c = fvec(cells.detach().cpu().reshape(-1).tolist())
     with torch.cuda.device(p.device):
-        check(_lib.lib().iff_isocell_emit(c, dptr(p), dptr(n), P, dptr(ori), dptr(dirs), stream_ptr(p.device)),
+        check(_lib.lib().iff_isocell_emit(c, dptr(p), dptr(n), P, dptr(ori), dptr(dirs), dptr(rays6), stream_ptr(p.device)),
               "iff_isocell_emit")
-    return ori, dirs
+    return (ori, dirs, rays6) if want_rays6 else (ori, dirs)
 
 
 def field_handle_from_ckpt(ckpt: dict, device) -> FieldHandle:

@@ -43,8 +43,8 @@ class PosePipeline:
         if point_range is not None:
             samples = samples[point_range[0]:point_range[1]].contiguous()
         normals = self.field.point_normals(samples)
-        ori, dirs = isocell_emit(self.cells, samples, normals)
-        rgb = self.field.march(torch.cat((ori, dirs), dim=-1), 0, 20, want_alpha=False)[0]
+        ori, dirs, rays = isocell_emit(self.cells, samples, normals, want_rays6=True)
+        rgb = self.field.march(rays, 0, 20, want_alpha=False)[0]
         self.last_sampler_stats = stats
         return ori, dirs, rgb
 

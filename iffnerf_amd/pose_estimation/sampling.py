@@ -57,6 +57,6 @@ def generate_all_possible_rays(point_sampling, point_normals, model, num_viewdir
                                sample_isocell_targets=27):
     from ..hip_field import isocell_emit
     cells = sampling_isocell(dtype=point_sampling.dtype, device="cpu", num_targets=sample_isocell_targets)
-    ori, dirs = isocell_emit(cells, point_sampling, point_normals)
-    rgb = model.march(torch.cat((ori, dirs), dim=-1), point_centred=True, N_samples=20)[0]
+    ori, dirs, rays = isocell_emit(cells, point_sampling, point_normals, want_rays6=True)
+    rgb = model.march(rays, point_centred=True, N_samples=20)[0]
     return ori, dirs, rgb

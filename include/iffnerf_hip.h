@@ -112,18 +112,21 @@ int iff_ref_normals(const iff_field* f, const float* features, int64_t n, float*
 
 /* rotate_isocell + renormalise + origin broadcast: pose_estimation/isocell.py:144-171,
  * pose_estimation/sampling.py:449-461.  cells_host [27,3] = isocell_distribution(27) (host floats, isocell.py:6-68);
- * points,normals [P,3] -> ori,dirs [27*P,3] (point-major, 27 directions contiguous). */
+ * points,normals [P,3] -> ori,dirs [27*P,3] (point-major, 27 directions contiguous); rays6_opt [27*P,6] (nullable)
+ * receives the same rays as (o, d) rows, the layout TensorBase.forward takes (sampling.py:246). */
 int iff_isocell_emit(const float* cells_host, const float* points, const float* normals, int64_t P, float* ori, float* dirs,
-                     void* stream);
+                     float* rays6_opt, void* stream);
 
 /* TensorBase.forward, models/tensorBase.py:775-917 (is_train=False, ndc_ray=False).
  *   rays [R, ray_cols] (ray_cols 6 or 7: o, d, [radius]); mode IFF_MARCH_*; n_samples <= 0 -> default
  *   (20 for point-centred, field n_samples for slab); bg [3] host floats.
  *   rgb [R,3], depth [R], acc [R] required; alpha [R,S] and counts [R,2] (valid, shaded samples) optional.
+ *   Workspace (the [R,S] compositing weights between the two launches): iff_march_workspace(f, R, mode, n_samples).
  * Also what renderer.OctreeRender_trilinear_fast (renderer.py:12-25) calls per chunk. */
+size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples);
 int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                     int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
-                    float* alpha_opt, int32_t* counts_opt, void* stream);
+                    float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------- surface sampler
  * iterative_surface_sampling_process, pose_estimation/sampling.py:509-532 (+ :78-116,131-213,35-67):
