@@ -244,9 +244,9 @@ extern "C" size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mod
     return march_workspace_bytes(R, march_samples(f, mode, n_samples));
 }
 
-extern "C" int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
-                               int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc, float* alpha_opt,
-                               int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream) {
+static int march_impl(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                      int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc, float* alpha_opt,
+                      int32_t* counts_opt, void* workspace, size_t workspace_bytes, float* stage_ms_host, void* stream) {
     IFF_REQUIRE(f != nullptr && R >= 0, "iff_march_shade: bad argument");
     if (R == 0) return 0;
     IFF_REQUIRE(rays && rgb && depth && acc && bg_host, "iff_march_shade: null buffer");
@@ -260,8 +260,25 @@ extern "C" int iff_march_shade(const iff_field* f, const float* rays, int32_t ra
         return fail(IFF_ERR_UNSUPPORTED, "slab sampler with contraction_type='unisphere' is not built "
                                          "(the reference's own branch is unfinished: models/tensorBase.py:511-525)");
     IFF_HIP(launch_march(f->dev, rays, ray_cols, R, mode, S, bg_host, rgb, depth, acc, alpha_opt, counts_opt, workspace,
-                         workspace_bytes, (hipStream_t)stream));
+                         workspace_bytes, stage_ms_host, (hipStream_t)stream));
     return 0;
+}
+
+extern "C" int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                               int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc, float* alpha_opt,
+                               int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream) {
+    return march_impl(f, rays, ray_cols, R, mode, n_samples, bg_host, rgb, depth, acc, alpha_opt, counts_opt, workspace,
+                      workspace_bytes, nullptr, stream);
+}
+
+extern "C" int iff_march_shade_timed(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                                     int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
+                                     float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes,
+                                     float* stage_ms_host, void* stream) {
+    IFF_REQUIRE(stage_ms_host != nullptr, "iff_march_shade_timed: stage_ms_host is null");
+    stage_ms_host[0] = stage_ms_host[1] = stage_ms_host[2] = 0.0f;
+    return march_impl(f, rays, ray_cols, R, mode, n_samples, bg_host, rgb, depth, acc, alpha_opt, counts_opt, workspace,
+                      workspace_bytes, stage_ms_host, stream);
 }
 
 extern "C" size_t iff_surface_sample_workspace(int64_t P) { return P > 0 ? sampler_workspace_bytes(P) : 0; }

@@ -268,8 +268,14 @@ size_t march_workspace_bytes(int64_t R, int S) { return march_feat_offset(R, S) 
 
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
                         float* rgb, float* depth, float* acc, float* alpha, int* counts, void* ws, size_t ws_bytes,
-                        hipStream_t s) {
+                        float* stage_ms_host, hipStream_t s) {
     if (ws_bytes < march_workspace_bytes(R, S)) return hipErrorInvalidValue;
+    // optional per-launch timing (bench.py's roofline): events on the launch stream, one synchronise at the end
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (stage_ms_host) {
+        for (auto& x : ev) { hipError_t ee = hipEventCreate(&x); if (ee != hipSuccess) return ee; }
+        (void)hipEventRecord(ev[0], s);
+    }
     MarchArgs a;
     a.rays = rays; a.ray_cols = ray_cols; a.R = R; a.mode = mode; a.S = S;
     a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2];
@@ -280,10 +286,20 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     hipLaunchKernelGGL(k4a_density_composite, dim3((unsigned)grid), dim3(256), 0, s, f, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
     grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
     hipLaunchKernelGGL((k4b_appearance<27>), dim3((unsigned)grid), dim3(256), lds, s, f, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_shade_blend(f, rays, ray_cols, a.feat, acc, a.bg, R, rgb, s);
+    if (stage_ms_host) (void)hipEventRecord(ev[2], s);
+    e = launch_shade_blend(f, rays, ray_cols, a.feat, acc, a.bg, R, rgb, s);
+    if (stage_ms_host) {
+        (void)hipEventRecord(ev[3], s);
+        hipError_t es = hipEventSynchronize(ev[3]);
+        for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&stage_ms_host[i], ev[i], ev[i + 1]);
+        for (auto& x : ev) (void)hipEventDestroy(x);
+        if (e == hipSuccess) e = es;
+    }
+    return e;
 }

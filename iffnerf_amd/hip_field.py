@@ -180,7 +180,8 @@ class FieldHandle:
 
     # ------------------------------------------------------------------ march
     def march(self, rays: torch.Tensor, mode: int, n_samples: int = -1, bg=(0.0, 0.0, 0.0), want_alpha: bool = True,
-              want_counts: bool = False):
+              want_counts: bool = False, stage_ms: Optional[list] = None):
+        """stage_ms: pass an empty list to run the instrumented (synchronous) variant; it receives the 3 launch times."""
         if rays.dim() != 2 or rays.shape[-1] not in (6, 7):
             raise RuntimeError(f"rays_chunk must be [R,6] or [R,7] (got {tuple(rays.shape)})")
         if not rays.is_cuda:
@@ -196,10 +197,18 @@ class FieldHandle:
         ws_bytes = int(_lib.lib().iff_march_workspace(self._h, R, mode, S)) if R > 0 else 0
         ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=r.device)   # weights + per-ray features
         with torch.cuda.device(self.device):
-            check(_lib.lib().iff_march_shade(self._h, dptr(r), r.shape[1], R, mode, S, fvec(bg), dptr(rgb), dptr(depth),
-                                             dptr(acc), dptr(alpha), dptr(counts, torch.int32), ws.data_ptr(),
-                                             ws.numel() * 4, stream_ptr(self.device)),
-                  "iff_march_shade")
+            if stage_ms is None:
+                check(_lib.lib().iff_march_shade(self._h, dptr(r), r.shape[1], R, mode, S, fvec(bg), dptr(rgb), dptr(depth),
+                                                 dptr(acc), dptr(alpha), dptr(counts, torch.int32), ws.data_ptr(),
+                                                 ws.numel() * 4, stream_ptr(self.device)),
+                      "iff_march_shade")
+            else:
+                ms = (C.c_float * 3)()
+                check(_lib.lib().iff_march_shade_timed(self._h, dptr(r), r.shape[1], R, mode, S, fvec(bg), dptr(rgb),
+                                                       dptr(depth), dptr(acc), dptr(alpha), dptr(counts, torch.int32),
+                                                       ws.data_ptr(), ws.numel() * 4, ms, stream_ptr(self.device)),
+                      "iff_march_shade_timed")
+                stage_ms[:] = [float(v) for v in ms]
         return rgb, depth, acc, alpha, counts, S
 
     # ------------------------------------------------------------------ surface sampler

@@ -127,6 +127,13 @@ size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t 
 int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                     int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
                     float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream);
+/* Same call (models/tensorBase.py:775-917), but SYNCHRONOUS and instrumented: stage_ms_host[3] receives the durations of
+ * its three launches (density+compositing, appearance gather, Ref shading) from hipEvents on `stream`.  Measurement
+ * aid for bench.py's roofline; not for the timed path. */
+int iff_march_shade_timed(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                          int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
+                          float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes,
+                          float* stage_ms_host, void* stream);
 
 /* ------------------------------------------------------------------------------------- surface sampler
  * iterative_surface_sampling_process, pose_estimation/sampling.py:509-532 (+ :78-116,131-213,35-67):
