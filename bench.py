@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--in-flight", type=int, default=4, help="cold queries kept in flight on separate streams (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,10 +112,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    def step(i):
-        if world_size == 1:
-            return pipe.query(tokens[0], GEN_POINTS, seed=1000 + i, k=TOPK)[0]
-        return pipe.query_sharded(tokens, GEN_POINTS, seed=1000 + i, k=TOPK)[0]
+    # N = 1: `in_flight` cold queries are kept in flight, each a captured hipGraph replayed on its own stream, so the
+    # latency-bound surface sampler of one query (47 workgroups) overlaps the throughput-bound stages of another.  Every
+    # replay bumps a device-side counter that is added to the sampler seed: no two steps draw the same rays.
+    # N > 1: eager launches on one stream (the RCCL all_gathers sit between the kernels).
+    in_flight = max(1, args.in_flight) if world_size == 1 else 1
+    if world_size == 1:
+        graphs = [pipe.capture_query(tokens[0].shape, GEN_POINTS, seed=(g + 1) << 40, k=TOPK) for g in range(in_flight)]
+        streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
+        for g in graphs:
+            g.tokens.copy_(tokens[0])
+        torch.cuda.synchronize(device)
+
+        def step(i):
+            with torch.cuda.stream(streams[i % in_flight]):
+                return graphs[i % in_flight].replay()
+    else:
+        def step(i):
+            return pipe.query_sharded(tokens, GEN_POINTS, seed=1000 + i, k=TOPK)[0]
 
     for i in range(args.warmup):
         step(i)
@@ -179,6 +194,12 @@ def main():
                     "other_kernels": {"k4a_density_composite": {"avg_launch_ms": round(march_launch_ms[0], 4),
                                                                  "achieved_GBps": round(bytes_a / (march_launch_ms[0] * 1e-3) / 1e9, 1)},
                                       "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4)}}}
+        try:   # HBM-side bytes per launch from the committed PMC passes (profiles/README.md), not measured live
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+                roofline["traffic"] = json.load(fh)["k4b_appearance<27>"]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except (OSError, KeyError, ValueError):
+            pass
         # warm path (rays resident, the reference's eval semantics): stage C only
         ori, dirs, rgb = pipe.emit(GEN_POINTS, seed=42)
         for _ in range(5):
@@ -196,7 +217,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "lego-shaped TensorVMSplit 300^3 (16/48 comps, 180^3 mask), gen_points=593 -> 16011 rays, "
                                    "M=256 tokens, top-100, cold path (A+B+C every step)",
-                       "queries_per_step": Q, "rays_total": GEN_POINTS * 27,
+                       "queries_per_step": Q, "rays_total": GEN_POINTS * 27, "queries_in_flight": in_flight,
+                       "launch": "hipGraph replay per query" if world_size == 1 else "eager",
                        "parallelism": "single GPU" if world_size == 1 else f"rays sharded over {world_size} ranks + 2 all_gathers"},
             "warm_poses_per_s": round(warm, 2),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -284,14 +284,14 @@ extern "C" int iff_march_shade_timed(const iff_field* f, const float* rays, int3
 extern "C" size_t iff_surface_sample_workspace(int64_t P) { return P > 0 ? sampler_workspace_bytes(P) : 0; }
 
 extern "C" int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t max_iterations, uint64_t seed,
-                                  float rho, float* samples, float* alpha, int32_t* stats, void* workspace,
+                                  const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha, int32_t* stats, void* workspace,
                                   size_t workspace_bytes, void* stream) {
     IFF_REQUIRE(f && samples && alpha && stats && workspace, "iff_surface_sample: null argument");
     IFF_REQUIRE(P >= 1, "iff_surface_sample: P must be >= 1");
     if (workspace_bytes < sampler_workspace_bytes(P))
         return fail(IFF_ERR_WORKSPACE, "iff_surface_sample: workspace %zu < %zu bytes", workspace_bytes, sampler_workspace_bytes(P));
     if (f->dev.mask && f->n_occ == 0) return fail(IFF_ERR_INVALID_ARGUMENT, "iff_surface_sample: the occupancy mask is empty");
-    IFF_HIP(launch_surface_sample_occ(f->dev, f->occ_list, f->n_occ, P, n_epochs, max_iterations, seed, rho, samples, alpha,
+    IFF_HIP(launch_surface_sample_occ(f->dev, f->occ_list, f->n_occ, P, n_epochs, max_iterations, seed, seed_dev_opt, rho, samples, alpha,
                                       stats, workspace, workspace_bytes, f->n_cus, (hipStream_t)stream));
     return 0;
 }

@@ -31,8 +31,8 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
 // sampler_kernels.hip
 size_t sampler_workspace_bytes(int64_t P);
 hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int64_t P, int n_epochs,
-                                     int max_iterations, uint64_t seed, float rho, float* samples, float* alpha, int* stats,
-                                     void* ws, size_t ws_bytes, int n_cus, hipStream_t s);
+                                     int max_iterations, uint64_t seed, const uint64_t* seed_dev, float rho, float* samples,
+                                     float* alpha, int* stats, void* ws, size_t ws_bytes, int n_cus, hipStream_t s);
 
 // identify_kernels.hip
 struct IdNetDev {

@@ -104,6 +104,7 @@ struct SamplerArgs {
     int64_t P;
     int n_epochs, max_iterations;
     uint32_t seed_lo, seed_hi;
+    const unsigned long long* seed_dev;   // nullable: added to the by-value seed at kernel start (graph replays vary it)
     float rho;
     float* samples;   // [P,3]
     float* alpha;     // [P]
@@ -133,6 +134,12 @@ __device__ inline void candidate_position(const SamplerArgs& a, const float base
 
 __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs a) {
     extern __shared__ int s_list[];               // [P] still-invalid sample ids, ascending
+    if (a.seed_dev) {
+        // agent-scope load: a scalar/L1-cached read can be stale when a graph node just before this one rewrote the word
+        unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) +
+                                __hip_atomic_load(a.seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.seed_lo = (uint32_t)(sd & 0xffffffffull); a.seed_hi = (uint32_t)(sd >> 32);
+    }
     __shared__ int hist[264];
     __shared__ int s_tot[4];
     SamplerWs* ws = (SamplerWs*)a.ws;
@@ -281,18 +288,29 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
     }
 }
 
+__global__ void k_zero_u64(unsigned long long* p, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int64_t P, int n_epochs,
-                                     int max_iterations, uint64_t seed, float rho, float* samples, float* alpha, int* stats,
-                                     void* ws, size_t ws_bytes, int n_cus, hipStream_t s) {
+                                     int max_iterations, uint64_t seed, const uint64_t* seed_dev, float rho, float* samples,
+                                     float* alpha, int* stats, void* ws, size_t ws_bytes, int n_cus, hipStream_t s) {
     if (P < 1 || P > SAMPLER_MAX_POINTS || n_epochs < 0 || n_epochs > SAMPLER_MAX_EPOCHS || max_iterations < 0 ||
         max_iterations > SAMPLER_MAX_ITERS)
         return hipErrorInvalidValue;
     if (ws_bytes < sampler_workspace_bytes(P)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(ws, 0, sampler_workspace_bytes(P), s);   // barrier words + both winner buffers
+    // barrier words + both winner buffers start at zero.  A kernel, not hipMemsetAsync: inside a captured hipGraph the
+    // memset node did not reliably precede the sampler on replay (ROCm 7.2) -- the barrier counter then starts from the
+    // previous replay's value and the grid barrier lets workgroups through early.
+    const int64_t n_words = (int64_t)(sampler_workspace_bytes(P) / 8);
+    hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, (unsigned long long*)ws, n_words);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     SamplerArgs a;
     a.P = P; a.n_epochs = n_epochs; a.max_iterations = max_iterations;
     a.seed_lo = (uint32_t)(seed & 0xffffffffu); a.seed_hi = (uint32_t)(seed >> 32);
+    a.seed_dev = (const unsigned long long*)seed_dev;
     a.rho = rho; a.samples = samples; a.alpha = alpha; a.stats = stats; a.ws = (unsigned char*)ws;
     a.occ_list = occ_list; a.n_occ = n_occ;
     // one workgroup per CU at most, so the grid is co-resident and the in-kernel barriers cannot deadlock

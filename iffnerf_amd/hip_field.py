@@ -212,7 +212,9 @@ class FieldHandle:
         return rgb, depth, acc, alpha, counts, S
 
     # ------------------------------------------------------------------ surface sampler
-    def surface_sample(self, n_points: int, rho: float, n_epochs: int = 4, max_iterations: int = 200, seed: int = 0):
+    def surface_sample(self, n_points: int, rho: float, n_epochs: int = 4, max_iterations: int = 200, seed: int = 0,
+                       seed_offset: Optional[torch.Tensor] = None):
+        """seed_offset: optional 1-element int64 device tensor added to ``seed`` on the device (hipGraph replays)."""
         L = _lib.lib()
         dev = self.device
         ws_bytes = int(L.iff_surface_sample_workspace(n_points))
@@ -221,7 +223,8 @@ class FieldHandle:
         alpha = torch.empty(n_points, dtype=torch.float32, device=dev)
         stats = torch.empty(max(n_epochs, 1), 4, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            check(L.iff_surface_sample(self._h, n_points, n_epochs, max_iterations, int(seed) & (2 ** 64 - 1), float(rho),
+            check(L.iff_surface_sample(self._h, n_points, n_epochs, max_iterations, int(seed) & (2 ** 64 - 1),
+                                       dptr(seed_offset, torch.int64, "seed_offset"), float(rho),
                                        dptr(samples), dptr(alpha), dptr(stats, torch.int32), ws.data_ptr(), ws_bytes,
                                        stream_ptr(dev)), "iff_surface_sample")
         return samples, alpha, stats

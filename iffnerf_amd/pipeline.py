@@ -36,10 +36,11 @@ class PosePipeline:
                    jitter_scale_from_kwargs(field_ckpt["kwargs"]), model_up)
 
     # ------------------------------------------------------------------ stage A + B  (explore_model)
-    def emit(self, gen_points: int, seed: int, point_range: Optional[Tuple[int, int]] = None):
+    def emit(self, gen_points: int, seed: int, point_range: Optional[Tuple[int, int]] = None, seed_offset=None):
         """-> (ori [27P,3], dirs [27P,3], rgb [27P,3]).  ``point_range`` keeps a contiguous block of the surface points
         (ray sharding across GPUs: every rank draws the same samples from the same seed and colours only its block)."""
-        samples, _, stats = self.field.surface_sample(gen_points, self.rho, n_epochs=4, max_iterations=200, seed=seed)
+        samples, _, stats = self.field.surface_sample(gen_points, self.rho, n_epochs=4, max_iterations=200, seed=seed,
+                                                      seed_offset=seed_offset)
         if point_range is not None:
             samples = samples[point_range[0]:point_range[1]].contiguous()
         normals = self.field.point_normals(samples)
@@ -60,10 +61,13 @@ class PosePipeline:
         idx, val = H.topk(score, k)
         return H.pose_from_topk(idx, val, ori, dirs, self.model_up), idx, val
 
-    def query(self, tokens, gen_points: int, seed: int, k: int = 100):
+    def query(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None):
         """Cold per-query path: emission + identification + pose."""
-        ori, dirs, rgb = self.emit(gen_points, seed)
+        ori, dirs, rgb = self.emit(gen_points, seed, seed_offset=seed_offset)
         return self.identify(tokens, ori, dirs, rgb, k)
+
+    def capture_query(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100) -> "CapturedQuery":
+        return CapturedQuery(self, tokens_shape, gen_points, seed, k)
 
     # ------------------------------------------------------------------ ray-sharded batch of queries (multi-GPU)
     def query_sharded(self, tokens, gen_points: int, seed: int, k: int = 100, group=None, materialize_map: bool = True):
@@ -94,3 +98,37 @@ class PosePipeline:
         poses = torch.stack([H.pose_from_topk(ar, val[q].contiguous(), pay[q, :, :3].contiguous(),
                                               pay[q, :, 3:].contiguous(), self.model_up) for q in range(Q)])
         return poses, val, idx
+
+
+class CapturedQuery:
+    """The cold query captured once as a hipGraph (torch.cuda.CUDAGraph) and replayed per query.
+
+    Replaying removes the per-launch host work (about twenty ctypes calls per query) and lets two captured queries run
+    on two streams, so the latency-bound sampler of one query overlaps the throughput-bound stages of the other.  Every
+    replay draws a fresh sampler stream: a device-side counter is bumped inside the graph and added to the seed
+    (``iff_surface_sample(..., seed_dev_opt)``).  Inputs/outputs live in static buffers: ``tokens`` in, ``c2w`` /
+    ``idx`` / ``val`` out (valid after the replay's stream has been synchronised, until the next replay).
+    """
+
+    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100):
+        dev = pipe.device
+        self.pipe = pipe
+        self.tokens = torch.zeros(tokens_shape, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                 # warm-up outside capture (lazy initialisations, allocator)
+            for _ in range(2):
+                pipe.query(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.counter += 1
+            self.c2w, self.idx, self.val = pipe.query(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+
+    def replay(self, tokens: Optional[torch.Tensor] = None):
+        if tokens is not None:
+            self.tokens.copy_(tokens, non_blocking=True)
+        self.graph.replay()
+        return self.c2w

@@ -139,13 +139,14 @@ int iff_march_shade_timed(const iff_field* f, const float* rays, int32_t ray_col
  * iterative_surface_sampling_process, pose_estimation/sampling.py:509-532 (+ :78-116,131-213,35-67):
  * P seeds in occupied mask voxels, then n_epochs epochs of "jitter <= 5P candidates, accept alpha >
  * quantile_0.6, pick one uniformly".  Device-side counter-based RNG (Philox4x32-10) keyed by `seed`;
- * no host synchronisation.  rho = jitter scale (sampling.py:518-523, computed by the caller).  samples [P,3],
+ * no host synchronisation.  seed_dev_opt (nullable, device): a 64-bit word added to `seed` when the kernel starts, so a
+ * captured hipGraph can draw a fresh stream on every replay.  rho = jitter scale (sampling.py:518-523, computed by the caller).  samples [P,3],
  * alpha [P]; stats [n_epochs,4] int32 = (iterations run, samples left invalid, float bits of the threshold, last
  * candidates-per-sample); stats[3] == -1 reports an in-kernel barrier timeout.
  * Workspace: iff_surface_sample_workspace(P). */
 size_t iff_surface_sample_workspace(int64_t P);
 int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t max_iterations, uint64_t seed,
-                       float rho, float* samples, float* alpha, int32_t* stats, void* workspace, size_t workspace_bytes,
+                       const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha, int32_t* stats, void* workspace, size_t workspace_bytes,
                        void* stream);
 
 /* ------------------------------------------------------------------------------------ identification

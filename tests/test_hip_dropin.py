@@ -112,3 +112,32 @@ def test_reference_module_paths_run_on_the_gpu(golden, dev, tmp_path, monkeypatc
         p.requires_grad_(True)
     with pytest.raises(RuntimeError, match="inference-only"):
         idm(ds.all_rgbs[0, ..., :3].to(dev), ds.all_rgbs[0, ..., 3].to(dev), ro, rd, rc)
+
+
+def test_captured_query_replays_like_eager(dev):
+    """hipGraph capture of the cold query: every replay equals the eager run with the same effective seed."""
+    from iffnerf_amd.pipeline import PosePipeline
+    ck = util.ckpt("small")
+    pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
+    tok = synthetic.make_tokens(256, 384, seed=7).to(dev)
+    eager = {s: [t.clone() for t in pipe.query(tok, 75, seed=100 + s, k=100)] for s in range(1, 5)}
+    cq = pipe.capture_query(tok.shape, 75, seed=100, k=100)
+    cq.tokens.copy_(tok)
+    torch.cuda.synchronize()
+    for s in range(1, 5):
+        cq.replay()
+        torch.cuda.synchronize()
+        assert int(cq.counter.item()) == s
+        assert torch.equal(cq.c2w, eager[s][0]) and torch.equal(cq.idx, eager[s][1]) and torch.equal(cq.val, eager[s][2])
+    # two captured queries on two streams do not disturb each other
+    cq2 = pipe.capture_query(tok.shape, 75, seed=100, k=100)
+    cq2.tokens.copy_(tok)
+    cq.counter.zero_(); cq2.counter.fill_(2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    with torch.cuda.stream(s1):
+        cq.replay()
+    with torch.cuda.stream(s2):
+        cq2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cq.c2w, eager[1][0]) and torch.equal(cq2.c2w, eager[3][0])
