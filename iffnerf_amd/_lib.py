@@ -38,7 +38,7 @@ class FieldDesc(C.Structure):
 
 
 class IdNetDesc(C.Structure):
-    _fields_ = [("feature_c", C.c_int32), ("fea", C.c_int32), ("img_fea", C.c_int32)] + [
+    _fields_ = [("feature_c", C.c_int32), ("fea", C.c_int32), ("img_fea", C.c_int32), ("gemm_mode", C.c_int32)] + [
         (n, C.c_void_p) for n in ("l1_w", "l1_b", "l2_w", "l2_b", "l3_w", "l3_b", "l4_w", "l4_b", "q_w", "q_b", "k_w", "k_b")]
 
 
@@ -71,7 +71,7 @@ SIGNATURES = {
     "iff_k_proj": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_q_proj_workspace": (_SZ, [_VP, _I32]),
     "iff_q_proj": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _SZ, _VP]),
-    "iff_attn_logits": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _F, _VP, _VP, _VP, _VP]),
+    "iff_attn_logits": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _F, _VP, _VP, _VP, _I32, _VP]),
     "iff_attn_colsum": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
     "iff_topk_workspace": (_SZ, [_I64, _I32]),
     "iff_topk": (C.c_int, [_VP, _I64, _I32, _VP, _VP, _VP, _SZ, _VP]),

@@ -317,13 +317,20 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
                     d->k_w && d->k_b, "iff_idnet_create: null weight");
     const int C = d->feature_c, Fe = d->fea, IF = d->img_fea;
     IFF_REQUIRE(C >= 16 && C % 16 == 0 && Fe >= 16 && Fe % 16 == 0 && IF >= 1, "iff_idnet_create: widths %d/%d/%d unsupported", C, Fe, IF);
+    IFF_REQUIRE(C % 32 == 0 && Fe % 32 == 0, "iff_idnet_create: widths must be multiples of 32 (got %d, %d)", C, Fe);
+    IFF_REQUIRE(d->gemm_mode == 0 || d->gemm_mode == 1, "iff_idnet_create: gemm_mode must be 0 (fp32 MFMA) or 1 (3xBF16)");
     const int KQ = (IF + 15) / 16 * 16;
+    const int XW = 160;                  // encoder input 141 padded to a multiple of 32 (identify_kernels.hip)
     iff_idnet* n = new iff_idnet();
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off = up256(off + floats * 4); return o; };
-    size_t o_w1 = take((size_t)144 * C), o_b1 = take(C), o_w2 = take((size_t)C * C), o_b2 = take(C),
-           o_w3 = take((size_t)(C + 144) * C), o_b3 = take(C), o_w4 = take((size_t)C * Fe), o_b4 = take(Fe),
+    size_t o_w1 = take((size_t)XW * C), o_b1 = take(C), o_w2 = take((size_t)C * C), o_b2 = take(C),
+           o_w3 = take((size_t)(C + XW) * C), o_b3 = take(C), o_w4 = take((size_t)C * Fe), o_b4 = take(Fe),
            o_wk = take((size_t)Fe * Fe), o_bk = take(Fe), o_wq = take((size_t)KQ * Fe), o_bq = take(Fe);
+    // bf16 planes: 3 x out x K_pad halves = 1.5 floats per element
+    auto take_planes = [&](size_t out_f, size_t kpad) { return take((out_f * kpad * 3 + 1) / 2); };
+    size_t o_p1 = take_planes(C, XW), o_p2 = take_planes(C, C), o_p3 = take_planes(C, C + XW), o_p4 = take_planes(Fe, C),
+           o_pk = take_planes(Fe, Fe);
     n->slab_bytes = off;
     hipError_t e = hipMalloc(&n->slab, off);
     if (e != hipSuccess) { delete n; return hip_fail(e, "hipMalloc(idnet weights)"); }
@@ -334,13 +341,18 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
         if (e__ != hipSuccess) { iff_idnet_destroy(n); return hip_fail(e__, #call); } \
     } while (0)
     IFF_NET_HIP(hipMemsetAsync(n->slab, 0, off, s));
-    IFF_NET_HIP(launch_transpose_pad(d->l1_w, (float*)(b + o_w1), C, IFF_RAY_INPUT, 144, 0, s));
+    IFF_NET_HIP(launch_transpose_pad(d->l1_w, (float*)(b + o_w1), C, IFF_RAY_INPUT, XW, 0, s));
     IFF_NET_HIP(launch_transpose_pad(d->l2_w, (float*)(b + o_w2), C, C, C, 0, s));
     // layer 3 consumes [h (C) | x (141)]: its weight columns 0..C-1 go to rows 0..C-1, columns C.. to rows C..C+140
-    IFF_NET_HIP(launch_transpose_pad(d->l3_w, (float*)(b + o_w3), C, C + IFF_RAY_INPUT, C + 144, 0, s));
+    IFF_NET_HIP(launch_transpose_pad(d->l3_w, (float*)(b + o_w3), C, C + IFF_RAY_INPUT, C + XW, 0, s));
     IFF_NET_HIP(launch_transpose_pad(d->l4_w, (float*)(b + o_w4), Fe, C, C, 0, s));
     IFF_NET_HIP(launch_transpose_pad(d->k_w, (float*)(b + o_wk), Fe, Fe, Fe, 0, s));
     IFF_NET_HIP(launch_transpose_pad(d->q_w, (float*)(b + o_wq), Fe, IF, KQ, 0, s));
+    IFF_NET_HIP(launch_split_rows(d->l1_w, b + o_p1, C, IFF_RAY_INPUT, XW, s));
+    IFF_NET_HIP(launch_split_rows(d->l2_w, b + o_p2, C, C, C, s));
+    IFF_NET_HIP(launch_split_rows(d->l3_w, b + o_p3, C, C + IFF_RAY_INPUT, C + XW, s));
+    IFF_NET_HIP(launch_split_rows(d->l4_w, b + o_p4, Fe, C, C, s));
+    IFF_NET_HIP(launch_split_rows(d->k_w, b + o_pk, Fe, Fe, Fe, s));
     struct { const float* src; size_t off; int n; } bs[] = {{d->l1_b, o_b1, C}, {d->l2_b, o_b2, C}, {d->l3_b, o_b3, C},
                                                             {d->l4_b, o_b4, Fe}, {d->k_b, o_bk, Fe}, {d->q_b, o_bq, Fe}};
     for (auto& p : bs) IFF_NET_HIP(hipMemcpyAsync(b + p.off, p.src, (size_t)p.n * 4, hipMemcpyDeviceToDevice, s));
@@ -348,6 +360,8 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     v.w1 = (const float*)(b + o_w1); v.b1 = (const float*)(b + o_b1); v.w2 = (const float*)(b + o_w2); v.b2 = (const float*)(b + o_b2);
     v.w3 = (const float*)(b + o_w3); v.b3 = (const float*)(b + o_b3); v.w4 = (const float*)(b + o_w4); v.b4 = (const float*)(b + o_b4);
     v.wk = (const float*)(b + o_wk); v.bk = (const float*)(b + o_bk); v.wq = (const float*)(b + o_wq); v.bq = (const float*)(b + o_bq);
+    v.p1 = b + o_p1; v.p2 = b + o_p2; v.p3 = b + o_p3; v.p4 = b + o_p4; v.pk = b + o_pk;
+    v.gemm_mode = d->gemm_mode;
     v.feature_c = C; v.fea = Fe; v.img_fea = IF;
     IFF_NET_HIP(hipStreamSynchronize(s));
     *out = n;
@@ -394,12 +408,13 @@ extern "C" int iff_q_proj(const iff_idnet* n, const float* img, int32_t M, float
 }
 
 extern "C" int iff_attn_logits(const float* q, const float* k, int32_t M, int64_t N, int32_t D, float divisor, float* logits,
-                               float* row_max, float* row_sumexp, void* stream) {
-    IFF_REQUIRE(M >= 0 && N >= 0 && D > 0 && D % 16 == 0, "iff_attn_logits: bad shape M=%d N=%lld D=%d", M, (long long)N, D);
+                               float* row_max, float* row_sumexp, int32_t gemm_mode, void* stream) {
+    IFF_REQUIRE(M >= 0 && N >= 0 && D > 0 && D % 32 == 0, "iff_attn_logits: bad shape M=%d N=%lld D=%d", M, (long long)N, D);
+    IFF_REQUIRE(gemm_mode == 0 || gemm_mode == 1, "iff_attn_logits: gemm_mode must be 0 or 1");
     if (M == 0 || N == 0) return 0;
     IFF_REQUIRE(q && k && logits, "iff_attn_logits: null buffer");
     IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_attn_logits: pass both row statistics or neither");
-    IFF_HIP(launch_attn_logits(q, k, M, N, D, divisor, logits, row_max, row_sumexp, (hipStream_t)stream));
+    IFF_HIP(launch_attn_logits(q, k, M, N, D, divisor, logits, row_max, row_sumexp, gemm_mode, (hipStream_t)stream));
     return 0;
 }
 

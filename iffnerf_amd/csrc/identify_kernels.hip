@@ -25,12 +25,13 @@ hipError_t launch_transpose_pad(const float* w, float* dst, int out_f, int in_f,
 }
 
 // ------------------------------------------------------------------------------------------------ encoder input
-// ray_preprocessor.py:30-37 + tensorBase.py:14-20: x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141), zero-padded to 144
+// ray_preprocessor.py:30-37 + tensorBase.py:14-20: x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141), zero-padded to XW = 160 (a multiple of both GEMM k-tiles, 16 and 32)
+constexpr int XW = 160;
 __global__ void k5_ray_input(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ c,
                              int64_t N, float* __restrict__ x) {
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < N * 144; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = t / 144;
-        int col = (int)(t - r * 144);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < N * XW; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t / XW;
+        int col = (int)(t - r * XW);
         float v = 0.0f;
         if (col < 3) v = o[3 * r + col];
         else if (col < 6) v = d[3 * r + col - 3];
@@ -211,10 +212,201 @@ static hipError_t gemm_nn(const float* A1, int lda1, int K1, const float* A2, in
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 3xBF16 split GEMM
+// fp32-accurate products on the bf16 matrix cores.  Every fp32 operand a is split exactly into three bf16 pieces
+// a = a0 + a1 + a2 (round-to-nearest each time, residuals are exact), and a*b is accumulated in fp32 as
+// a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0: the dropped cross terms are below 2^-25 |a b|, i.e. under half an ulp of
+// the product -- the same class of error as any re-association of an fp32 sum.  6 x v_mfma_f32_32x32x16_bf16 cover the
+// work of 8 x v_mfma_f32_32x32x2_f32 in 192 instead of 512 cycles per SIMD (bf16 MFMA runs 16x the fp32-MFMA rate).
+// Weights are pre-split at load time ([3][out][K_pad] bf16, the nn.Linear row layout); activations are split while
+// they are staged into LDS.  Tile 64 x 128 x 32, 4 waves of 32 x 64, single LDS buffer + register prefetch.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BK3 = 32, LD3 = BK3 + 8;     // LDS row: 32 bf16 + 8 pad = 80 B, conflict-free for 16-B fragment reads
+
+__device__ inline void split3(float4 v, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+    float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __bf16 h0 = (__bf16)x[i];
+        float r1 = x[i] - (float)h0;
+        __bf16 h1 = (__bf16)r1;
+        float r2 = r1 - (float)h1;
+        p0[i] = h0; p1[i] = h1; p2[i] = (__bf16)r2;
+    }
+}
+
+__global__ void k_split_rows(const float* __restrict__ w, __bf16* __restrict__ planes, int out_f, int in_f, int in_pad) {
+    // w [out][in] fp32 -> planes [3][out][in_pad] bf16 (zero beyond in)
+    int64_t n = (int64_t)out_f * in_pad;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        int o = (int)(t / in_pad), i = (int)(t - (int64_t)o * in_pad);
+        float x = (i < in_f) ? w[(size_t)o * in_f + i] : 0.0f;
+        __bf16 h0 = (__bf16)x;
+        float r1 = x - (float)h0;
+        __bf16 h1 = (__bf16)r1;
+        float r2 = r1 - (float)h1;
+        planes[t] = h0; planes[n + t] = h1; planes[2 * n + t] = (__bf16)r2;
+    }
+}
+hipError_t launch_split_rows(const float* w, void* planes, int out_f, int in_f, int in_pad, hipStream_t s) {
+    int64_t n = (int64_t)out_f * in_pad;
+    hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (__bf16*)planes, out_f, in_f, in_pad);
+    return hipGetLastError();
+}
+
+// Y = act([A1 | A2] * W^T + bias) with W given as pre-split planes Wp [3][Nout][Kp] (B_FP32 = false), or
+// Y = (A1 * Bf^T) / divisor with Bf fp32 rows [Nout][ldb] split on the fly (B_FP32 = true; the attention logits).
+template <bool RELU, bool B_FP32>
+__global__ void __launch_bounds__(256) k_gemm_bf3(const float* __restrict__ A1, int lda1, int K1,
+                                                  const float* __restrict__ A2, int lda2, int K2,
+                                                  const __bf16* __restrict__ Wp, int Kp, const float* __restrict__ Bf, int ldb,
+                                                  const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
+                                                  int64_t M, int64_t Nout, float divisor) {
+    constexpr int BM = 64;
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][BM][LD3];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN][LD3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int64_t col0 = (int64_t)blockIdx.y * BN;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    const int K = K1 + K2;
+    const int nk = K / BK3;
+    const size_t plane = (size_t)Nout * Kp;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    // staging registers.  A: 64 rows x 32 k fp32 = 512 float4 -> 2 per thread (row = f >> 3, k = (f & 7) * 4).
+    // B pre-split: 3 planes x 128 cols x 32 k bf16 = 1536 16-B chunks -> 6 per thread; B fp32: 1024 float4 -> 4 per thread.
+    float4 ra[2];
+    uint4 rbw[6];
+    float4 rbf[4];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK3;
+        const float* Asrc; int lda, kk;
+        if (k0 < K1) { Asrc = A1; lda = lda1; kk = k0; } else { Asrc = A2; lda = lda2; kk = k0 - K1; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int f = tid + u * 256;
+            int r = f >> 3, kq = (f & 7) * 4;
+            int64_t gr = row0 + r;
+            ra[u] = (gr < M) ? ld4(Asrc + gr * lda + kk + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (B_FP32) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int f = tid + u * 256;
+                int r = f >> 3, kq = (f & 7) * 4;
+                int64_t gc = col0 + r;
+                rbf[u] = (gc < Nout) ? ld4(Bf + gc * ldb + k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                int f = tid + u * 256;                  // chunk id: plane p = f / 512, col = (f % 512) >> 2, k8 = (f & 3) * 8
+                int p = f >> 9, c = (f & 511) >> 2, k8 = (f & 3) * 8;
+                int64_t gc = col0 + c;
+                rbw[u] = (gc < Nout) ? *reinterpret_cast<const uint4*>(Wp + p * plane + gc * Kp + k0 + k8) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int f = tid + u * 256;
+            int r = f >> 3, kq = (f & 7) * 4;
+            bf16x4 p0, p1, p2;
+            split3(ra[u], p0, p1, p2);
+            *reinterpret_cast<bf16x4*>(&As[0][r][kq]) = p0;
+            *reinterpret_cast<bf16x4*>(&As[1][r][kq]) = p1;
+            *reinterpret_cast<bf16x4*>(&As[2][r][kq]) = p2;
+        }
+        if (B_FP32) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int f = tid + u * 256;
+                int r = f >> 3, kq = (f & 7) * 4;
+                bf16x4 p0, p1, p2;
+                split3(rbf[u], p0, p1, p2);
+                *reinterpret_cast<bf16x4*>(&Bs[0][r][kq]) = p0;
+                *reinterpret_cast<bf16x4*>(&Bs[1][r][kq]) = p1;
+                *reinterpret_cast<bf16x4*>(&Bs[2][r][kq]) = p2;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                int f = tid + u * 256;
+                int p = f >> 9, c = (f & 511) >> 2, k8 = (f & 3) * 8;
+                *reinterpret_cast<uint4*>(&Bs[p][c][k8]) = rbw[u];
+            }
+        }
+    };
+
+    const int lr = lane & 31, lh = lane >> 5;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                 // the previous tile's fragment reads are done
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);          // in flight while this tile is multiplied
+#pragma unroll
+        for (int ks = 0; ks < BK3 / 16; ++ks) {
+            const int ko = 16 * ks + 8 * lh;
+            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[0][wr + lr][ko]);
+            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[1][wr + lr][ko]);
+            bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[2][wr + lr][ko]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[0][wc + 32 * j + lr][ko]);
+                bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[1][wc + 32 * j + lr][ko]);
+                bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&Bs[2][wc + 32 * j + lr][ko]);
+                // smallest contributions first
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int64_t gc = col0 + wc + j * 32 + (lane & 31);
+        float bv = 0.0f;
+        if (!B_FP32 && bias && gc < Nout) bv = bias[gc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int64_t gr = row0 + wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gr < M && gc < Nout) {
+                float v = acc[j][r];
+                if (B_FP32) v = v / divisor;
+                else v = v + bv;
+                if (RELU) v = fmaxf(v, 0.0f);
+                Y[gr * ldy + gc] = v;
+            }
+        }
+    }
+}
+
+template <bool RELU>
+static hipError_t gemm_bf3(const float* A1, int lda1, int K1, const float* A2, int lda2, int K2, const void* Wp, int Kp,
+                           int Nout, const float* bias, float* Y, int64_t ldy, int64_t M, hipStream_t s) {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((Nout + BN - 1) / BN));
+    hipLaunchKernelGGL((k_gemm_bf3<RELU, false>), grid, dim3(256), 0, s, A1, lda1, K1, A2, lda2, K2, (const __bf16*)Wp, Kp,
+                       (const float*)nullptr, 0, bias, Y, ldy, M, (int64_t)Nout, 1.0f);
+    return hipGetLastError();
+}
+
 size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N) {
-    // x [N,144] + two ping-pong activations [N, max(feature_c, fea)]
+    // x [N,XW] + two ping-pong activations [N, max(feature_c, fea)]
     int wide = n.feature_c > n.fea ? n.feature_c : n.fea;
-    return (size_t)N * (144 + 2 * (size_t)wide) * sizeof(float) + 256;
+    return (size_t)N * (XW + 2 * (size_t)wide) * sizeof(float) + 256;
 }
 
 hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* feat,
@@ -223,18 +415,29 @@ hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, 
     if (ws_bytes < ray_encode_workspace_bytes(n, N)) return hipErrorInvalidValue;
     int wide = n.feature_c > n.fea ? n.feature_c : n.fea;
     float* x = (float*)ws;
-    float* h1 = x + (size_t)N * 144;
+    float* h1 = x + (size_t)N * XW;
     float* h2 = h1 + (size_t)N * wide;
     const int C = n.feature_c;
-    int64_t tot = N * 144;
+    int64_t tot = N * XW;
     int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
     hipLaunchKernelGGL(k5_ray_input, dim3(grid), dim3(256), 0, s, o, d, rgb, N, x);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // mlp: Linear(141,C) ReLU Linear(C,C) ReLU ; mlp2: Linear(C+141,C) ReLU Linear(C,fea)   (ray_preprocessor.py:9-25)
-    if ((e = gemm_nn<true>(x, 144, 144, nullptr, 0, 0, n.w1, C, n.b1, h1, C, N, s)) != hipSuccess) return e;
+    if (n.gemm_mode == 1) {
+        if ((e = gemm_bf3<true>(x, XW, XW, nullptr, 0, 0, n.p1, XW, C, n.b1, h1, C, N, s)) != hipSuccess) return e;
+        if ((e = gemm_bf3<true>(h1, C, C, nullptr, 0, 0, n.p2, C, C, n.b2, h2, C, N, s)) != hipSuccess) return e;
+        if ((e = gemm_bf3<true>(h2, C, C, x, XW, XW, n.p3, C + XW, C, n.b3, h1, C, N, s)) != hipSuccess) return e;
+        float* f_out = feat ? feat : h2;
+        if ((e = gemm_bf3<false>(h1, C, C, nullptr, 0, 0, n.p4, C, n.fea, n.b4, f_out, n.fea, N, s)) != hipSuccess) return e;
+        if (kout) {
+            if ((e = gemm_bf3<false>(f_out, n.fea, n.fea, nullptr, 0, 0, n.pk, n.fea, n.fea, n.bk, kout, n.fea, N, s)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    if ((e = gemm_nn<true>(x, XW, XW, nullptr, 0, 0, n.w1, C, n.b1, h1, C, N, s)) != hipSuccess) return e;
     if ((e = gemm_nn<true>(h1, C, C, nullptr, 0, 0, n.w2, C, n.b2, h2, C, N, s)) != hipSuccess) return e;
-    if ((e = gemm_nn<true>(h2, C, C, x, 144, 144, n.w3, C, n.b3, h1, C, N, s)) != hipSuccess) return e;
+    if ((e = gemm_nn<true>(h2, C, C, x, XW, XW, n.w3, C, n.b3, h1, C, N, s)) != hipSuccess) return e;
     float* f_out = feat ? feat : h2;
     if ((e = gemm_nn<false>(h1, C, C, nullptr, 0, 0, n.w4, n.fea, n.b4, f_out, n.fea, N, s)) != hipSuccess) return e;
     if (kout) {
@@ -245,6 +448,7 @@ hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, 
 
 hipError_t launch_k_proj(const IdNetDev& n, const float* feat, int64_t N, float* kout, hipStream_t s) {
     if (N == 0) return hipSuccess;
+    if (n.gemm_mode == 1) return gemm_bf3<false>(feat, n.fea, n.fea, nullptr, 0, 0, n.pk, n.fea, n.fea, n.bk, kout, n.fea, N, s);
     return gemm_nn<false>(feat, n.fea, n.fea, nullptr, 0, 0, n.wk, n.fea, n.bk, kout, n.fea, N, s);
 }
 
@@ -329,9 +533,21 @@ __global__ void __launch_bounds__(256) k6_row_stats(const float* __restrict__ lo
 }
 
 hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, int D, float divisor, float* logits,
-                              float* row_max, float* row_sumexp, hipStream_t s) {
+                              float* row_max, float* row_sumexp, int gemm_mode, hipStream_t s) {
     if (M == 0 || N == 0) return hipSuccess;
-    if (D % BK != 0) return hipErrorInvalidValue;
+    if (D % BK3 != 0) return hipErrorInvalidValue;
+    if (gemm_mode == 1) {
+        dim3 grid3((unsigned)((M + 63) / 64), (unsigned)((N + BN - 1) / BN));
+        hipLaunchKernelGGL((k_gemm_bf3<false, true>), grid3, dim3(256), 0, s, q, D, D, (const float*)nullptr, 0, 0,
+                           (const __bf16*)nullptr, 0, k, D, (const float*)nullptr, logits, N, (int64_t)M, N, divisor);
+        hipError_t e3 = hipGetLastError();
+        if (e3 != hipSuccess) return e3;
+        if (row_max && row_sumexp) {
+            hipLaunchKernelGGL(k6_row_stats, dim3(M), dim3(256), 0, s, logits, N, row_max, row_sumexp);
+            e3 = hipGetLastError();
+        }
+        return e3;
+    }
     constexpr int MTL = 1;
     dim3 grid((unsigned)((M + 64 * MTL - 1) / (64 * MTL)), (unsigned)((N + BN - 1) / BN));
     hipLaunchKernelGGL((k_gemm_f32<false, true, MTL>), grid, dim3(256), 0, s, q, D, D, (const float*)nullptr, 0, 0, k, D,

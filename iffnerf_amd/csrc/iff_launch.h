@@ -36,13 +36,16 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
 
 // identify_kernels.hip
 struct IdNetDev {
-    // weights transposed to [in][out] (k-major) and zero-padded so every GEMM has K % 4 == 0, N % 128 == 0
-    const float* w1; const float* b1;   // [144][256]   (141 inputs padded to 144)
+    // weights transposed to [in][out] (k-major), K zero-padded to a multiple of 32
+    const float* w1; const float* b1;   // [160][256]   (141 inputs padded to 160)
     const float* w2; const float* b2;   // [256][256]
-    const float* w3; const float* b3;   // [400][256]   rows 0..255 <- h, rows 256..396 <- x (141), 3 zero rows
+    const float* w3; const float* b3;   // [416][256]   rows 0..255 <- h, rows 256..396 <- x (141), then zero rows
     const float* w4; const float* b4;   // [256][384]
     const float* wk; const float* bk;   // [384][384]
     const float* wq; const float* bq;   // [400][384]   (398 inputs padded to 400)
+    // the same weights pre-split into three bf16 planes [3][out][K_pad] (nn.Linear row layout) for the 3xBF16 GEMM
+    const void* p1; const void* p2; const void* p3; const void* p4; const void* pk;
+    int gemm_mode;                      // 0: fp32-input MFMA (k-ordered fmaf chain), 1: 3xBF16 split on the bf16 MFMA
     int feature_c, fea, img_fea;
 };
 size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N);
@@ -52,8 +55,9 @@ hipError_t launch_k_proj(const IdNetDev& n, const float* feat, int64_t N, float*
 hipError_t launch_q_proj(const IdNetDev& n, const float* img, int M, float* q, void* scratch, hipStream_t s);
 hipError_t launch_transpose_pad(const float* w_out_in, float* dst_in_out, int out_f, int in_f, int in_pad, int row_off,
                                 hipStream_t s);
-hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, int D, float scale, float* logits,
-                              float* row_max, float* row_sumexp, hipStream_t s);
+hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, int D, float divisor, float* logits,
+                              float* row_max, float* row_sumexp, int gemm_mode, hipStream_t s);
+hipError_t launch_split_rows(const float* w, void* planes, int out_f, int in_f, int in_pad, hipStream_t s);
 hipError_t launch_attn_colsum(float* logits, int M, int64_t N, const float* row_max, const float* row_sumexp,
                               int write_attention, float* score, hipStream_t s);
 size_t topk_workspace_bytes(int64_t N, int k);

@@ -14,6 +14,8 @@ import torch
 from . import _lib
 from ._lib import check, dptr, fvec, stream_ptr
 
+GEMM_F32, GEMM_BF16X3 = 0, 1        # include/iffnerf_hip.h IFF_GEMM_*
+
 _KEYS = (("l1", "ray_preprocessor.mlp.0"), ("l2", "ray_preprocessor.mlp.2"), ("l3", "ray_preprocessor.mlp2.0"),
          ("l4", "ray_preprocessor.mlp2.2"), ("q", "attention.q_proj"), ("k", "attention.k_proj"))
 
@@ -30,8 +32,9 @@ def _gpu(t: torch.Tensor, name: str, cols: Optional[int] = None) -> torch.Tensor
 class IdNetHandle:
     """Weights of RayPreprocessor + MultiHeadAttention, transposed/padded once for the MFMA GEMMs."""
 
-    def __init__(self, weights: Dict[str, torch.Tensor], device):
+    def __init__(self, weights: Dict[str, torch.Tensor], device, gemm_mode: int = GEMM_BF16X3):
         self._h = None
+        self.gemm_mode = int(gemm_mode)
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(f"IdNetHandle needs a GPU device (got {device}); libiffnerf_hip has no CPU path")
@@ -49,6 +52,7 @@ class IdNetHandle:
         if int(weights["ray_preprocessor.mlp.0.weight"].shape[1]) != 141:
             raise RuntimeError("ray encoder input width must be 141 (pospe=8, viewpe=8, rgbpe=6)")
         d.feature_c, d.fea, d.img_fea = self.feature_c, self.fea, self.img_fea
+        d.gemm_mode = self.gemm_mode
         out = C.c_void_p()
         with torch.cuda.device(device):
             check(_lib.lib().iff_idnet_create(C.byref(d), stream_ptr(device), C.byref(out)), "iff_idnet_create")
@@ -102,7 +106,7 @@ class IdNetHandle:
         return q
 
 
-def attn_logits(q: torch.Tensor, k: torch.Tensor, want_stats: bool = True):
+def attn_logits(q: torch.Tensor, k: torch.Tensor, want_stats: bool = True, gemm_mode: int = GEMM_BF16X3):
     """logits = q k^T / sqrt(d) and the per-row softmax statistics (max, sum exp)."""
     q, k = _gpu(q, "q"), _gpu(k, "k")
     M, D = q.shape
@@ -112,7 +116,7 @@ def attn_logits(q: torch.Tensor, k: torch.Tensor, want_stats: bool = True):
     rsum = q.new_empty(M) if want_stats else None
     with torch.cuda.device(q.device):
         check(_lib.lib().iff_attn_logits(dptr(q), dptr(k), M, N, D, float(math.sqrt(D)), dptr(logits), dptr(rmax), dptr(rsum),
-                                         stream_ptr(q.device)), "iff_attn_logits")
+                                         int(gemm_mode), stream_ptr(q.device)), "iff_attn_logits")
     return logits, rmax, rsum
 
 

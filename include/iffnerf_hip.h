@@ -37,6 +37,13 @@ extern "C" {
 #define IFF_MARCH_POINT_CENTRED 0   /* sampler = TensorBase.sample_point_color (models/tensorBase.py:623-638) */
 #define IFF_MARCH_SLAB          1   /* sampler = TensorBase.sample_ray, is_train=False (models/tensorBase.py:494-536) */
 
+/* matrix-product arithmetic of the ray encoder / attention logits (both keep fp32 accuracy):
+ *   F32     v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fmaf chain
+ *   BF16X3  every fp32 operand split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product block, fp32 accumulation;
+ *           dropped terms < 2^-25 relative -- the error class of an fp32 re-association, at ~2.7x the throughput */
+#define IFF_GEMM_F32    0
+#define IFF_GEMM_BF16X3 1
+
 #define IFF_ISOCELL_DIRS 27         /* pose_estimation/sampling.py:229-234, isocell.py:6-68 (27 targets, N0=3) */
 #define IFF_RAY_FEATURES 384        /* DINOv2 ViT-S/14 width: pose_estimation/backbone.py:12-14 */
 #define IFF_RAY_INPUT    141        /* pose_estimation/ray_preprocessor.py:8 (3*3 + 2*3*(8+8+6)) */
@@ -158,6 +165,7 @@ typedef struct iff_idnet_desc {
     int32_t feature_c;              /* 256 (identification_module.py:66-68) */
     int32_t fea;                    /* 384 */
     int32_t img_fea;                /* 398 = 384 + 14 */
+    int32_t gemm_mode;              /* IFF_GEMM_F32: fp32-input MFMA; IFF_GEMM_BF16X3: 3xBF16 split on the bf16 MFMA */
     const float* l1_w; const float* l1_b;   /* ray_preprocessor.mlp.0   [feature_c,141] */
     const float* l2_w; const float* l2_b;   /* ray_preprocessor.mlp.2   [feature_c,feature_c] */
     const float* l3_w; const float* l3_b;   /* ray_preprocessor.mlp2.0  [feature_c,feature_c+141] */
@@ -188,7 +196,7 @@ int iff_q_proj(const iff_idnet* net, const float* img, int32_t M, float* q, void
  *   iff_attn_colsum: attention = exp(l - row_max)/row_sumexp written in place when write_attention != 0,
  *                    score[N] = sum_i attention_ij   (identification_module.py:167) */
 int iff_attn_logits(const float* q, const float* k, int32_t M, int64_t N, int32_t D, float divisor, float* logits,
-                    float* row_max, float* row_sumexp, void* stream);
+                    float* row_max, float* row_sumexp, int32_t gemm_mode, void* stream);
 int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const float* row_max, const float* row_sumexp,
                     int32_t write_attention, float* score, void* stream);
 

@@ -51,7 +51,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert b"null" in L.iff_last_error()
     assert L.iff_march_shade(None, None, 6, 4, 0, 20, None, None, None, None, None, None, None, 0, None) != 0
     with pytest.raises(RuntimeError):
-        _lib.check(L.iff_attn_logits(None, None, 4, 4, 7, 1.0, None, None, None, None), "iff_attn_logits")
+        _lib.check(L.iff_attn_logits(None, None, 4, 4, 7, 1.0, None, None, None, 0, None), "iff_attn_logits")
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -145,3 +145,26 @@ def test_attention_shapes_and_errors(net, dev):
         net.ray_encode(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 3))       # CPU tensors: no fallback
     f, _ = net.ray_encode(torch.zeros(0, 3, device=dev), torch.zeros(0, 3, device=dev), torch.zeros(0, 3, device=dev))
     assert f.shape == (0, 384)
+
+
+def test_gemm_modes_agree(golden, dev):
+    """fp32-MFMA chain vs 3xBF16 split: both are fp32-accurate; they agree to fp32 rounding and give the same top-100."""
+    from iffnerf_amd import hip_identify as H
+    g = golden["g6_identify"]
+    w = synthetic.make_id_weights(seed=99)
+    o, d, c = (golden.t("g6_identify", k).to(dev) for k in ("ori", "dirs", "rgb"))
+    tok = synthetic.make_tokens(256, 384, seed=int(g["tokens_seed"])).to(dev)
+    tops = []
+    feats = []
+    for mode in (H.GEMM_F32, H.GEMM_BF16X3):
+        net = H.IdNetHandle(w, dev, gemm_mode=mode)
+        feat, k = net.ray_encode(o, d, c, want_features=True, want_k=True)
+        close(feat[:64], g["ray_feat_tile"], 2e-5, 1e-5, f"ray features, mode {mode}")
+        logits, rmax, rsum = H.attn_logits(net.q_proj(tok), k, gemm_mode=mode)
+        close(logits[:32, :64], g["m256_logits_tile"], TOL_LOGIT, what=f"logits, mode {mode}")
+        score = H.attn_colsum(logits, rmax, rsum)
+        idx, _ = H.topk(score, 100)
+        assert idx.cpu().tolist() == g["m256_top_idx"].tolist(), f"top-100, mode {mode}"
+        feats.append(feat)
+        tops.append(logits)
+    assert float((feats[0] - feats[1]).abs().max()) < 5e-6
