@@ -309,6 +309,44 @@ extern "C" void iff_idnet_destroy(iff_idnet* n) {
     delete n;
 }
 
+// q_proj, k_proj and the last encoder Linear have no nonlinearity between them (ray_preprocessor.py:24-25,38;
+// multihead_attention.py:60-63), so with h3 the encoder's last hidden activation
+//   q . k = (Wq t + bq) . (Wk (W4 h3 + b4) + bk) = (H t + hb) . h3 + (r . t + r0),
+//   G = Wk W4, g = Wk b4 + bk, H = G^T Wq, hb = G^T bq, r = Wq^T g, r0 = bq . g.
+// The products are formed once, in double, and rounded to fp32: the same class of error as re-associating an fp32 sum.
+// Output: wqf [KQ][ld] k-major (column c < C: H row c; column C: r; others 0), bqf [ld].
+static void fold_heads(const float* W4, const float* b4, const float* Wk, const float* bk, const float* Wq, const float* bq, int C,
+                       int Fe, int IF, int KQ, int ld, std::vector<float>& wqf, std::vector<float>& bqf) {
+    std::vector<double> G((size_t)Fe * C, 0.0), g(Fe, 0.0);
+    for (int e = 0; e < Fe; ++e) {
+        double* Ge = &G[(size_t)e * C];
+        double acc = bk[e];
+        for (int f = 0; f < Fe; ++f) {
+            const double w = Wk[(size_t)e * Fe + f];
+            const float* w4 = W4 + (size_t)f * C;
+            for (int c = 0; c < C; ++c) Ge[c] += w * (double)w4[c];
+            acc += w * (double)b4[f];
+        }
+        g[e] = acc;
+    }
+    std::vector<double> H((size_t)KQ * ld, 0.0), hb(ld, 0.0);
+    for (int e = 0; e < Fe; ++e) {
+        const double* Ge = &G[(size_t)e * C];
+        for (int i = 0; i < IF; ++i) {
+            const double w = Wq[(size_t)e * IF + i];
+            double* Hi = &H[(size_t)i * ld];
+            for (int c = 0; c < C; ++c) Hi[c] += w * Ge[c];
+            Hi[C] += w * g[e];
+        }
+        for (int c = 0; c < C; ++c) hb[c] += (double)bq[e] * Ge[c];
+        hb[C] += (double)bq[e] * g[e];
+    }
+    wqf.resize((size_t)KQ * ld);
+    bqf.resize(ld);
+    for (size_t t = 0; t < H.size(); ++t) wqf[t] = (float)H[t];
+    for (int c = 0; c < ld; ++c) bqf[c] = (float)hb[c];
+}
+
 extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet** out) {
     IFF_REQUIRE(d && out, "iff_idnet_create: null argument");
     *out = nullptr;
@@ -331,6 +369,8 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     auto take_planes = [&](size_t out_f, size_t kpad) { return take((out_f * kpad * 3 + 1) / 2); };
     size_t o_p1 = take_planes(C, XW), o_p2 = take_planes(C, C), o_p3 = take_planes(C, C + XW), o_p4 = take_planes(Fe, C),
            o_pk = take_planes(Fe, Fe);
+    const int QLD = C + 16;
+    size_t o_wqf = take((size_t)KQ * QLD), o_bqf = take(QLD);
     n->slab_bytes = off;
     hipError_t e = hipMalloc(&n->slab, off);
     if (e != hipSuccess) { delete n; return hip_fail(e, "hipMalloc(idnet weights)"); }
@@ -364,6 +404,16 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     v.gemm_mode = d->gemm_mode;
     v.feature_c = C; v.fea = Fe; v.img_fea = IF;
     IFF_NET_HIP(hipStreamSynchronize(s));
+    {
+        std::vector<float> W4((size_t)Fe * C), b4(Fe), Wk((size_t)Fe * Fe), bk(Fe), Wq((size_t)Fe * IF), bq(Fe), wqf, bqf;
+        struct { std::vector<float>* dst; const float* src; } dl[] = {{&W4, d->l4_w}, {&b4, d->l4_b}, {&Wk, d->k_w},
+                                                                      {&bk, d->k_b}, {&Wq, d->q_w}, {&bq, d->q_b}};
+        for (auto& p : dl) IFF_NET_HIP(hipMemcpy(p.dst->data(), p.src, p.dst->size() * 4, hipMemcpyDeviceToHost));
+        fold_heads(W4.data(), b4.data(), Wk.data(), bk.data(), Wq.data(), bq.data(), C, Fe, IF, KQ, QLD, wqf, bqf);
+        IFF_NET_HIP(hipMemcpy(b + o_wqf, wqf.data(), wqf.size() * 4, hipMemcpyHostToDevice));
+        IFF_NET_HIP(hipMemcpy(b + o_bqf, bqf.data(), bqf.size() * 4, hipMemcpyHostToDevice));
+        v.wqf = (const float*)(b + o_wqf); v.bqf = (const float*)(b + o_bqf); v.qf_ld = QLD;
+    }
     *out = n;
     return 0;
 }
@@ -381,6 +431,42 @@ extern "C" int iff_ray_encode(const iff_idnet* n, const float* o, const float* d
     if (workspace_bytes < ray_encode_workspace_bytes(n->dev, N))
         return fail(IFF_ERR_WORKSPACE, "iff_ray_encode: workspace %zu < %zu bytes", workspace_bytes, ray_encode_workspace_bytes(n->dev, N));
     IFF_HIP(launch_ray_encode(n->dev, o, d, rgb, N, feat_opt, k_out, workspace, workspace_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" size_t iff_ray_trunk_workspace(const iff_idnet* n, int64_t N) {
+    return (n && N > 0) ? ray_trunk_workspace_bytes(n->dev, N) : 0;
+}
+
+extern "C" int iff_ray_trunk(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N, float* h3,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(n && N >= 0, "iff_ray_trunk: bad argument");
+    if (N == 0) return 0;
+    IFF_REQUIRE(o && d && rgb && h3 && workspace, "iff_ray_trunk: null buffer");
+    if (workspace_bytes < ray_trunk_workspace_bytes(n->dev, N))
+        return fail(IFF_ERR_WORKSPACE, "iff_ray_trunk: workspace %zu < %zu bytes", workspace_bytes, ray_trunk_workspace_bytes(n->dev, N));
+    IFF_HIP(launch_ray_trunk(n->dev, o, d, rgb, N, h3, workspace, workspace_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int32_t iff_q_fold_width(const iff_idnet* n) { return n ? n->dev.qf_ld : 0; }
+
+extern "C" int iff_q_fold(const iff_idnet* n, const float* img, int32_t M, float* qf, void* stream) {
+    IFF_REQUIRE(n && M >= 0, "iff_q_fold: bad argument");
+    if (M == 0) return 0;
+    IFF_REQUIRE(img && qf, "iff_q_fold: null buffer");
+    IFF_HIP(launch_q_fold(n->dev, img, M, qf, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_attn_logits_folded(const iff_idnet* n, const float* qf, const float* h3, int32_t M, int64_t N, float divisor,
+                                      float* logits, float* row_max, float* row_sumexp, void* stream) {
+    IFF_REQUIRE(n && M >= 0 && N >= 0, "iff_attn_logits_folded: bad argument");
+    if (M == 0 || N == 0) return 0;
+    IFF_REQUIRE(qf && h3 && logits, "iff_attn_logits_folded: null buffer");
+    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_attn_logits_folded: pass both row statistics or neither");
+    IFF_HIP(launch_attn_logits_folded(qf, n->dev.qf_ld, h3, M, N, n->dev.feature_c, divisor, logits, row_max, row_sumexp,
+                                      (hipStream_t)stream));
     return 0;
 }
 

@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(256) k_gemm_bf3(const float* __restrict__ A1, 
                                                   const float* __restrict__ A2, int lda2, int K2,
                                                   const __bf16* __restrict__ Wp, int Kp, const float* __restrict__ Bf, int ldb,
                                                   const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
-                                                  int64_t M, int64_t Nout, float divisor) {
+                                                  int64_t M, int64_t Nout, float divisor, const float* __restrict__ rowc,
+                                                  int rowc_ld) {
     constexpr int BM = 64;
     __shared__ __attribute__((aligned(16))) __bf16 As[3][BM][LD3];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN][LD3];
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(256) k_gemm_bf3(const float* __restrict__ A1, 
             int64_t gr = row0 + wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (gr < M && gc < Nout) {
                 float v = acc[j][r];
-                if (B_FP32) v = v / divisor;
+                if (B_FP32) v = (rowc ? v + rowc[gr * rowc_ld] : v) / divisor;
                 else v = v + bv;
                 if (RELU) v = fmaxf(v, 0.0f);
                 Y[gr * ldy + gc] = v;
@@ -399,7 +400,7 @@ static hipError_t gemm_bf3(const float* A1, int lda1, int K1, const float* A2, i
                            int Nout, const float* bias, float* Y, int64_t ldy, int64_t M, hipStream_t s) {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)((Nout + BN - 1) / BN));
     hipLaunchKernelGGL((k_gemm_bf3<RELU, false>), grid, dim3(256), 0, s, A1, lda1, K1, A2, lda2, K2, (const __bf16*)Wp, Kp,
-                       (const float*)nullptr, 0, bias, Y, ldy, M, (int64_t)Nout, 1.0f);
+                       (const float*)nullptr, 0, bias, Y, ldy, M, (int64_t)Nout, 1.0f, (const float*)nullptr, 0);
     return hipGetLastError();
 }
 
@@ -407,6 +408,39 @@ size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N) {
     // x [N,XW] + two ping-pong activations [N, max(feature_c, fea)]
     int wide = n.feature_c > n.fea ? n.feature_c : n.fea;
     return (size_t)N * (XW + 2 * (size_t)wide) * sizeof(float) + 256;
+}
+size_t ray_trunk_workspace_bytes(const IdNetDev& n, int64_t N) {
+    // x [N,XW] + two activations [N, feature_c]
+    return (size_t)N * (XW + 2 * (size_t)n.feature_c) * sizeof(float) + 256;
+}
+
+// the three ReLU layers: mlp.0, mlp.2, mlp2.0 (ray_preprocessor.py:9-22,30-38) -> h3 [N, feature_c]
+static hipError_t trunk(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* x, float* h1,
+                        float* h2, float* h3, hipStream_t s) {
+    const int C = n.feature_c;
+    int64_t tot = N * XW;
+    int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
+    hipLaunchKernelGGL(k5_ray_input, dim3(grid), dim3(256), 0, s, o, d, rgb, N, x);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (n.gemm_mode == 1) {
+        if ((e = gemm_bf3<true>(x, XW, XW, nullptr, 0, 0, n.p1, XW, C, n.b1, h1, C, N, s)) != hipSuccess) return e;
+        if ((e = gemm_bf3<true>(h1, C, C, nullptr, 0, 0, n.p2, C, C, n.b2, h2, C, N, s)) != hipSuccess) return e;
+        return gemm_bf3<true>(h2, C, C, x, XW, XW, n.p3, C + XW, C, n.b3, h3, C, N, s);
+    }
+    if ((e = gemm_nn<true>(x, XW, XW, nullptr, 0, 0, n.w1, C, n.b1, h1, C, N, s)) != hipSuccess) return e;
+    if ((e = gemm_nn<true>(h1, C, C, nullptr, 0, 0, n.w2, C, n.b2, h2, C, N, s)) != hipSuccess) return e;
+    return gemm_nn<true>(h2, C, C, x, XW, XW, n.w3, C, n.b3, h3, C, N, s);
+}
+
+hipError_t launch_ray_trunk(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* h3, void* ws,
+                            size_t ws_bytes, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    if (ws_bytes < ray_trunk_workspace_bytes(n, N)) return hipErrorInvalidValue;
+    float* x = (float*)ws;
+    float* h1 = x + (size_t)N * XW;
+    float* h2 = h1 + (size_t)N * n.feature_c;
+    return trunk(n, o, d, rgb, N, x, h1, h2, h3, s);
 }
 
 hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* feat,
@@ -418,32 +452,18 @@ hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, 
     float* h1 = x + (size_t)N * XW;
     float* h2 = h1 + (size_t)N * wide;
     const int C = n.feature_c;
-    int64_t tot = N * XW;
-    int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
-    hipLaunchKernelGGL(k5_ray_input, dim3(grid), dim3(256), 0, s, o, d, rgb, N, x);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
     // mlp: Linear(141,C) ReLU Linear(C,C) ReLU ; mlp2: Linear(C+141,C) ReLU Linear(C,fea)   (ray_preprocessor.py:9-25)
-    if (n.gemm_mode == 1) {
-        if ((e = gemm_bf3<true>(x, XW, XW, nullptr, 0, 0, n.p1, XW, C, n.b1, h1, C, N, s)) != hipSuccess) return e;
-        if ((e = gemm_bf3<true>(h1, C, C, nullptr, 0, 0, n.p2, C, C, n.b2, h2, C, N, s)) != hipSuccess) return e;
-        if ((e = gemm_bf3<true>(h2, C, C, x, XW, XW, n.p3, C + XW, C, n.b3, h1, C, N, s)) != hipSuccess) return e;
-        float* f_out = feat ? feat : h2;
-        if ((e = gemm_bf3<false>(h1, C, C, nullptr, 0, 0, n.p4, C, n.fea, n.b4, f_out, n.fea, N, s)) != hipSuccess) return e;
-        if (kout) {
-            if ((e = gemm_bf3<false>(f_out, n.fea, n.fea, nullptr, 0, 0, n.pk, n.fea, n.fea, n.bk, kout, n.fea, N, s)) != hipSuccess) return e;
-        }
-        return hipSuccess;
-    }
-    if ((e = gemm_nn<true>(x, XW, XW, nullptr, 0, 0, n.w1, C, n.b1, h1, C, N, s)) != hipSuccess) return e;
-    if ((e = gemm_nn<true>(h1, C, C, nullptr, 0, 0, n.w2, C, n.b2, h2, C, N, s)) != hipSuccess) return e;
-    if ((e = gemm_nn<true>(h2, C, C, x, XW, XW, n.w3, C, n.b3, h1, C, N, s)) != hipSuccess) return e;
+    hipError_t e = trunk(n, o, d, rgb, N, x, h1, h2, h1, s);
+    if (e != hipSuccess) return e;
     float* f_out = feat ? feat : h2;
-    if ((e = gemm_nn<false>(h1, C, C, nullptr, 0, 0, n.w4, n.fea, n.b4, f_out, n.fea, N, s)) != hipSuccess) return e;
-    if (kout) {
-        if ((e = gemm_nn<false>(f_out, n.fea, n.fea, nullptr, 0, 0, n.wk, n.fea, n.bk, kout, n.fea, N, s)) != hipSuccess) return e;
+    if (n.gemm_mode == 1) {
+        if ((e = gemm_bf3<false>(h1, C, C, nullptr, 0, 0, n.p4, C, n.fea, n.b4, f_out, n.fea, N, s)) != hipSuccess) return e;
+        if (kout) e = gemm_bf3<false>(f_out, n.fea, n.fea, nullptr, 0, 0, n.pk, n.fea, n.fea, n.bk, kout, n.fea, N, s);
+        return e;
     }
-    return hipSuccess;
+    if ((e = gemm_nn<false>(h1, C, C, nullptr, 0, 0, n.w4, n.fea, n.b4, f_out, n.fea, N, s)) != hipSuccess) return e;
+    if (kout) e = gemm_nn<false>(f_out, n.fea, n.fea, nullptr, 0, 0, n.wk, n.fea, n.bk, kout, n.fea, N, s);
+    return e;
 }
 
 hipError_t launch_k_proj(const IdNetDev& n, const float* feat, int64_t N, float* kout, hipStream_t s) {
@@ -539,7 +559,8 @@ hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, 
     if (gemm_mode == 1) {
         dim3 grid3((unsigned)((M + 63) / 64), (unsigned)((N + BN - 1) / BN));
         hipLaunchKernelGGL((k_gemm_bf3<false, true>), grid3, dim3(256), 0, s, q, D, D, (const float*)nullptr, 0, 0,
-                           (const __bf16*)nullptr, 0, k, D, (const float*)nullptr, logits, N, (int64_t)M, N, divisor);
+                           (const __bf16*)nullptr, 0, k, D, (const float*)nullptr, logits, N, (int64_t)M, N, divisor,
+                           (const float*)nullptr, 0);
         hipError_t e3 = hipGetLastError();
         if (e3 != hipSuccess) return e3;
         if (row_max && row_sumexp) {
@@ -552,6 +573,32 @@ hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, 
     dim3 grid((unsigned)((M + 64 * MTL - 1) / (64 * MTL)), (unsigned)((N + BN - 1) / BN));
     hipLaunchKernelGGL((k_gemm_f32<false, true, MTL>), grid, dim3(256), 0, s, q, D, D, (const float*)nullptr, 0, 0, k, D,
                        (const float*)nullptr, logits, N, (int64_t)M, N, divisor);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (row_max && row_sumexp) {
+        hipLaunchKernelGGL(k6_row_stats, dim3(M), dim3(256), 0, s, logits, N, row_max, row_sumexp);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+// Folded token side (api.hip: fold_heads): qf [M][qf_ld] = img * wqf + bqf.  Columns 0..C-1 dotted with a ray's h3 plus
+// column C give q . k of the unfolded chain (multihead_attention.py:60-63 after ray_preprocessor.py:38).
+hipError_t launch_q_fold(const IdNetDev& n, const float* img, int M, float* qf, hipStream_t s) {
+    if (M == 0) return hipSuccess;
+    int kp = (n.img_fea + 15) / 16 * 16;
+    dim3 grid((unsigned)((M + 15) / 16), (unsigned)((n.qf_ld + 63) / 64));
+    hipLaunchKernelGGL(k_gemm_small, grid, dim3(256), 0, s, img, n.img_fea, kp, n.wqf, n.qf_ld, n.bqf, qf, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, int M, int64_t N, int C, float divisor,
+                                     float* logits, float* row_max, float* row_sumexp, hipStream_t s) {
+    if (M == 0 || N == 0) return hipSuccess;
+    if (C % BK3 != 0 || ldq <= C) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + BN - 1) / BN));
+    hipLaunchKernelGGL((k_gemm_bf3<false, true>), grid, dim3(256), 0, s, qf, ldq, C, (const float*)nullptr, 0, 0,
+                       (const __bf16*)nullptr, 0, h3, C, (const float*)nullptr, logits, N, (int64_t)M, N, divisor, qf + C, ldq);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (row_max && row_sumexp) {

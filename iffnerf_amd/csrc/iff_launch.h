@@ -45,12 +45,21 @@ struct IdNetDev {
     const float* wq; const float* bq;   // [400][384]   (398 inputs padded to 400)
     // the same weights pre-split into three bf16 planes [3][out][K_pad] (nn.Linear row layout) for the 3xBF16 GEMM
     const void* p1; const void* p2; const void* p3; const void* p4; const void* pk;
+    // q_proj, k_proj and mlp2.2 folded into one token-side Linear (api.hip: fold_heads): wqf [KQ][qf_ld] k-major,
+    // bqf [qf_ld]; columns 0..C-1 give the folded query, column C the per-token constant, the rest are zero
+    const float* wqf; const float* bqf; int qf_ld;
     int gemm_mode;                      // 0: fp32-input MFMA (k-ordered fmaf chain), 1: 3xBF16 split on the bf16 MFMA
     int feature_c, fea, img_fea;
 };
 size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N);
 hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* feat,
                              float* kout, void* ws, size_t ws_bytes, hipStream_t s);
+size_t ray_trunk_workspace_bytes(const IdNetDev& n, int64_t N);
+hipError_t launch_ray_trunk(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* h3,
+                            void* ws, size_t ws_bytes, hipStream_t s);
+hipError_t launch_q_fold(const IdNetDev& n, const float* img, int M, float* qf, hipStream_t s);
+hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, int M, int64_t N, int C, float divisor,
+                                     float* logits, float* row_max, float* row_sumexp, hipStream_t s);
 hipError_t launch_k_proj(const IdNetDev& n, const float* feat, int64_t N, float* kout, hipStream_t s);
 hipError_t launch_q_proj(const IdNetDev& n, const float* img, int M, float* q, void* scratch, hipStream_t s);
 hipError_t launch_transpose_pad(const float* w_out_in, float* dst_in_out, int out_f, int in_f, int in_pad, int row_off,

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
 // lane), lanes 12..15 shadow lane 11.  Samples are taken in order, so the accumulation is deterministic.  Output: the
 // per-ray feature vector [R][28] (27 features + a "has shaded samples" flag) for K4c.
 template <int APP>
-__global__ void __launch_bounds__(256) k4b_appearance(FieldDev f, MarchArgs a) {
+__global__ void __launch_bounds__(256, 4) k4b_appearance(FieldDev f, MarchArgs a) {
     extern __shared__ __align__(16) float smem[];
     constexpr int NL = 12;                         // n_app / 4 gather lanes per ray
     constexpr int LD = (APP + 3) & ~3;

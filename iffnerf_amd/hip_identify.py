@@ -86,6 +86,44 @@ class IdNetHandle:
                                    stream_ptr(self.device)), "iff_ray_encode")
         return feat, k
 
+    def ray_trunk(self, o, d, rgb):
+        """The encoder up to its last ReLU (ray_preprocessor.py:29-38) -> h3 [N, feature_c], the ray side of the folded
+        logits (``q_fold`` / ``attn_logits_folded``)."""
+        o, d, rgb = _gpu(o, "rays_ori", 3), _gpu(d, "rays_dir", 3), _gpu(rgb, "rays_rgb", 3)
+        N = o.shape[0]
+        if d.shape[0] != N or rgb.shape[0] != N:
+            raise RuntimeError("rays_ori / rays_dir / rays_rgb must have the same number of rows")
+        L = _lib.lib()
+        h3 = o.new_empty(N, self.feature_c)
+        ws_bytes = int(L.iff_ray_trunk_workspace(self._h, N))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=o.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_ray_trunk(self._h, dptr(o), dptr(d), dptr(rgb), N, dptr(h3), ws.data_ptr(), ws_bytes,
+                                  stream_ptr(self.device)), "iff_ray_trunk")
+        return h3
+
+    def q_fold(self, img_features):
+        """Token side of the folded logits: [M, img_fea] -> qf [M, feature_c + 16] (column feature_c = per-token constant)."""
+        x = _gpu(img_features, "img_features", self.img_fea)
+        M = x.shape[0]
+        L = _lib.lib()
+        qf = x.new_empty(M, int(L.iff_q_fold_width(self._h)))
+        with torch.cuda.device(self.device):
+            check(L.iff_q_fold(self._h, dptr(x), M, dptr(qf), stream_ptr(self.device)), "iff_q_fold")
+        return qf
+
+    def attn_logits_folded(self, qf, h3, want_stats: bool = True):
+        """logits = q k^T / sqrt(fea) from the folded operands, plus the per-row softmax statistics."""
+        qf, h3 = _gpu(qf, "qf"), _gpu(h3, "h3", self.feature_c)
+        M, N = qf.shape[0], h3.shape[0]
+        logits = qf.new_empty(M, N)
+        rmax = qf.new_empty(M) if want_stats else None
+        rsum = qf.new_empty(M) if want_stats else None
+        with torch.cuda.device(self.device):
+            check(_lib.lib().iff_attn_logits_folded(self._h, dptr(qf), dptr(h3), M, N, float(math.sqrt(self.fea)), dptr(logits),
+                                                    dptr(rmax), dptr(rsum), stream_ptr(self.device)), "iff_attn_logits_folded")
+        return logits, rmax, rsum
+
     def k_proj(self, ray_features):
         """k_proj alone, for MultiHeadAttention called with already-encoded rays."""
         x = _gpu(ray_features, "ray_features", self.fea)

@@ -24,16 +24,25 @@ def jitter_scale_from_kwargs(kw: dict) -> float:
 
 
 class PosePipeline:
-    def __init__(self, field: FieldHandle, idnet: H.IdNetHandle, rho: float, model_up=(0.0, 0.0, 1.0)):
+    def __init__(self, field: FieldHandle, idnet: H.IdNetHandle, rho: float, model_up=(0.0, 0.0, 1.0), fold_heads: bool = True):
         self.field, self.idnet, self.rho = field, idnet, float(rho)
+        self.fold_heads = bool(fold_heads)   # logits through iff_attn_logits_folded (include/iffnerf_hip.h) or the 5-GEMM chain
         self.model_up = torch.as_tensor(model_up, dtype=torch.float32).cpu()
         self.cells = isocell_distribution(27, torch.float32, "cpu")
         self.device = field.device
 
     @classmethod
-    def from_checkpoints(cls, field_ckpt: dict, id_weights: Dict[str, torch.Tensor], device, model_up=(0.0, 0.0, 1.0)):
+    def from_checkpoints(cls, field_ckpt: dict, id_weights: Dict[str, torch.Tensor], device, model_up=(0.0, 0.0, 1.0),
+                         fold_heads: bool = True):
         return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device),
-                   jitter_scale_from_kwargs(field_ckpt["kwargs"]), model_up)
+                   jitter_scale_from_kwargs(field_ckpt["kwargs"]), model_up, fold_heads)
+
+    def logits(self, tokens, ori, dirs, rgb):
+        """tokens [M, C+14] x rays -> (logits [M,N], row_max [M], row_sumexp [M])."""
+        if self.fold_heads:
+            return self.idnet.attn_logits_folded(self.idnet.q_fold(tokens), self.idnet.ray_trunk(ori, dirs, rgb))
+        _, k = self.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
+        return H.attn_logits(self.idnet.q_proj(tokens), k, gemm_mode=self.idnet.gemm_mode)
 
     # ------------------------------------------------------------------ stage A + B  (explore_model)
     def emit(self, gen_points: int, seed: int, point_range: Optional[Tuple[int, int]] = None, seed_offset=None):
@@ -51,8 +60,7 @@ class PosePipeline:
 
     # ------------------------------------------------------------------ stage C  (test_image + pose solve)
     def scores(self, tokens, ori, dirs, rgb, materialize_map: bool = True):
-        _, k = self.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
-        logits, rmax, rsum = H.attn_logits(self.idnet.q_proj(tokens), k)
+        logits, rmax, rsum = self.logits(tokens, ori, dirs, rgb)
         score = H.attn_colsum(logits, rmax, rsum, write_attention=materialize_map)
         return score, logits
 
@@ -80,8 +88,7 @@ class PosePipeline:
         lo, hi = D.shard_points(gen_points, rank, ws)
         ori, dirs, rgb = self.emit(gen_points, seed, (lo, hi) if ws > 1 else None)
         n_local = ori.shape[0]
-        _, kmat = self.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
-        logits, rmax, rsum = H.attn_logits(self.idnet.q_proj(tokens.reshape(Q * M, C)), kmat)
+        logits, rmax, rsum = self.logits(tokens.reshape(Q * M, C), ori, dirs, rgb)
         gmax, gsum = D.merge_row_stats(rmax, rsum, group)
         kl = min(k, n_local)
         lval = ori.new_full((Q, k), float("-inf"))

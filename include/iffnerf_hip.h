@@ -189,6 +189,25 @@ size_t iff_q_proj_workspace(const iff_idnet* net, int32_t M);
 int iff_q_proj(const iff_idnet* net, const float* img, int32_t M, float* q, void* workspace, size_t workspace_bytes,
                void* stream);
 
+/* The same logits with the three bias-only-separated Linears folded (no nonlinearity lies between
+ * ray_preprocessor.py:24-25 mlp2.2, multihead_attention.py:60 q_proj and :61 k_proj):
+ *   q . k = (Wq t + bq) . (Wk (W4 h3 + b4) + bk) = qf[0:C] . h3 + qf[C]
+ * with h3 [N,feature_c] the encoder's last hidden activation (after mlp2.0 + ReLU, ray_preprocessor.py:38) and
+ * qf [M, iff_q_fold_width] one token-side Linear whose weights are formed once, in double, at iff_idnet_create.
+ * Removes two of the five per-ray GEMMs and a third of the logits GEMM; results agree with the unfolded chain to fp32
+ * re-association error (tests/test_hip_identify.py::test_folded_heads).
+ *   iff_ray_trunk:          o,d,rgb [N,3] -> h3 [N,feature_c]          (ray_preprocessor.py:29-38 up to the last ReLU)
+ *   iff_q_fold:             img [M,img_fea] -> qf [M, width]           (multihead_attention.py:60, folded)
+ *   iff_attn_logits_folded: logits[M,N] = (qf[:, :C] h3^T + qf[:, C]) / divisor, row statistics as iff_attn_logits
+ *                           (multihead_attention.py:6-8) */
+size_t iff_ray_trunk_workspace(const iff_idnet* net, int64_t N);
+int iff_ray_trunk(const iff_idnet* net, const float* o, const float* d, const float* rgb, int64_t N, float* h3,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int32_t iff_q_fold_width(const iff_idnet* net);
+int iff_q_fold(const iff_idnet* net, const float* img, int32_t M, float* qf, void* stream);
+int iff_attn_logits_folded(const iff_idnet* net, const float* qf, const float* h3, int32_t M, int64_t N, float divisor,
+                           float* logits, float* row_max, float* row_sumexp, void* stream);
+
 /* scaled_attention_product (multihead_attention.py:4-12, mask=None), split so that ray shards on several
  * GPUs can exchange row statistics between the two halves:
  *   iff_attn_logits: logits[M,N] = q k^T / divisor (divisor = sqrt(d_k)), row_max[M], row_sumexp[M]
