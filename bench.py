@@ -5,7 +5,7 @@
 
 Step = one pass of the hot path over one batch of synthetic queries, COLD: every step re-runs stage A (device-side
 surface sampler + normals + 27-ray fans), stage B (20-sample VM march + Ref shading of every ray) and stage C (ray
-encoder + k_proj, q_proj, softmax over rays, column-sum score, top-100, closed-form pose).  Nothing is cached between
+encoder + q/k projections (folded, include/iffnerf_hip.h), softmax over rays, column-sum score, top-100, closed-form pose).  Nothing is cached between
 steps except the model tables; the ray encoder is recomputed per step as the reference does per image
 (pose_estimation/identification_module.py:164).  Workload at N = 1 is BASELINE.json configs[1]: "lego 800x800, 16k
 candidate rays": a synthetic lego-shaped TensorVMSplit (300^3 grid, 16/48 components, 180^3 mask), gen_points = 593 ->
@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--in-flight", type=int, default=4, help="cold queries kept in flight on separate streams (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N > 1 code path (captured segments + all_gathers) at any world size, for rehearsal on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,8 +99,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world_size > 1:
+    sharded = world_size > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     from iffnerf_amd import synthetic
@@ -108,28 +114,30 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world_size > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # N = 1: `in_flight` cold queries are kept in flight, each a captured hipGraph replayed on its own stream, so the
-    # latency-bound surface sampler of one query (47 workgroups) overlaps the throughput-bound stages of another.  Every
-    # replay bumps a device-side counter that is added to the sampler seed: no two steps draw the same rays.
-    # N > 1: eager launches on one stream (the RCCL all_gathers sit between the kernels).
-    in_flight = max(1, args.in_flight) if world_size == 1 else 1
-    if world_size == 1:
+    # `in_flight` steps are kept in flight, each a captured hipGraph (N = 1) or three captured segments with the two RCCL
+    # all_gathers issued eagerly between them (N > 1), replayed round-robin on their own streams, so the latency-bound
+    # surface sampler of one step (47 workgroups) overlaps the throughput-bound stages of another.  Every replay bumps a
+    # device-side counter that is added to the sampler seed: no two steps draw the same rays.  At N > 1 all steps use the
+    # one default process group, so every rank issues the collectives in the same order.
+    in_flight = max(1, args.in_flight)
+    streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
+    if not sharded:
         graphs = [pipe.capture_query(tokens[0].shape, GEN_POINTS, seed=(g + 1) << 40, k=TOPK) for g in range(in_flight)]
-        streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
         for g in graphs:
             g.tokens.copy_(tokens[0])
-        torch.cuda.synchronize(device)
-
-        def step(i):
-            with torch.cuda.stream(streams[i % in_flight]):
-                return graphs[i % in_flight].replay()
     else:
-        def step(i):
-            return pipe.query_sharded(tokens, GEN_POINTS, seed=1000 + i, k=TOPK)[0]
+        graphs = [pipe.capture_query_sharded(tokens.shape, GEN_POINTS, seed=(g + 1) << 40, k=TOPK) for g in range(in_flight)]
+        for g in graphs:
+            g.tokens.copy_(tokens)
+    torch.cuda.synchronize(device)
+
+    def step(i):
+        with torch.cuda.stream(streams[i % in_flight]):
+            return graphs[i % in_flight].replay()
 
     for i in range(args.warmup):
         step(i)
@@ -139,7 +147,7 @@ def main():
         out = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world_size > 1:
+    if sharded:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -150,7 +158,7 @@ def main():
         # ---- per-stage and dominant-kernel timing with events on the launch stream (outside the timed region)
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
         n_rep = 20
-        stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "encode_kproj": 0.0, "attention_topk_pose": 0.0}
+        stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "ray_encoder": 0.0, "attention_topk_pose": 0.0}
         march_launch_ms = [0.0, 0.0, 0.0]      # K4a density+compositing, K4b appearance gather, K4c Ref shading
         bytes_a = bytes_b = 0.0
         from iffnerf_amd import hip_identify as H
@@ -165,9 +173,9 @@ def main():
             e[2].record()
             rgb = pipe.field.march(rays, 0, 20, want_alpha=False)[0]
             e[3].record()
-            _, kmat = pipe.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
+            h3 = pipe.idnet.ray_trunk(ori, dirs, rgb)          # the folded path PosePipeline.logits runs (fold_heads=True)
             e[4].record()
-            logits, rmax, rsum = H.attn_logits(pipe.idnet.q_proj(tokens[0]), kmat)
+            logits, rmax, rsum = pipe.idnet.attn_logits_folded(pipe.idnet.q_fold(tokens[0]), h3)
             score = H.attn_colsum(logits, rmax, rsum, write_attention=True)
             idx, val = H.topk(score, TOPK)
             H.pose_from_topk(idx, val, ori, dirs, pipe.model_up)
@@ -218,8 +226,10 @@ def main():
             "config": {"workload": "lego-shaped TensorVMSplit 300^3 (16/48 comps, 180^3 mask), gen_points=593 -> 16011 rays, "
                                    "M=256 tokens, top-100, cold path (A+B+C every step)",
                        "queries_per_step": Q, "rays_total": GEN_POINTS * 27, "queries_in_flight": in_flight,
-                       "launch": "hipGraph replay per query" if world_size == 1 else "eager",
-                       "parallelism": "single GPU" if world_size == 1 else f"rays sharded over {world_size} ranks + 2 all_gathers"},
+                       "emissions_per_step": 1,
+                       "gemm": "3xBF16 split on the bf16 MFMA (fp32-accurate), fp32 accumulate; march and shading in fp32",
+                       "launch": "hipGraph replay per query" if not sharded else "3 hipGraph segments + 2 eager RCCL all_gathers per step",
+                       "parallelism": "single GPU" if not sharded else f"rays sharded over {world_size} ranks + 2 all_gathers"},
             "warm_poses_per_s": round(warm, 2),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": roofline,
@@ -228,7 +238,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(ck, idw, tokens[0].cpu())
         else:
             result["cpu_baseline"] = None
-    if world_size > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

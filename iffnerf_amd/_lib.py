@@ -81,6 +81,9 @@ SIGNATURES = {
     "iff_topk_workspace": (_SZ, [_I64, _I32]),
     "iff_topk": (C.c_int, [_VP, _I64, _I32, _VP, _VP, _VP, _SZ, _VP]),
     "iff_pose_from_topk": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _I64, c_float_p, _VP, _VP, _VP]),
+    "iff_attn_colsum_batched": (C.c_int, [_VP, _I32, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
+    "iff_topk_batched": (C.c_int, [_VP, _I32, _I64, _I32, _VP, _VP, _VP]),
+    "iff_pose_from_topk_batched": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _I64, _I64, c_float_p, _VP, _VP]),
 }
 
 

@@ -509,7 +509,16 @@ extern "C" int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const 
     IFF_REQUIRE(M >= 1 && M <= 8192 && N >= 0, "iff_attn_colsum: bad shape");
     if (N == 0) return 0;
     IFF_REQUIRE(logits_inout && row_max && row_sumexp && score, "iff_attn_colsum: null buffer");
-    IFF_HIP(launch_attn_colsum(logits_inout, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));
+    IFF_HIP(launch_attn_colsum(logits_inout, 1, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_attn_colsum_batched(float* logits_inout, int32_t Q, int32_t M, int64_t N, const float* row_max,
+                                       const float* row_sumexp, int32_t write_attention, float* score, void* stream) {
+    IFF_REQUIRE(Q >= 0 && Q <= 65535 && M >= 1 && M <= 8192 && N >= 0, "iff_attn_colsum_batched: bad shape");
+    if (N == 0 || Q == 0) return 0;
+    IFF_REQUIRE(logits_inout && row_max && row_sumexp && score, "iff_attn_colsum_batched: null buffer");
+    IFF_HIP(launch_attn_colsum(logits_inout, Q, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));
     return 0;
 }
 
@@ -520,7 +529,17 @@ extern "C" int iff_topk(const float* score, int64_t N, int32_t k, int64_t* idx, 
     IFF_REQUIRE(score && idx && val, "iff_topk: null buffer");
     IFF_REQUIRE(k >= 1 && k <= 1024, "iff_topk: k = %d outside [1, 1024]", k);
     IFF_REQUIRE(N >= k, "iff_topk: k = %d exceeds N = %lld (torch.topk raises here too)", k, (long long)N);
-    IFF_HIP(launch_topk(score, N, k, idx, val, workspace, workspace_bytes, (hipStream_t)stream));
+    IFF_HIP(launch_topk(score, 1, N, k, idx, val, workspace, workspace_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_topk_batched(const float* score, int32_t Q, int64_t N, int32_t k, int64_t* idx, float* val, void* stream) {
+    IFF_REQUIRE(Q >= 0, "iff_topk_batched: bad batch");
+    if (Q == 0) return 0;
+    IFF_REQUIRE(score && idx && val, "iff_topk_batched: null buffer");
+    IFF_REQUIRE(k >= 1 && k <= 1024, "iff_topk_batched: k = %d outside [1, 1024]", k);
+    IFF_REQUIRE(N >= k, "iff_topk_batched: k = %d exceeds N = %lld", k, (long long)N);
+    IFF_HIP(launch_topk(score, Q, N, k, idx, val, nullptr, 0, (hipStream_t)stream));
     return 0;
 }
 
@@ -528,6 +547,17 @@ extern "C" int iff_pose_from_topk(const int64_t* idx, const float* val, int32_t 
                                   int64_t N, const float* up_host, float* c2w, float* parts_opt, void* stream) {
     IFF_REQUIRE(idx && val && rays_o && rays_d && up_host && c2w, "iff_pose_from_topk: null buffer");
     IFF_REQUIRE(k >= 1 && k <= 1024, "iff_pose_from_topk: k = %d outside [1, 1024]", k);
-    IFF_HIP(launch_pose(idx, val, k, rays_o, rays_d, N, up_host, c2w, parts_opt, (hipStream_t)stream));
+    IFF_HIP(launch_pose(idx, val, 1, k, rays_o, rays_d, N, 0, up_host, c2w, parts_opt, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_pose_from_topk_batched(const int64_t* idx, const float* val, int32_t Q, int32_t k, const float* rays_o,
+                                          const float* rays_d, int64_t N, int64_t ray_batch_stride, const float* up_host,
+                                          float* c2w, void* stream) {
+    IFF_REQUIRE(Q >= 0 && ray_batch_stride >= 0, "iff_pose_from_topk_batched: bad batch");
+    if (Q == 0) return 0;
+    IFF_REQUIRE(idx && val && rays_o && rays_d && up_host && c2w, "iff_pose_from_topk_batched: null buffer");
+    IFF_REQUIRE(k >= 1 && k <= 1024, "iff_pose_from_topk_batched: k = %d outside [1, 1024]", k);
+    IFF_HIP(launch_pose(idx, val, Q, k, rays_o, rays_d, N, ray_batch_stride, up_host, c2w, nullptr, (hipStream_t)stream));
     return 0;
 }

@@ -617,6 +617,10 @@ __global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int
     extern __shared__ float s_stats[];   // [2][M] then [4][64] partials
     float* s_part = s_stats + 2 * M;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    {   // blockIdx.y = query of a batch: logits [Q][M][N], statistics [Q][M], score [Q][N]
+        const int64_t qb = blockIdx.y;
+        logits += qb * M * N; row_max += qb * M; row_sumexp += qb * M; score += qb * N;
+    }
     for (int i = tid; i < M; i += 256) { s_stats[i] = row_max[i]; s_stats[M + i] = row_sumexp[i]; }
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 64 + lane;
@@ -636,10 +640,10 @@ __global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int
     if (g == 0 && j < N) score[j] = (s_part[lane] + s_part[64 + lane]) + (s_part[128 + lane] + s_part[192 + lane]);
 }
 
-hipError_t launch_attn_colsum(float* logits, int M, int64_t N, const float* row_max, const float* row_sumexp,
+hipError_t launch_attn_colsum(float* logits, int Q, int M, int64_t N, const float* row_max, const float* row_sumexp,
                               int write_attention, float* score, hipStream_t s) {
-    if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(k6_colsum, dim3((unsigned)((N + 63) / 64)), dim3(256), (2 * (size_t)M + 256) * sizeof(float), s, logits,
+    if (N == 0 || Q == 0) return hipSuccess;
+    hipLaunchKernelGGL(k6_colsum, dim3((unsigned)((N + 63) / 64), (unsigned)Q), dim3(256), (2 * (size_t)M + 256) * sizeof(float), s, logits,
                        M, N, row_max, row_sumexp, write_attention, score);
     return hipGetLastError();
 }
@@ -665,6 +669,7 @@ __global__ void __launch_bounds__(TK_THREADS) k7_topk(const float* __restrict__ 
     __shared__ int n_gt, n_eq, eq_base;
     __shared__ int scan[TK_THREADS];
     const int tid = threadIdx.x;
+    score += (int64_t)blockIdx.x * N; idx += (int64_t)blockIdx.x * k; val += (int64_t)blockIdx.x * k;   // one workgroup per query
     const uint32_t T = iff_wg_select_key<true>(score, N, k, hist);
     if (tid == 0) { n_gt = 0; n_eq = 0; eq_base = 0; }
     s_val[tid] = -INFINITY; s_idx[tid] = 0x7fffffff; s_eq[tid] = 0x7fffffff;
@@ -737,9 +742,9 @@ __global__ void __launch_bounds__(TK_THREADS) k7_topk(const float* __restrict__ 
 
 size_t topk_workspace_bytes(int64_t N, int k) { (void)N; (void)k; return 256; }
 
-hipError_t launch_topk(const float* score, int64_t N, int k, int64_t* idx, float* val, void* ws, size_t ws_bytes, hipStream_t s) {
+hipError_t launch_topk(const float* score, int Q, int64_t N, int k, int64_t* idx, float* val, void* ws, size_t ws_bytes, hipStream_t s) {
     (void)ws; (void)ws_bytes;
-    if (k < 1 || k > 1024 || k > N || N >= 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k7_topk, dim3(1), dim3(TK_THREADS), 0, s, score, N, k, idx, val);
+    if (k < 1 || k > 1024 || k > N || N >= 0x7fffffff || Q < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k7_topk, dim3((unsigned)Q), dim3(TK_THREADS), 0, s, score, N, k, idx, val);
     return hipGetLastError();
 }

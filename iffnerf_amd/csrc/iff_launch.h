@@ -67,12 +67,12 @@ hipError_t launch_transpose_pad(const float* w_out_in, float* dst_in_out, int ou
 hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, int D, float divisor, float* logits,
                               float* row_max, float* row_sumexp, int gemm_mode, hipStream_t s);
 hipError_t launch_split_rows(const float* w, void* planes, int out_f, int in_f, int in_pad, hipStream_t s);
-hipError_t launch_attn_colsum(float* logits, int M, int64_t N, const float* row_max, const float* row_sumexp,
+hipError_t launch_attn_colsum(float* logits, int Q, int M, int64_t N, const float* row_max, const float* row_sumexp,
                               int write_attention, float* score, hipStream_t s);
 size_t topk_workspace_bytes(int64_t N, int k);
-hipError_t launch_topk(const float* score, int64_t N, int k, int64_t* idx, float* val, void* ws, size_t ws_bytes,
+hipError_t launch_topk(const float* score, int Q, int64_t N, int k, int64_t* idx, float* val, void* ws, size_t ws_bytes,
                        hipStream_t s);
 
 // pose_kernels.hip
-hipError_t launch_pose(const int64_t* idx, const float* val, int k, const float* rays_o, const float* rays_d, int64_t N,
-                       const float* up3, float* c2w, float* parts, hipStream_t s);
+hipError_t launch_pose(const int64_t* idx, const float* val, int Q, int k, const float* rays_o, const float* rays_d, int64_t N,
+                       int64_t ray_batch_stride, const float* up3, float* c2w, float* parts, hipStream_t s);

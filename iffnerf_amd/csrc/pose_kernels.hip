@@ -85,8 +85,14 @@ __device__ inline void block_sum(float* v, float* buf) {
 
 __global__ void __launch_bounds__(256) k_pose(const int64_t* __restrict__ idx, const float* __restrict__ val, int k,
                                               const float* __restrict__ rays_o, const float* __restrict__ rays_d, int64_t N,
-                                              float up0, float up1, float up2, int isin_direct_limit,
+                                              int64_t ray_batch_stride, float up0, float up1, float up2, int isin_direct_limit,
                                               float* __restrict__ c2w, float* __restrict__ parts) {
+    {   // blockIdx.x = query of a batch (the per-image loop of pose_estimation/test.py:67-91)
+        const int64_t qb = blockIdx.x;
+        idx += qb * k; val += qb * k; c2w += qb * 16;
+        rays_o += qb * ray_batch_stride; rays_d += qb * ray_batch_stride;
+        if (parts) parts += qb * (8 + k);
+    }
     __shared__ float4 so4[PK_MAX];                  // origin xyz + "occurs exactly once" flag in .w
     __shared__ float sd[PK_MAX * 3], sw[PK_MAX];
     __shared__ unsigned char keep[PK_MAX], flag[PK_MAX * 3];
@@ -255,11 +261,12 @@ __global__ void __launch_bounds__(256) k_pose(const int64_t* __restrict__ idx, c
     }
 }
 
-hipError_t launch_pose(const int64_t* idx, const float* val, int k, const float* rays_o, const float* rays_d, int64_t N,
-                       const float* up3, float* c2w, float* parts, hipStream_t s) {
-    if (k < 1 || k > PK_MAX) return hipErrorInvalidValue;
+hipError_t launch_pose(const int64_t* idx, const float* val, int Q, int k, const float* rays_o, const float* rays_d, int64_t N,
+                       int64_t ray_batch_stride, const float* up3, float* c2w, float* parts, hipStream_t s) {
+    if (k < 1 || k > PK_MAX || Q < 1) return hipErrorInvalidValue;
     // aten's heuristic (taken from numpy): direct membership test iff n_test < 10 * n_elements^0.145
     const int lim = (int)(int64_t)(10.0f * std::pow((double)(3 * k), 0.145));
-    hipLaunchKernelGGL(k_pose, dim3(1), dim3(256), 0, s, idx, val, k, rays_o, rays_d, N, up3[0], up3[1], up3[2], lim, c2w, parts);
+    hipLaunchKernelGGL(k_pose, dim3((unsigned)Q), dim3(256), 0, s, idx, val, k, rays_o, rays_d, N, ray_batch_stride, up3[0], up3[1],
+                       up3[2], lim, c2w, parts);
     return hipGetLastError();
 }

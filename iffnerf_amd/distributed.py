@@ -46,7 +46,11 @@ def _all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
 
 def merge_row_stats(row_max: torch.Tensor, row_sumexp: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Local (max_i, sum_j exp(l_ij - max_i)) over this rank's columns -> the same statistics over all columns."""
-    both = _all_gather_stack(torch.stack((row_max, row_sumexp), dim=-1), group)      # [G, R, 2]
+    return merge_row_stats_gathered(_all_gather_stack(torch.stack((row_max, row_sumexp), dim=-1), group))
+
+
+def merge_row_stats_gathered(both: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``both`` [G, R, 2]: every rank's (max, sum-exp) per row, in rank order -> global (max [R], sum-exp [R])."""
     gmax = both[..., 0].max(dim=0).values
     gsum = torch.zeros_like(gmax)
     for r in range(both.shape[0]):                                                    # fixed rank order: reproducible
@@ -61,9 +65,12 @@ def merge_topk(local_val: torch.Tensor, local_idx: torch.Tensor, payload: torch.
     that must travel with the winners (origin, direction).  Returns (val [Q,k], idx [Q,k], payload [Q,k,C]) ordered by
     value descending, lower global index first on ties -- the order ``iff_topk`` produces on one GPU.
     """
-    vals = _all_gather_stack(local_val, group)                     # [G,Q,kl]
-    idxs = _all_gather_stack(local_idx, group)
-    pays = _all_gather_stack(payload, group)                       # [G,Q,kl,C]
+    return merge_topk_gathered(_all_gather_stack(local_val, group), _all_gather_stack(local_idx, group),
+                               _all_gather_stack(payload, group), k)
+
+
+def merge_topk_gathered(vals: torch.Tensor, idxs: torch.Tensor, pays: torch.Tensor, k: int):
+    """vals, idxs [G,Q,kl], pays [G,Q,kl,C] (every rank's candidates in rank order) -> global top-k as ``merge_topk``."""
     G, Q, kl = vals.shape
     vals = vals.permute(1, 0, 2).reshape(Q, G * kl)
     idxs = idxs.permute(1, 0, 2).reshape(Q, G * kl)
@@ -86,3 +93,16 @@ def gather_scores(local_score: torch.Tensor, counts, group=None) -> torch.Tensor
     padded[:, :local_score.shape[1]] = local_score
     allp = _all_gather_stack(padded, group)
     return torch.cat([allp[r, :, :counts[r]] for r in range(ws)], dim=1)
+
+
+def pack_candidates(val: torch.Tensor, idx: torch.Tensor, payload: torch.Tensor) -> torch.Tensor:
+    """(val [Q,k] f32, idx [Q,k] int64 < 2^31, payload [Q,k,C] f32) -> one f32 message [Q,k,2+C] (index bits in slot 1)."""
+    bits = idx.to(torch.int32).contiguous().view(torch.float32)
+    return torch.cat((val[..., None], bits[..., None], payload), dim=-1).contiguous()
+
+
+def unpack_candidates(msg: torch.Tensor):
+    """Inverse of ``pack_candidates`` on a gathered message [..., k, 2+C] -> (val, idx int64, payload)."""
+    val = msg[..., 0].contiguous()
+    idx = msg[..., 1].contiguous().view(torch.int32).to(torch.int64)
+    return val, idx, msg[..., 2:].contiguous()

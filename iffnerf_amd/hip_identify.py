@@ -195,3 +195,57 @@ def pose_from_topk(idx, val, rays_o, rays_d, model_up, want_parts: bool = False)
         check(_lib.lib().iff_pose_from_topk(dptr(idx, torch.int64), dptr(val), k, dptr(o), dptr(d), o.shape[0], up, dptr(c2w),
                                             dptr(parts), stream_ptr(o.device)), "iff_pose_from_topk")
     return (c2w, parts) if want_parts else c2w
+
+
+# ---------------------------------------------------------------------------------------------- batches of queries
+def attn_colsum_batched(logits: torch.Tensor, row_max: torch.Tensor, row_sumexp: torch.Tensor, Q: int,
+                        write_attention: bool = True):
+    """logits [Q*M, N] (Q queries of M token rows each), statistics [Q*M] -> score [Q, N]; attention in place if asked."""
+    QM, N = logits.shape
+    if Q < 1 or QM % Q:
+        raise RuntimeError(f"logits rows ({QM}) must be a multiple of the number of queries ({Q})")
+    score = logits.new_empty(Q, N)
+    with torch.cuda.device(logits.device):
+        check(_lib.lib().iff_attn_colsum_batched(dptr(logits), Q, QM // Q, N, dptr(row_max), dptr(row_sumexp),
+                                                 int(write_attention), dptr(score), stream_ptr(logits.device)),
+              "iff_attn_colsum_batched")
+    return score
+
+
+def topk_batched(score: torch.Tensor, k: int):
+    """score [Q, N] -> (idx [Q, k] int64, val [Q, k]), each row as ``topk``."""
+    s = _gpu(score, "scores")
+    if s.dim() != 2:
+        raise RuntimeError("topk_batched expects scores [Q, N]")
+    Q, N = s.shape
+    if k > N:
+        raise RuntimeError(f"selected index k out of range (k={k}, N={N})")
+    idx = torch.empty(Q, k, dtype=torch.int64, device=s.device)
+    val = s.new_empty(Q, k)
+    with torch.cuda.device(s.device):
+        check(_lib.lib().iff_topk_batched(dptr(s), Q, N, k, dptr(idx, torch.int64), dptr(val), stream_ptr(s.device)),
+              "iff_topk_batched")
+    return idx, val
+
+
+def pose_from_topk_batched(idx, val, rays_o, rays_d, model_up):
+    """idx, val [Q, k]; rays_o / rays_d either one shared ray set [N, 3] or per-query candidates [Q, n, 3] -> c2w [Q, 4, 4]."""
+    idx = idx.detach().to(torch.int64).contiguous()
+    val = _gpu(val, "weights")
+    if not idx.is_cuda:
+        raise RuntimeError("idx must live on the GPU; libiffnerf_hip has no CPU path")
+    Q, k = idx.shape
+    o = rays_o.detach().to(torch.float32).contiguous()
+    d = rays_d.detach().to(torch.float32).contiguous()
+    if not (o.is_cuda and d.is_cuda):
+        raise RuntimeError("rays must live on the GPU; libiffnerf_hip has no CPU path")
+    if o.shape != d.shape or o.shape[-1] != 3 or (o.dim() == 3 and o.shape[0] != Q) or o.dim() not in (2, 3):
+        raise RuntimeError("rays_o / rays_d must both be [N,3] or [Q,n,3]")
+    n = o.shape[-2]
+    stride = n * 3 if o.dim() == 3 else 0
+    c2w = o.new_empty(Q, 4, 4)
+    up = fvec(torch.as_tensor(model_up).detach().cpu().reshape(-1).tolist())
+    with torch.cuda.device(o.device):
+        check(_lib.lib().iff_pose_from_topk_batched(dptr(idx, torch.int64), dptr(val), Q, k, dptr(o), dptr(d), n, stride, up,
+                                                    dptr(c2w), stream_ptr(o.device)), "iff_pose_from_topk_batched")
+    return c2w

@@ -69,42 +69,68 @@ class PosePipeline:
         idx, val = H.topk(score, k)
         return H.pose_from_topk(idx, val, ori, dirs, self.model_up), idx, val
 
-    def query(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None):
-        """Cold per-query path: emission + identification + pose."""
+    def query(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None, materialize_map: bool = False):
+        """Cold per-query path: emission + identification + pose -> (c2w, top-k idx, top-k val).  The attention map is not
+        part of the result, so by default it is not written back (scores come straight from logits + row statistics)."""
         ori, dirs, rgb = self.emit(gen_points, seed, seed_offset=seed_offset)
-        return self.identify(tokens, ori, dirs, rgb, k)
+        return self.identify(tokens, ori, dirs, rgb, k, materialize_map)
 
     def capture_query(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100) -> "CapturedQuery":
         return CapturedQuery(self, tokens_shape, gen_points, seed, k)
 
     # ------------------------------------------------------------------ ray-sharded batch of queries (multi-GPU)
+    # Three local segments with one small exchange between each pair (distributed.py): the eager ``query_sharded`` and the
+    # captured ``CapturedShardedQuery`` run the same three functions.
+    def shard_local_logits(self, tokens, gen_points: int, seed: int, rank: int, ws: int, seed_offset=None):
+        """Segment 1: this rank's block of the ray set and its logits columns.
+        -> (ori, dirs [n_local,3], logits [Q*M, n_local], stats [Q*M, 2] = local (row max, row sum-exp))."""
+        from . import distributed as D
+        Q, M, C = tokens.shape
+        lo, hi = D.shard_points(gen_points, rank, ws)
+        ori, dirs, rgb = self.emit(gen_points, seed, (lo, hi) if ws > 1 else None, seed_offset=seed_offset)
+        logits, rmax, rsum = self.logits(tokens.reshape(Q * M, C), ori, dirs, rgb)
+        return ori, dirs, logits, torch.stack((rmax, rsum), dim=-1)
+
+    def shard_local_candidates(self, logits, stats_all, ori, dirs, Q: int, k: int, first_ray: int, materialize_map: bool = True):
+        """Segment 2: global statistics -> this rank's score columns -> its top-k candidates per query, packed as one
+        message [Q, k, 8] = (score, global ray index bits, origin, direction); unfilled slots hold -inf / 2^31-1."""
+        from . import distributed as D
+        gmax, gsum = D.merge_row_stats_gathered(stats_all)
+        score = H.attn_colsum_batched(logits, gmax.contiguous(), gsum.contiguous(), Q, write_attention=materialize_map)
+        n_local = ori.shape[0]
+        kl = min(k, n_local)
+        i, v = H.topk_batched(score, kl)
+        lval = ori.new_full((Q, k), float("-inf"))
+        lidx = torch.full((Q, k), 2 ** 31 - 1, dtype=torch.int64, device=ori.device)
+        pay = ori.new_zeros(Q, k, 6)
+        lval[:, :kl], lidx[:, :kl] = v, i + first_ray
+        pay[:, :kl, :3], pay[:, :kl, 3:] = ori[i], dirs[i]
+        return D.pack_candidates(lval, lidx, pay)
+
+    def shard_global_poses(self, cand_all, k: int):
+        """Segment 3: every rank's candidates [G, Q, k, 8] -> (poses [Q,4,4], val [Q,k], global ray idx [Q,k])."""
+        from . import distributed as D
+        vals, idxs, pays = D.unpack_candidates(cand_all)
+        val, idx, pay = D.merge_topk_gathered(vals, idxs, pays, k)
+        Q = val.shape[0]
+        ar = torch.arange(k, device=val.device).expand(Q, k).contiguous()
+        poses = H.pose_from_topk_batched(ar, val.contiguous(), pay[..., :3].contiguous(), pay[..., 3:].contiguous(), self.model_up)
+        return poses, val, idx
+
     def query_sharded(self, tokens, gen_points: int, seed: int, k: int = 100, group=None, materialize_map: bool = True):
         """``tokens`` [Q,M,C+14]: Q query images against ONE emitted ray set whose surface points are sharded over the
         ranks of ``group``.  Every rank returns the Q poses [Q,4,4] (identical on all ranks) and the global top-k
         (values [Q,k], global ray indices [Q,k]).  With one rank this is ``query`` for each image."""
         from . import distributed as D
         rank, ws = D.world(group)
-        Q, M, C = tokens.shape
-        lo, hi = D.shard_points(gen_points, rank, ws)
-        ori, dirs, rgb = self.emit(gen_points, seed, (lo, hi) if ws > 1 else None)
-        n_local = ori.shape[0]
-        logits, rmax, rsum = self.logits(tokens.reshape(Q * M, C), ori, dirs, rgb)
-        gmax, gsum = D.merge_row_stats(rmax, rsum, group)
-        kl = min(k, n_local)
-        lval = ori.new_full((Q, k), float("-inf"))
-        lidx = torch.full((Q, k), 2 ** 62, dtype=torch.int64, device=ori.device)
-        pay = ori.new_zeros(Q, k, 6)
-        for q in range(Q):
-            sl = slice(q * M, (q + 1) * M)
-            score = H.attn_colsum(logits[sl], gmax[sl].contiguous(), gsum[sl].contiguous(), write_attention=materialize_map)
-            i, v = H.topk(score, kl)
-            lval[q, :kl], lidx[q, :kl] = v, i + lo * 27
-            pay[q, :kl, :3], pay[q, :kl, 3:] = ori[i], dirs[i]
-        val, idx, pay = D.merge_topk(lval, lidx, pay, k, group)
-        ar = torch.arange(k, device=ori.device)
-        poses = torch.stack([H.pose_from_topk(ar, val[q].contiguous(), pay[q, :, :3].contiguous(),
-                                              pay[q, :, 3:].contiguous(), self.model_up) for q in range(Q)])
-        return poses, val, idx
+        Q = tokens.shape[0]
+        lo, _ = D.shard_points(gen_points, rank, ws)
+        ori, dirs, logits, stats = self.shard_local_logits(tokens, gen_points, seed, rank, ws)
+        cand = self.shard_local_candidates(logits, D._all_gather_stack(stats, group), ori, dirs, Q, k, lo * 27, materialize_map)
+        return self.shard_global_poses(D._all_gather_stack(cand, group), k)
+
+    def capture_query_sharded(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100, group=None) -> "CapturedShardedQuery":
+        return CapturedShardedQuery(self, tokens_shape, gen_points, seed, k, group)
 
 
 class CapturedQuery:
@@ -139,3 +165,63 @@ class CapturedQuery:
             self.tokens.copy_(tokens, non_blocking=True)
         self.graph.replay()
         return self.c2w
+
+
+class CapturedShardedQuery:
+    """``PosePipeline.query_sharded`` as three captured hipGraph segments with the two RCCL all_gathers issued eagerly between
+    them (collectives are never captured).  A replay costs the host three graph launches and two collective calls instead
+    of about forty kernel launches, and several instances replayed round-robin on their own streams keep the latency-bound
+    sampler of one batch under the throughput-bound stages of another.  All instances use ONE process group, so the
+    collectives of all in-flight batches are issued in the same order on every rank.
+
+    Static buffers: ``tokens`` [Q,M,C] in; ``poses`` [Q,4,4], ``val`` / ``idx`` [Q,k] out (valid once the replay's stream
+    is synchronised, until the next replay of this instance).
+    """
+
+    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100, group=None):
+        import torch.distributed as dist
+        from . import distributed as D
+        dev = pipe.device
+        self.pipe, self.group, self.k = pipe, group, k
+        self.rank, self.ws = D.world(group)
+        self.collective = dist.is_available() and dist.is_initialized()
+        Q = int(tokens_shape[0])
+        lo, _ = D.shard_points(gen_points, self.rank, self.ws)
+        self.tokens = torch.zeros(tokens_shape, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                 # warm-up outside capture (lazy initialisations, allocator, RCCL)
+            for _ in range(2):
+                pipe.query_sharded(self.tokens, gen_points, seed, k, group)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        opts = dict(capture_error_mode="thread_local")     # the RCCL watchdog thread must not invalidate a capture
+        self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1, **opts):
+            self.counter += 1
+            ori, dirs, logits, self.stats = pipe.shard_local_logits(self.tokens, gen_points, seed, self.rank, self.ws,
+                                                                    seed_offset=self.counter)
+        self.stats_all = self.stats.new_zeros((self.ws,) + tuple(self.stats.shape))
+        with torch.cuda.graph(self.g2, **opts):
+            self.cand = pipe.shard_local_candidates(logits, self.stats_all, ori, dirs, Q, k, lo * 27, materialize_map=False)
+        self.cand_all = self.cand.new_zeros((self.ws,) + tuple(self.cand.shape))
+        with torch.cuda.graph(self.g3, **opts):
+            self.poses, self.val, self.idx = pipe.shard_global_poses(self.cand_all, k)
+
+    def _gather(self, out, src):
+        import torch.distributed as dist
+        if self.collective:
+            dist.all_gather_into_tensor(out, src, group=self.group)
+        else:
+            out.copy_(src[None])
+
+    def replay(self, tokens: Optional[torch.Tensor] = None):
+        if tokens is not None:
+            self.tokens.copy_(tokens, non_blocking=True)
+        self.g1.replay()
+        self._gather(self.stats_all, self.stats)
+        self.g2.replay()
+        self._gather(self.cand_all, self.cand)
+        self.g3.replay()
+        return self.poses

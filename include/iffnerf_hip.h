@@ -218,12 +218,19 @@ int iff_attn_logits(const float* q, const float* k, int32_t M, int64_t N, int32_
                     float* row_max, float* row_sumexp, int32_t gemm_mode, void* stream);
 int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const float* row_max, const float* row_sumexp,
                     int32_t write_attention, float* score, void* stream);
+/* iff_attn_colsum for Q queries at once: logits [Q,M,N], statistics [Q,M] -> score [Q,N]
+ * (the per-image loop of pose_estimation/test.py:67-91 around identification_module.py:167) */
+int iff_attn_colsum_batched(float* logits_inout, int32_t Q, int32_t M, int64_t N, const float* row_max,
+                            const float* row_sumexp, int32_t write_attention, float* score, void* stream);
 
 /* torch.topk(scores, k) (identification_module.py:207): values descending, ties by lower index first.
  * idx [k] int64, val [k].  Workspace: iff_topk_workspace(N, k). */
 size_t iff_topk_workspace(int64_t N, int32_t k);
 int iff_topk(const float* score, int64_t N, int32_t k, int64_t* idx, float* val, void* workspace,
              size_t workspace_bytes, void* stream);
+/* Q score rows at once (identification_module.py:207 inside the per-image loop of test.py:67-91):
+ * score [Q,N] -> idx [Q,k], val [Q,k]; one workgroup per query */
+int iff_topk_batched(const float* score, int32_t Q, int64_t N, int32_t k, int64_t* idx, float* val, void* stream);
 
 /* Per-image pose solve, pose_estimation/test.py:133-174,192-194 with pose_geometry.py:42-95,175-204:
  * unique-origin filter, LS line intersection, negative exclusion, look-at rotation, NaN/singular -> identity.
@@ -231,6 +238,12 @@ int iff_topk(const float* score, int64_t N, int32_t k, int64_t* idx, float* val,
  * c2w [16] row-major; parts_opt [8 + k] = centre(3), watch(3), n_kept, spare, weights[k] (nullable). */
 int iff_pose_from_topk(const int64_t* idx, const float* val, int32_t k, const float* rays_o, const float* rays_d,
                        int64_t N, const float* up_host, float* c2w, float* parts_opt, void* stream);
+/* Q pose solves at once (the per-image loop of pose_estimation/test.py:67-91 around :133-174): idx, val [Q,k] ->
+ * c2w [Q,16].  ray_batch_stride = 0: all queries index ONE ray set rays_o/rays_d [N,3]; otherwise query q reads
+ * rays_o + q * ray_batch_stride (floats), e.g. k*3 for per-query gathered candidates [Q,k,3]. */
+int iff_pose_from_topk_batched(const int64_t* idx, const float* val, int32_t Q, int32_t k, const float* rays_o,
+                               const float* rays_d, int64_t N, int64_t ray_batch_stride, const float* up_host,
+                               float* c2w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,132 @@
+"""GPU: the ray-sharded batch-of-queries path (PosePipeline.query_sharded and its captured form).
+
+There is one GPU on the test box, so the two-rank exchange is covered three ways: (1) one rank, no process group: the
+sharded code path must reproduce the plain per-query path; (2) two ranks EMULATED on one GPU -- each rank's segments run
+one after the other and the gathered messages are stacked by hand, exactly what the all_gathers deliver -- against the
+unsharded result; (3) a real RCCL process group of world size 1 under the captured segments, two batches in flight.
+The exchange/merge code itself also runs under world_size-2 gloo in tests/test_distributed_gloo.py.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from iffnerf_amd import synthetic
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def pipe(dev):
+    from iffnerf_amd.pipeline import PosePipeline
+    return PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
+
+
+def _tokens(dev, Q=3, M=64):
+    return torch.stack([synthetic.make_tokens(M, 384, seed=7 + q) for q in range(Q)]).to(dev)
+
+
+def test_one_rank_equals_the_per_query_path(pipe, dev):
+    tok = _tokens(dev)
+    poses, val, idx = pipe.query_sharded(tok, 75, seed=31, k=100)
+    for q in range(tok.shape[0]):
+        c2w, i, v = pipe.query(tok[q], 75, seed=31, k=100)
+        assert torch.equal(idx[q], i) and torch.equal(val[q], v)
+        assert torch.equal(poses[q], c2w)
+
+
+def test_two_emulated_ranks_equal_one(pipe, dev):
+    from iffnerf_amd import distributed as D
+    tok = _tokens(dev)
+    Q, k, P = tok.shape[0], 100, 75
+    want_pose, want_val, want_idx = pipe.query_sharded(tok, P, seed=77, k=k)
+    for ws in (2, 3):
+        seg1 = [pipe.shard_local_logits(tok, P, 77, r, ws) for r in range(ws)]
+        assert sum(s[0].shape[0] for s in seg1) == P * 27
+        stats_all = torch.stack([s[3] for s in seg1])
+        cands = []
+        for r, (ori, dirs, logits, _) in enumerate(seg1):
+            lo, _ = D.shard_points(P, r, ws)
+            cands.append(pipe.shard_local_candidates(logits, stats_all, ori, dirs, Q, k, lo * 27, materialize_map=False))
+        poses, val, idx = pipe.shard_global_poses(torch.stack(cands), k)
+        assert torch.equal(idx, want_idx), f"{ws} shards: global top-k indices differ from the unsharded run"
+        torch.testing.assert_close(val, want_val, atol=1e-7, rtol=2e-5)
+        torch.testing.assert_close(poses, want_pose, atol=1e-5, rtol=0)
+
+
+def test_few_rays_per_rank_pads_candidates(pipe, dev):
+    """A shard with fewer than k rays: its message is padded with -inf / sentinel indices that never win."""
+    from iffnerf_amd import distributed as D
+    tok = _tokens(dev, Q=2)
+    P, k, ws = 9, 100, 3                       # 243 rays in total, 81 per rank < k
+    want_pose, want_val, want_idx = pipe.query_sharded(tok, P, seed=5, k=k)
+    seg1 = [pipe.shard_local_logits(tok, P, 5, r, ws) for r in range(ws)]
+    stats_all = torch.stack([s[3] for s in seg1])
+    cands = torch.stack([pipe.shard_local_candidates(s[2], stats_all, s[0], s[1], 2, k, D.shard_points(P, r, ws)[0] * 27, False)
+                         for r, s in enumerate(seg1)])
+    poses, val, idx = pipe.shard_global_poses(cands, k)
+    assert torch.equal(idx, want_idx) and int(idx.max()) < P * 27
+    torch.testing.assert_close(poses, want_pose, atol=1e-5, rtol=0)
+
+
+def test_captured_segments_replay_like_eager(pipe, dev):
+    tok = _tokens(dev)
+    eager = {s: [t.clone() for t in pipe.query_sharded(tok, 75, seed=200 + s, k=100)] for s in (1, 2, 3)}
+    cq = pipe.capture_query_sharded(tok.shape, 75, seed=200, k=100)
+    cq.tokens.copy_(tok)
+    torch.cuda.synchronize()
+    for s in (1, 2, 3):
+        cq.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cq.idx, eager[s][2]) and torch.equal(cq.val, eager[s][1]) and torch.equal(cq.poses, eager[s][0])
+
+
+_RCCL_WORLD1 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from iffnerf_amd import synthetic
+from iffnerf_amd.pipeline import PosePipeline
+from tests import util
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
+tok = torch.stack([synthetic.make_tokens(64, 384, seed=7 + q) for q in range(3)]).to(dev)
+eager = {s: [t.clone() for t in pipe.query_sharded(tok, 75, seed=300 + s, k=100)] for s in (1, 2, 3)}
+cqs = [pipe.capture_query_sharded(tok.shape, 75, seed=300, k=100) for _ in range(2)]
+streams = [torch.cuda.Stream(dev) for _ in cqs]
+for c in cqs:
+    c.tokens.copy_(tok)
+cqs[1].counter.fill_(1)          # instance 0 plays seeds 301, 302; instance 1 plays 302, 303
+torch.cuda.synchronize()
+for rnd in range(2):
+    for c, s in zip(cqs, streams):
+        with torch.cuda.stream(s):
+            c.replay()
+    torch.cuda.synchronize()
+    for j, c in enumerate(cqs):
+        want = eager[1 + rnd + j]
+        assert torch.equal(c.idx, want[2]) and torch.equal(c.poses, want[0]), (rnd, j)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+"""
+
+
+def test_captured_segments_with_a_real_rccl_group():
+    """World size 1 over the nccl (= RCCL) backend: the collectives between the captured segments are real RCCL calls."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1, ROOT, str(port)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
