@@ -356,7 +356,7 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     const int C = d->feature_c, Fe = d->fea, IF = d->img_fea;
     IFF_REQUIRE(C >= 16 && C % 16 == 0 && Fe >= 16 && Fe % 16 == 0 && IF >= 1, "iff_idnet_create: widths %d/%d/%d unsupported", C, Fe, IF);
     IFF_REQUIRE(C % 32 == 0 && Fe % 32 == 0, "iff_idnet_create: widths must be multiples of 32 (got %d, %d)", C, Fe);
-    IFF_REQUIRE(d->gemm_mode == 0 || d->gemm_mode == 1, "iff_idnet_create: gemm_mode must be 0 (fp32 MFMA) or 1 (3xBF16)");
+    IFF_REQUIRE(d->gemm_mode >= 0 && d->gemm_mode <= 2, "iff_idnet_create: gemm_mode must be 0 (fp32 MFMA), 1 (3xBF16) or 2 (3xBF16, one launch per layer)");
     const int KQ = (IF + 15) / 16 * 16;
     const int XW = 160;                  // encoder input 141 padded to a multiple of 32 (identify_kernels.hip)
     iff_idnet* n = new iff_idnet();
@@ -371,6 +371,8 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
            o_pk = take_planes(Fe, Fe);
     const int QLD = C + 16;
     size_t o_wqf = take((size_t)KQ * QLD), o_bqf = take(QLD);
+    const bool fused = (C == 256);
+    size_t o_f1 = fused ? take_planes(C, XW) : 0, o_f2 = fused ? take_planes(C, C) : 0, o_f3 = fused ? take_planes(C, C + XW) : 0;
     n->slab_bytes = off;
     hipError_t e = hipMalloc(&n->slab, off);
     if (e != hipSuccess) { delete n; return hip_fail(e, "hipMalloc(idnet weights)"); }
@@ -401,8 +403,17 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     v.w3 = (const float*)(b + o_w3); v.b3 = (const float*)(b + o_b3); v.w4 = (const float*)(b + o_w4); v.b4 = (const float*)(b + o_b4);
     v.wk = (const float*)(b + o_wk); v.bk = (const float*)(b + o_bk); v.wq = (const float*)(b + o_wq); v.bq = (const float*)(b + o_bq);
     v.p1 = b + o_p1; v.p2 = b + o_p2; v.p3 = b + o_p3; v.p4 = b + o_p4; v.pk = b + o_pk;
-    v.gemm_mode = d->gemm_mode;
+    v.gemm_mode = d->gemm_mode == 0 ? 0 : 1;
     v.feature_c = C; v.fea = Fe; v.img_fea = IF;
+    v.f1 = v.f2 = v.f3 = nullptr;
+    v.fused_trunk = 0;
+    if (fused) {
+        IFF_NET_HIP(launch_frag_order(b + o_p1, b + o_f1, XW, s));
+        IFF_NET_HIP(launch_frag_order(b + o_p2, b + o_f2, C, s));
+        IFF_NET_HIP(launch_frag_order(b + o_p3, b + o_f3, C + XW, s));
+        v.f1 = b + o_f1; v.f2 = b + o_f2; v.f3 = b + o_f3;
+        v.fused_trunk = d->gemm_mode == 1 ? 1 : 0;
+    }
     IFF_NET_HIP(hipStreamSynchronize(s));
     {
         std::vector<float> W4((size_t)Fe * C), b4(Fe), Wk((size_t)Fe * Fe), bk(Fe), Wq((size_t)Fe * IF), bq(Fe), wqf, bqf;

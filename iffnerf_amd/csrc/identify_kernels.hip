@@ -404,6 +404,240 @@ static hipError_t gemm_bf3(const float* A1, int lda1, int K1, const float* A2, i
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ fused encoder trunk
+// The three ReLU layers of the ray encoder (ray_preprocessor.py:9-22,30-38) in ONE launch for feature_c = 256:
+//   h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2), h3 = relu(W3 [h2 | x] + b3)
+// A workgroup owns 64 rays; wave w owns output features 64w..64w+63 of every layer.  Activations never leave the CU:
+// they sit in LDS as three bf16 planes [plane][ray][feature] (the 3xBF16 split above) and are the MFMA's B operand
+// (k = feature, column = ray); the weights are the A operand, read straight from L2 in "fragment order" (each
+// wave-instruction one contiguous KiB, prepared once by k_frag_order) -- every wave needs different output rows, so
+// staging them through LDS would buy no reuse.  The products come out transposed (rows = features, columns = rays):
+// a lane holds 4 consecutive features of one ray per register quad, so the next layer's planes are written with 8-byte
+// LDS stores and h3 with 16-byte global stores.  The x-part of layer 3 is accumulated together with layer 1 (both read
+// x), which lets h1/h2 reuse x's LDS: 99 KiB, one workgroup (4 waves) per CU, two barriers per layer boundary and none
+// inside the k loops.  Per launch at 16 011 rays: 251 workgroups, 52 k-steps x 24 MFMA per wave.
+constexpr int TR = 64;            // rays per workgroup
+constexpr int SLD = 264;          // bf16 per LDS row: 256 + 8 -> 528 B, an odd multiple of 16 B (conflict-free 16-B reads)
+constexpr int TC = 256;           // feature_c this kernel is built for
+
+// nn.Linear planes Wp [3][256][Kp] -> fragment order Wf[ks][p][nb][lane][8]: lane l of the (nb, ks) fragment holds
+// W[32 nb + (l & 31)][16 ks + 8 (l >> 5) + 0..7], the 32x32x16 A-operand map
+__global__ void k_frag_order(const __bf16* __restrict__ Wp, __bf16* __restrict__ Wf, int Kp) {
+    const int nks = Kp / 16;
+    const int64_t n = (int64_t)nks * 3 * 8 * 64 * 8;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        int i = (int)(t & 7), lane = (int)((t >> 3) & 63), nb = (int)((t >> 9) & 7);
+        int64_t rest = t >> 12;
+        int pl = (int)(rest % 3), ks = (int)(rest / 3);
+        int row = nb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + i;
+        Wf[t] = Wp[((size_t)pl * TC + row) * Kp + k];
+    }
+}
+hipError_t launch_frag_order(const void* Wp, void* Wf, int Kp, hipStream_t s) {
+    int64_t n = (int64_t)(Kp / 16) * 3 * 8 * 64 * 8;
+    hipLaunchKernelGGL(k_frag_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const __bf16*)Wp, (__bf16*)Wf, Kp);
+    return hipGetLastError();
+}
+
+// encoder input as three bf16 planes [3][N][XW] (same values as k5_ray_input, split once here instead of per GEMM tile)
+__global__ void k5_ray_input_planes(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ c,
+                                    int64_t N, __bf16* __restrict__ xp) {
+    const int64_t tot = N * XW;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t / XW;
+        int col = (int)(t - r * XW);
+        float v = 0.0f;
+        if (col < 3) v = o[3 * r + col];
+        else if (col < 6) v = d[3 * r + col - 3];
+        else if (col < 9) v = c[3 * r + col - 6];
+        else if (col < 141) {
+            int b = col - 9;
+            const float* src;
+            int F;
+            if (b < 48) { src = o; F = 8; }
+            else if (b < 96) { src = d; F = 8; b -= 48; }
+            else { src = c; F = 6; b -= 96; }
+            int half = F * 3;
+            bool is_cos = b >= half;
+            if (is_cos) b -= half;
+            int j = b / F, k = b - j * F;
+            float arg = src[3 * r + j] * (float)(1 << k);
+            v = is_cos ? cosf(arg) : sinf(arg);
+        }
+        __bf16 h0 = (__bf16)v;
+        float r1 = v - (float)h0;
+        __bf16 h1 = (__bf16)r1;
+        float r2 = r1 - (float)h1;
+        xp[t] = h0; xp[tot + t] = h1; xp[2 * tot + t] = (__bf16)r2;
+    }
+}
+
+struct WFrag { bf16x8 p[2][3]; };      // [feature group][plane]
+
+__device__ inline void trunk_load_w(WFrag& w, const uint4* __restrict__ Wf, int ks, int wave, int lane) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int fg = 0; fg < 2; ++fg) {
+            uint4 v = Wf[(((size_t)ks * 3 + pl) * 8 + 2 * wave + fg) * 64 + lane];
+            w.p[fg][pl] = *reinterpret_cast<bf16x8*>(&v);
+        }
+}
+
+// acc[fg][rg] += W(fg) * act(rg) over one 16-wide k-step, six bf16 products per tile, smallest contributions first
+__device__ inline void trunk_mfma(f32x16 (&acc)[2][2], const WFrag& w, const bf16x8 (&a)[2][3]) {
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg)
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[fg][2], a[rg][0], acc[fg][rg], 0, 0, 0);
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[fg][0], a[rg][2], acc[fg][rg], 0, 0, 0);
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[fg][1], a[rg][1], acc[fg][rg], 0, 0, 0);
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[fg][1], a[rg][0], acc[fg][rg], 0, 0, 0);
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[fg][0], a[rg][1], acc[fg][rg], 0, 0, 0);
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[fg][0], a[rg][0], acc[fg][rg], 0, 0, 0);
+        }
+}
+
+__global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, int64_t N, const uint4* __restrict__ Wf1,
+                                                const uint4* __restrict__ Wf2, const uint4* __restrict__ Wf3,
+                                                const float* __restrict__ b1, const float* __restrict__ b2,
+                                                const float* __restrict__ b3, float* __restrict__ h3) {
+    __shared__ __attribute__((aligned(16))) __bf16 S[3][TR][SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * TR;
+
+    // x planes -> LDS (rows beyond N are zero): 3 planes x 64 rays x 20 sixteen-byte chunks
+    for (int cix = tid; cix < 3 * TR * (XW / 8); cix += 256) {
+        int pl = cix / (TR * (XW / 8)), rem = cix - pl * (TR * (XW / 8));
+        int ray = rem / (XW / 8), ch = rem - ray * (XW / 8);
+        int64_t gr = row0 + ray;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gr < N) v = *reinterpret_cast<const uint4*>(xp + ((size_t)pl * N + gr) * XW + ch * 8);
+        *reinterpret_cast<uint4*>(&S[pl][ray][ch * 8]) = v;
+    }
+    __syncthreads();
+
+    auto load_act = [&](bf16x8 (&a)[2][3], int ks) {
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[rg][pl] = *reinterpret_cast<const bf16x8*>(&S[pl][32 * rg + lr][16 * ks + 8 * lh]);
+    };
+    // relu(acc + bias) -> three bf16 planes of this wave's 64 features for all 64 rays
+    auto write_planes = [&](const f32x16 (&acc)[2][2], const float* __restrict__ bias) {
+#pragma unroll
+        for (int fg = 0; fg < 2; ++fg)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 64 * wave + 32 * fg + 8 * q + 4 * lh;          // features f0..f0+3 <- registers 4q..4q+3
+                const float4 bv = *reinterpret_cast<const float4*>(bias + f0);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    bf16x4 p0, p1, p2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = fmaxf(acc[fg][rg][4 * q + i] + bb[i], 0.0f);
+                        __bf16 h0 = (__bf16)v;
+                        float r1 = v - (float)h0;
+                        __bf16 h1 = (__bf16)r1;
+                        float r2 = r1 - (float)h1;
+                        p0[i] = h0; p1[i] = h1; p2[i] = (__bf16)r2;
+                    }
+                    *reinterpret_cast<bf16x4*>(&S[0][32 * rg + lr][f0]) = p0;
+                    *reinterpret_cast<bf16x4*>(&S[1][32 * rg + lr][f0]) = p1;
+                    *reinterpret_cast<bf16x4*>(&S[2][32 * rg + lr][f0]) = p2;
+                }
+            }
+    };
+    auto zero = [](f32x16 (&acc)[2][2]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    };
+
+    f32x16 acc[2][2], acc3[2][2];
+    zero(acc); zero(acc3);
+    bf16x8 act[2][3];
+    WFrag wa, wb, wc, wd;
+
+    // layer 1 and the x-part of layer 3 (weight columns 256..415 = k-steps 16..25 of Wf3), one pass over x
+    constexpr int KX = XW / 16, KH = TC / 16;
+    trunk_load_w(wa, Wf1, 0, wave, lane);
+    trunk_load_w(wb, Wf3, KH, wave, lane);
+#pragma unroll 1
+    for (int ks = 0; ks < KX; ks += 2) {
+        trunk_load_w(wc, Wf1, ks + 1, wave, lane);
+        trunk_load_w(wd, Wf3, KH + ks + 1, wave, lane);
+        load_act(act, ks);
+        trunk_mfma(acc, wa, act);
+        trunk_mfma(acc3, wb, act);
+        if (ks + 2 < KX) {
+            trunk_load_w(wa, Wf1, ks + 2, wave, lane);
+            trunk_load_w(wb, Wf3, KH + ks + 2, wave, lane);
+        }
+        load_act(act, ks + 1);
+        trunk_mfma(acc, wc, act);
+        trunk_mfma(acc3, wd, act);
+    }
+    __syncthreads();                      // every wave has finished reading x
+    write_planes(acc, b1);
+    __syncthreads();
+
+    // layer 2
+    zero(acc);
+    trunk_load_w(wa, Wf2, 0, wave, lane);
+#pragma unroll 1
+    for (int ks = 0; ks < KH; ks += 2) {
+        trunk_load_w(wc, Wf2, ks + 1, wave, lane);
+        load_act(act, ks);
+        trunk_mfma(acc, wa, act);
+        if (ks + 2 < KH) trunk_load_w(wa, Wf2, ks + 2, wave, lane);
+        load_act(act, ks + 1);
+        trunk_mfma(acc, wc, act);
+    }
+    __syncthreads();
+    write_planes(acc, b2);
+    __syncthreads();
+
+    // layer 3, h-part (k-steps 0..15 of Wf3), on top of the x-part
+    trunk_load_w(wa, Wf3, 0, wave, lane);
+#pragma unroll 1
+    for (int ks = 0; ks < KH; ks += 2) {
+        trunk_load_w(wc, Wf3, ks + 1, wave, lane);
+        load_act(act, ks);
+        trunk_mfma(acc3, wa, act);
+        if (ks + 2 < KH) trunk_load_w(wa, Wf3, ks + 2, wave, lane);
+        load_act(act, ks + 1);
+        trunk_mfma(acc3, wc, act);
+    }
+    // h3 = relu(. + b3): lane holds 4 consecutive features of ray (32 rg + lr) per register quad -> 16-byte stores
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 64 * wave + 32 * fg + 8 * q + 4 * lh;
+            const float4 bv = *reinterpret_cast<const float4*>(b3 + f0);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                int64_t gr = row0 + 32 * rg + lr;
+                if (gr < N) {
+                    float4 o4;
+                    o4.x = fmaxf(acc3[fg][rg][4 * q + 0] + bv.x, 0.0f);
+                    o4.y = fmaxf(acc3[fg][rg][4 * q + 1] + bv.y, 0.0f);
+                    o4.z = fmaxf(acc3[fg][rg][4 * q + 2] + bv.z, 0.0f);
+                    o4.w = fmaxf(acc3[fg][rg][4 * q + 3] + bv.w, 0.0f);
+                    *reinterpret_cast<float4*>(h3 + gr * TC + f0) = o4;
+                }
+            }
+        }
+}
+
 size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N) {
     // x [N,XW] + two ping-pong activations [N, max(feature_c, fea)]
     int wide = n.feature_c > n.fea ? n.feature_c : n.fea;
@@ -420,6 +654,16 @@ static hipError_t trunk(const IdNetDev& n, const float* o, const float* d, const
     const int C = n.feature_c;
     int64_t tot = N * XW;
     int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
+    if (n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk) {
+        // x planes (3 x N x 160 bf16 = 960 B per ray) fit in the fp32 x slot + h1 of the workspace
+        __bf16* xp = (__bf16*)x;
+        hipLaunchKernelGGL(k5_ray_input_planes, dim3(grid), dim3(256), 0, s, o, d, rgb, N, xp);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+        hipLaunchKernelGGL(k5_trunk, dim3((unsigned)((N + TR - 1) / TR)), dim3(256), 0, s, xp, N, (const uint4*)n.f1,
+                           (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, h3);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k5_ray_input, dim3(grid), dim3(256), 0, s, o, d, rgb, N, x);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -48,6 +48,9 @@ struct IdNetDev {
     // q_proj, k_proj and mlp2.2 folded into one token-side Linear (api.hip: fold_heads): wqf [KQ][qf_ld] k-major,
     // bqf [qf_ld]; columns 0..C-1 give the folded query, column C the per-token constant, the rest are zero
     const float* wqf; const float* bqf; int qf_ld;
+    // layers 1-3 in the fragment order of the fused trunk kernel (k5_trunk; only when feature_c == 256), else null
+    const void* f1; const void* f2; const void* f3;
+    int fused_trunk;                    // 1: one launch for the three ReLU layers; 0: one 3xBF16 GEMM launch per layer
     int gemm_mode;                      // 0: fp32-input MFMA (k-ordered fmaf chain), 1: 3xBF16 split on the bf16 MFMA
     int feature_c, fea, img_fea;
 };
@@ -66,6 +69,7 @@ hipError_t launch_transpose_pad(const float* w_out_in, float* dst_in_out, int ou
                                 hipStream_t s);
 hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, int D, float divisor, float* logits,
                               float* row_max, float* row_sumexp, int gemm_mode, hipStream_t s);
+hipError_t launch_frag_order(const void* Wp, void* Wf, int Kp, hipStream_t s);
 hipError_t launch_split_rows(const float* w, void* planes, int out_f, int in_f, int in_pad, hipStream_t s);
 hipError_t launch_attn_colsum(float* logits, int Q, int M, int64_t N, const float* row_max, const float* row_sumexp,
                               int write_attention, float* score, hipStream_t s);

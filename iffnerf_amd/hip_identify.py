@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import check, dptr, fvec, stream_ptr
 
-GEMM_F32, GEMM_BF16X3 = 0, 1        # include/iffnerf_hip.h IFF_GEMM_*
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_LAYERED = 0, 1, 2        # include/iffnerf_hip.h IFF_GEMM_*
 
 _KEYS = (("l1", "ray_preprocessor.mlp.0"), ("l2", "ray_preprocessor.mlp.2"), ("l3", "ray_preprocessor.mlp2.0"),
          ("l4", "ray_preprocessor.mlp2.2"), ("q", "attention.q_proj"), ("k", "attention.k_proj"))
@@ -154,7 +154,7 @@ def attn_logits(q: torch.Tensor, k: torch.Tensor, want_stats: bool = True, gemm_
     rsum = q.new_empty(M) if want_stats else None
     with torch.cuda.device(q.device):
         check(_lib.lib().iff_attn_logits(dptr(q), dptr(k), M, N, D, float(math.sqrt(D)), dptr(logits), dptr(rmax), dptr(rsum),
-                                         int(gemm_mode), stream_ptr(q.device)), "iff_attn_logits")
+                                         min(int(gemm_mode), 1), stream_ptr(q.device)), "iff_attn_logits")
     return logits, rmax, rsum
 
 

@@ -40,9 +40,12 @@ extern "C" {
 /* matrix-product arithmetic of the ray encoder / attention logits (both keep fp32 accuracy):
  *   F32     v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fmaf chain
  *   BF16X3  every fp32 operand split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product block, fp32 accumulation;
- *           dropped terms < 2^-25 relative -- the error class of an fp32 re-association, at ~2.7x the throughput */
+ *           dropped terms < 2^-25 relative -- the error class of an fp32 re-association, at ~2.7x the throughput
+ *   BF16X3_LAYERED  the same arithmetic with one launch per encoder layer (BF16X3 runs the three ReLU layers of a
+ *           256-wide encoder as one launch with the activations kept in LDS; other widths always run layered) */
 #define IFF_GEMM_F32    0
 #define IFF_GEMM_BF16X3 1
+#define IFF_GEMM_BF16X3_LAYERED 2
 
 #define IFF_ISOCELL_DIRS 27         /* pose_estimation/sampling.py:229-234, isocell.py:6-68 (27 targets, N0=3) */
 #define IFF_RAY_FEATURES 384        /* DINOv2 ViT-S/14 width: pose_estimation/backbone.py:12-14 */
@@ -165,7 +168,7 @@ typedef struct iff_idnet_desc {
     int32_t feature_c;              /* 256 (identification_module.py:66-68) */
     int32_t fea;                    /* 384 */
     int32_t img_fea;                /* 398 = 384 + 14 */
-    int32_t gemm_mode;              /* IFF_GEMM_F32: fp32-input MFMA; IFF_GEMM_BF16X3: 3xBF16 split on the bf16 MFMA */
+    int32_t gemm_mode;              /* IFF_GEMM_* */
     const float* l1_w; const float* l1_b;   /* ray_preprocessor.mlp.0   [feature_c,141] */
     const float* l2_w; const float* l2_b;   /* ray_preprocessor.mlp.2   [feature_c,feature_c] */
     const float* l3_w; const float* l3_b;   /* ray_preprocessor.mlp2.0  [feature_c,feature_c+141] */

@@ -156,7 +156,7 @@ def test_gemm_modes_agree(golden, dev):
     tok = synthetic.make_tokens(256, 384, seed=int(g["tokens_seed"])).to(dev)
     tops = []
     feats = []
-    for mode in (H.GEMM_F32, H.GEMM_BF16X3):
+    for mode in (H.GEMM_F32, H.GEMM_BF16X3_LAYERED, H.GEMM_BF16X3):
         net = H.IdNetHandle(w, dev, gemm_mode=mode)
         feat, k = net.ray_encode(o, d, c, want_features=True, want_k=True)
         close(feat[:64], g["ray_feat_tile"], 2e-5, 1e-5, f"ray features, mode {mode}")
@@ -167,7 +167,30 @@ def test_gemm_modes_agree(golden, dev):
         assert idx.cpu().tolist() == g["m256_top_idx"].tolist(), f"top-100, mode {mode}"
         feats.append(feat)
         tops.append(logits)
-    assert float((feats[0] - feats[1]).abs().max()) < 5e-6
+    assert float((feats[0] - feats[1]).abs().max()) < 5e-6 and float((feats[0] - feats[2]).abs().max()) < 5e-6
+
+
+def test_fused_trunk_matches_layered(golden, dev):
+    """k5_trunk (three layers, one launch, activations in LDS) vs one 3xBF16 GEMM launch per layer and vs the fp32 MFMA chain:
+    same h3 to fp32 rounding, including a ragged last 64-ray tile and N < 64."""
+    from iffnerf_amd import hip_identify as H
+    from oracle import identify as oid
+    w = synthetic.make_id_weights(seed=99)
+    o, d, c = (golden.t("g6_identify", k).to(dev) for k in ("ori", "dirs", "rgb"))
+    nets = {m: H.IdNetHandle(w, dev, gemm_mode=m) for m in (H.GEMM_F32, H.GEMM_BF16X3_LAYERED, H.GEMM_BF16X3)}
+    x = oid.ray_input(o.cpu().double(), d.cpu().double(), c.cpu().double())
+    w64 = {k: v.double() for k, v in w.items()}
+    h = torch.relu(torch.nn.functional.linear(x, w64["ray_preprocessor.mlp.0.weight"], w64["ray_preprocessor.mlp.0.bias"]))
+    h = torch.relu(torch.nn.functional.linear(h, w64["ray_preprocessor.mlp.2.weight"], w64["ray_preprocessor.mlp.2.bias"]))
+    truth = torch.relu(torch.nn.functional.linear(torch.cat((h, x), -1), w64["ray_preprocessor.mlp2.0.weight"],
+                                                  w64["ray_preprocessor.mlp2.0.bias"]))
+    for n in (o.shape[0], 1999, 64, 37, 1):
+        got = {m: net.ray_trunk(o[:n], d[:n], c[:n]) for m, net in nets.items()}
+        for m, t in got.items():
+            assert t.shape == (n, 256)
+            err = float((t.cpu().double() - truth[:n]).abs().max())
+            assert err < 2e-5, (m, n, err)
+        assert float((got[H.GEMM_BF16X3] - got[H.GEMM_BF16X3_LAYERED]).abs().max()) < 5e-6
 
 
 def test_folded_heads(golden, net, dev):
