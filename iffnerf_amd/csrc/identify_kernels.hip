@@ -5,6 +5,7 @@
 #include "iff_device.h"
 #include "iff_launch.h"
 #include "iff_select.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -508,14 +509,28 @@ __global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, i
     const int lr = lane & 31, lh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * TR;
 
-    // x planes -> LDS (rows beyond N are zero): 3 planes x 64 rays x 20 sixteen-byte chunks
-    for (int cix = tid; cix < 3 * TR * (XW / 8); cix += 256) {
-        int pl = cix / (TR * (XW / 8)), rem = cix - pl * (TR * (XW / 8));
-        int ray = rem / (XW / 8), ch = rem - ray * (XW / 8);
-        int64_t gr = row0 + ray;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gr < N) v = *reinterpret_cast<const uint4*>(xp + ((size_t)pl * N + gr) * XW + ch * 8);
-        *reinterpret_cast<uint4*>(&S[pl][ray][ch * 8]) = v;
+    // x planes -> LDS (rows beyond N are zero): 3 planes x 64 rays x 20 sixteen-byte chunks = 15 per thread, all
+    // requested before the first is stored (a rolled loop would pay the memory latency 15 times over)
+    {
+        constexpr int CH = XW / 8, PER = 3 * TR * CH / 256;
+        static_assert(3 * TR * CH % 256 == 0, "x tile must divide over the workgroup");
+        uint4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            int cix = tid + 256 * u;
+            int pl = cix / (TR * CH), rem = cix - pl * (TR * CH);
+            int ray = rem / CH, ch = rem - ray * CH;
+            int64_t gr = row0 + ray;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (gr < N) v[u] = *reinterpret_cast<const uint4*>(xp + ((size_t)pl * N + gr) * XW + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            int cix = tid + 256 * u;
+            int pl = cix / (TR * CH), rem = cix - pl * (TR * CH);
+            int ray = rem / CH, ch = rem - ray * CH;
+            *reinterpret_cast<uint4*>(&S[pl][ray][ch * 8]) = v[u];
+        }
     }
     __syncthreads();
 
@@ -563,60 +578,61 @@ __global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, i
 
     f32x16 acc[2][2], acc3[2][2];
     zero(acc); zero(acc3);
-    bf16x8 act[2][3];
-    WFrag wa, wb, wc, wd;
+    constexpr int KX = XW / 16, KH = TC / 16;
+
+    // One k loop, software-pipelined in registers: the weight fragments of k-step ks + DEPTH - 1 are requested before
+    // k-step ks is multiplied (an L2 hit under load takes longer than one k-step's 24 MFMAs).  DUAL: two weight streams
+    // over the same activations (layer 1 and the x-part of layer 3).
+    auto phase = [&](auto nk_c, auto depth_c, auto dual_c, f32x16 (&accA)[2][2], const uint4* __restrict__ WA, int ksA,
+                     f32x16 (&accB)[2][2], const uint4* __restrict__ WB, int ksB) {
+        constexpr int NK = decltype(nk_c)::value, DEPTH = decltype(depth_c)::value;
+        constexpr bool DUAL = decltype(dual_c)::value;
+        WFrag wa[DEPTH], wb[DUAL ? DEPTH : 1];
+        bf16x8 act[2][2][3];                   // activations one k-step ahead as well (LDS latency)
+        load_act(act[0], 0);
+#pragma unroll
+        for (int i = 0; i < DEPTH - 1; ++i) {
+            if (i < NK) {
+                trunk_load_w(wa[i], WA, ksA + i, wave, lane);
+                if (DUAL) trunk_load_w(wb[i], WB, ksB + i, wave, lane);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            if (ks + DEPTH - 1 < NK) {
+                trunk_load_w(wa[(ks + DEPTH - 1) % DEPTH], WA, ksA + ks + DEPTH - 1, wave, lane);
+                if (DUAL) trunk_load_w(wb[(ks + DEPTH - 1) % DEPTH], WB, ksB + ks + DEPTH - 1, wave, lane);
+            }
+            if (ks + 1 < NK) load_act(act[(ks + 1) & 1], ks + 1);
+            __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them)
+            trunk_mfma(accA, wa[ks % DEPTH], act[ks & 1]);
+            if (DUAL) trunk_mfma(accB, wb[ks % DEPTH], act[ks & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using std::integral_constant;
 
     // layer 1 and the x-part of layer 3 (weight columns 256..415 = k-steps 16..25 of Wf3), one pass over x
-    constexpr int KX = XW / 16, KH = TC / 16;
-    trunk_load_w(wa, Wf1, 0, wave, lane);
-    trunk_load_w(wb, Wf3, KH, wave, lane);
-#pragma unroll 1
-    for (int ks = 0; ks < KX; ks += 2) {
-        trunk_load_w(wc, Wf1, ks + 1, wave, lane);
-        trunk_load_w(wd, Wf3, KH + ks + 1, wave, lane);
-        load_act(act, ks);
-        trunk_mfma(acc, wa, act);
-        trunk_mfma(acc3, wb, act);
-        if (ks + 2 < KX) {
-            trunk_load_w(wa, Wf1, ks + 2, wave, lane);
-            trunk_load_w(wb, Wf3, KH + ks + 2, wave, lane);
-        }
-        load_act(act, ks + 1);
-        trunk_mfma(acc, wc, act);
-        trunk_mfma(acc3, wd, act);
-    }
+    phase(integral_constant<int, KX>{}, integral_constant<int, 3>{}, integral_constant<bool, true>{}, acc, Wf1, 0, acc3, Wf3, KH);
     __syncthreads();                      // every wave has finished reading x
     write_planes(acc, b1);
     __syncthreads();
 
     // layer 2
     zero(acc);
-    trunk_load_w(wa, Wf2, 0, wave, lane);
-#pragma unroll 1
-    for (int ks = 0; ks < KH; ks += 2) {
-        trunk_load_w(wc, Wf2, ks + 1, wave, lane);
-        load_act(act, ks);
-        trunk_mfma(acc, wa, act);
-        if (ks + 2 < KH) trunk_load_w(wa, Wf2, ks + 2, wave, lane);
-        load_act(act, ks + 1);
-        trunk_mfma(acc, wc, act);
-    }
+    phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, integral_constant<bool, false>{}, acc, Wf2, 0, acc, Wf2, 0);
     __syncthreads();
     write_planes(acc, b2);
     __syncthreads();
 
     // layer 3, h-part (k-steps 0..15 of Wf3), on top of the x-part
-    trunk_load_w(wa, Wf3, 0, wave, lane);
-#pragma unroll 1
-    for (int ks = 0; ks < KH; ks += 2) {
-        trunk_load_w(wc, Wf3, ks + 1, wave, lane);
-        load_act(act, ks);
-        trunk_mfma(acc3, wa, act);
-        if (ks + 2 < KH) trunk_load_w(wa, Wf3, ks + 2, wave, lane);
-        load_act(act, ks + 1);
-        trunk_mfma(acc3, wc, act);
-    }
-    // h3 = relu(. + b3): lane holds 4 consecutive features of ray (32 rg + lr) per register quad -> 16-byte stores
+    phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, integral_constant<bool, false>{}, acc3, Wf3, 0, acc3, Wf3, 0);
+    // h3 = relu(. + b3).  A lane holds 4 consecutive features of one ray per register quad; the tile is transposed
+    // through LDS (fp32 [ray][260]) so that every global store instruction writes one whole 1-KiB row of h3.
+    __syncthreads();                      // every wave has finished reading h2
+    constexpr int OLD = TC + 4;           // 1040-B rows: an odd multiple of 16 B
+    float* O = reinterpret_cast<float*>(&S[0][0][0]);
+    static_assert(TR * OLD * 4 <= 3 * TR * SLD * 2, "output tile must fit in the activation planes");
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg)
 #pragma unroll
@@ -625,17 +641,21 @@ __global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, i
             const float4 bv = *reinterpret_cast<const float4*>(b3 + f0);
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
-                int64_t gr = row0 + 32 * rg + lr;
-                if (gr < N) {
-                    float4 o4;
-                    o4.x = fmaxf(acc3[fg][rg][4 * q + 0] + bv.x, 0.0f);
-                    o4.y = fmaxf(acc3[fg][rg][4 * q + 1] + bv.y, 0.0f);
-                    o4.z = fmaxf(acc3[fg][rg][4 * q + 2] + bv.z, 0.0f);
-                    o4.w = fmaxf(acc3[fg][rg][4 * q + 3] + bv.w, 0.0f);
-                    *reinterpret_cast<float4*>(h3 + gr * TC + f0) = o4;
-                }
+                float4 o4;
+                o4.x = fmaxf(acc3[fg][rg][4 * q + 0] + bv.x, 0.0f);
+                o4.y = fmaxf(acc3[fg][rg][4 * q + 1] + bv.y, 0.0f);
+                o4.z = fmaxf(acc3[fg][rg][4 * q + 2] + bv.z, 0.0f);
+                o4.w = fmaxf(acc3[fg][rg][4 * q + 3] + bv.w, 0.0f);
+                *reinterpret_cast<float4*>(&O[(32 * rg + lr) * OLD + f0]) = o4;
             }
         }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TR / 4; ++i) {
+        const int ray = wave * (TR / 4) + i;
+        const int64_t gr = row0 + ray;
+        if (gr < N) *reinterpret_cast<float4*>(h3 + gr * TC + 4 * lane) = *reinterpret_cast<const float4*>(&O[ray * OLD + 4 * lane]);
+    }
 }
 
 size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N) {
