@@ -158,7 +158,7 @@ def main():
         # ---- per-stage and dominant-kernel timing with events on the launch stream (outside the timed region)
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
         n_rep = 20
-        stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "ray_encoder": 0.0, "attention_topk_pose": 0.0}
+        stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "encoder_logits": 0.0, "score_topk_pose": 0.0}
         march_launch_ms = [0.0, 0.0, 0.0]      # K4a density+compositing, K4b appearance gather, K4c Ref shading
         bytes_a = bytes_b = 0.0
         from iffnerf_amd import hip_identify as H
@@ -173,10 +173,9 @@ def main():
             e[2].record()
             rgb = pipe.field.march(rays, 0, 20, want_alpha=False)[0]
             e[3].record()
-            h3 = pipe.idnet.ray_trunk(ori, dirs, rgb)          # the folded path PosePipeline.logits runs (fold_heads=True)
+            logits, rmax, rsum = pipe.logits(tokens[0], ori, dirs, rgb)     # q_fold + ray_input + fused trunk/logits + stats merge
             e[4].record()
-            logits, rmax, rsum = pipe.idnet.attn_logits_folded(pipe.idnet.q_fold(tokens[0]), h3)
-            score = H.attn_colsum(logits, rmax, rsum, write_attention=True)
+            score = H.attn_colsum(logits, rmax, rsum, write_attention=False)
             idx, val = H.topk(score, TOPK)
             H.pose_from_topk(idx, val, ori, dirs, pipe.model_up)
             e[5].record()

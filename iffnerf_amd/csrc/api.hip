@@ -481,6 +481,25 @@ extern "C" int iff_attn_logits_folded(const iff_idnet* n, const float* qf, const
     return 0;
 }
 
+extern "C" size_t iff_ray_logits_folded_workspace(const iff_idnet* n, int64_t N, int32_t M) {
+    return (n && N > 0 && M > 0) ? ray_logits_workspace_bytes(n->dev, N, M) : 0;
+}
+
+extern "C" int iff_ray_logits_folded(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf,
+                                     int32_t M, float divisor, float* logits, float* row_max, float* row_sumexp, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(n && N >= 0 && M >= 0, "iff_ray_logits_folded: bad argument");
+    if (N == 0 || M == 0) return 0;
+    IFF_REQUIRE(o && d && rgb && qf && logits && workspace, "iff_ray_logits_folded: null buffer");
+    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_ray_logits_folded: pass both row statistics or neither");
+    if (workspace_bytes < ray_logits_workspace_bytes(n->dev, N, M))
+        return fail(IFF_ERR_WORKSPACE, "iff_ray_logits_folded: workspace %zu < %zu bytes", workspace_bytes,
+                    ray_logits_workspace_bytes(n->dev, N, M));
+    IFF_HIP(launch_ray_logits_folded(n->dev, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes,
+                                     (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int iff_k_proj(const iff_idnet* n, const float* ray_features, int64_t N, float* k_out, void* stream) {
     IFF_REQUIRE(n && N >= 0, "iff_k_proj: bad argument");
     if (N == 0) return 0;

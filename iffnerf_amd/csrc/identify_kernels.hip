@@ -500,10 +500,79 @@ __device__ inline void trunk_mfma(f32x16 (&acc)[2][2], const WFrag& w, const bf1
         }
 }
 
+// acc[tg][rg] += act(rg) * Q(tg): rows = rays, columns = tokens (the logits tile; operands swapped so that the softmax
+// reduction over rays runs down a lane's registers instead of across lanes)
+__device__ inline void trunk_mfma_t(f32x16 (&acc)[2][2], const WFrag& w, const bf16x8 (&a)[2][3]) {
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rg][0], w.p[tg][2], acc[tg][rg], 0, 0, 0);
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rg][2], w.p[tg][0], acc[tg][rg], 0, 0, 0);
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rg][1], w.p[tg][1], acc[tg][rg], 0, 0, 0);
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rg][0], w.p[tg][1], acc[tg][rg], 0, 0, 0);
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rg][1], w.p[tg][0], acc[tg][rg], 0, 0, 0);
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rg][0], w.p[tg][0], acc[tg][rg], 0, 0, 0);
+        }
+}
+
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // 16-byte store at 4-byte alignment
+
+// folded query rows qf [M][ld] (iff_q_fold) -> three bf16 planes in the fragment order of k5_trunk, one 256-token block
+// after the other: Qf[tb][ks][plane][nb][lane][8], token = 256 tb + 32 nb + (lane & 31), feature = 16 ks + 8 (lane >> 5) + i;
+// tokens beyond M are zero
+__global__ void k_qf_frag(const float* __restrict__ qf, int ld, int M, __bf16* __restrict__ Qf, int n_tb) {
+    const int64_t n = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;           // elements per plane
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        int i = (int)(t & 7), lane = (int)((t >> 3) & 63), nb = (int)((t >> 9) & 7);
+        int rest = (int)(t >> 12);
+        int ks = rest % (TC / 16), tb = rest / (TC / 16);
+        int tok = tb * 256 + nb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + i;
+        float v = tok < M ? qf[(size_t)tok * ld + k] : 0.0f;
+        __bf16 h0 = (__bf16)v;
+        float r1 = v - (float)h0;
+        __bf16 h1 = (__bf16)r1;
+        float r2 = r1 - (float)h1;
+        // destination index of (tb, ks, plane, nb, lane, i)
+        size_t base = ((((size_t)tb * (TC / 16) + ks) * 3) * 8 + nb) * 512 + lane * 8 + i;
+        Qf[base] = h0; Qf[base + 8 * 512] = h1; Qf[base + 16 * 512] = (__bf16)r2;
+    }
+}
+
+// per-token softmax statistics from the per-workgroup partials of k5_trunk<true>: part [n_blk][Mpad][2] = (max, sum exp)
+// over each workgroup's 64 rays -> row_max [M], row_sumexp [M]; one wave per token, fixed merge order
+__global__ void __launch_bounds__(256) k6_merge_stats(const float2* __restrict__ part, int n_blk, int Mpad, int M,
+                                                      float* __restrict__ row_max, float* __restrict__ row_sumexp) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= M) return;
+    float m = -INFINITY, sacc = 0.0f;
+    for (int b = lane; b < n_blk; b += 64) {
+        float2 p = part[(size_t)b * Mpad + t];
+        if (p.x > m) { sacc = sacc * expf(m - p.x); m = p.x; }
+        if (p.x != -INFINITY) sacc += p.y * expf(p.x - m);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(sacc, off, 64);
+        float mm = fmaxf(m, m2);
+        sacc = ((m == -INFINITY) ? 0.0f : sacc * expf(m - mm)) + ((m2 == -INFINITY) ? 0.0f : s2 * expf(m2 - mm));
+        m = mm;
+    }
+    if (lane == 0) { row_max[t] = m; row_sumexp[t] = sacc; }
+}
+
+// LOGITS = false: h3 [N][256] out.  LOGITS = true: h3 stays in LDS and is multiplied with the folded query planes Qf
+// ("layer 4", multihead_attention.py:6-7 folded): logits [M][N] = (qf[:, :256] h3^T + qf[:, 256]) / divisor out, plus
+// this workgroup's softmax partials (max, sum exp over its 64 rays) per token.
+template <bool LOGITS>
 __global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, int64_t N, const uint4* __restrict__ Wf1,
                                                 const uint4* __restrict__ Wf2, const uint4* __restrict__ Wf3,
                                                 const float* __restrict__ b1, const float* __restrict__ b2,
-                                                const float* __restrict__ b3, float* __restrict__ h3) {
+                                                const float* __restrict__ b3, float* __restrict__ h3,
+                                                const uint4* __restrict__ Qf, const float* __restrict__ rowc, int rowc_ld,
+                                                int M, float divisor, float* __restrict__ logits,
+                                                float2* __restrict__ part, int Mpad) {
     __shared__ __attribute__((aligned(16))) __bf16 S[3][TR][SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -583,10 +652,10 @@ __global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, i
     // One k loop, software-pipelined in registers: the weight fragments of k-step ks + DEPTH - 1 are requested before
     // k-step ks is multiplied (an L2 hit under load takes longer than one k-step's 24 MFMAs).  DUAL: two weight streams
     // over the same activations (layer 1 and the x-part of layer 3).
-    auto phase = [&](auto nk_c, auto depth_c, auto dual_c, f32x16 (&accA)[2][2], const uint4* __restrict__ WA, int ksA,
-                     f32x16 (&accB)[2][2], const uint4* __restrict__ WB, int ksB) {
+    auto phase = [&](auto nk_c, auto depth_c, auto dual_c, auto swap_c, f32x16 (&accA)[2][2], const uint4* __restrict__ WA,
+                     int ksA, f32x16 (&accB)[2][2], const uint4* __restrict__ WB, int ksB) {
         constexpr int NK = decltype(nk_c)::value, DEPTH = decltype(depth_c)::value;
-        constexpr bool DUAL = decltype(dual_c)::value;
+        constexpr bool DUAL = decltype(dual_c)::value, SWAP = decltype(swap_c)::value;
         WFrag wa[DEPTH], wb[DUAL ? DEPTH : 1];
         bf16x8 act[2][2][3];                   // activations one k-step ahead as well (LDS latency)
         load_act(act[0], 0);
@@ -605,31 +674,86 @@ __global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, i
             }
             if (ks + 1 < NK) load_act(act[(ks + 1) & 1], ks + 1);
             __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them)
-            trunk_mfma(accA, wa[ks % DEPTH], act[ks & 1]);
+            if (SWAP) trunk_mfma_t(accA, wa[ks % DEPTH], act[ks & 1]);
+            else trunk_mfma(accA, wa[ks % DEPTH], act[ks & 1]);
             if (DUAL) trunk_mfma(accB, wb[ks % DEPTH], act[ks & 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     using std::integral_constant;
+    using no_t = integral_constant<bool, false>;
+    using yes_t = integral_constant<bool, true>;
 
     // layer 1 and the x-part of layer 3 (weight columns 256..415 = k-steps 16..25 of Wf3), one pass over x
-    phase(integral_constant<int, KX>{}, integral_constant<int, 3>{}, integral_constant<bool, true>{}, acc, Wf1, 0, acc3, Wf3, KH);
+    phase(integral_constant<int, KX>{}, integral_constant<int, 3>{}, yes_t{}, no_t{}, acc, Wf1, 0, acc3, Wf3, KH);
     __syncthreads();                      // every wave has finished reading x
     write_planes(acc, b1);
     __syncthreads();
 
     // layer 2
     zero(acc);
-    phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, integral_constant<bool, false>{}, acc, Wf2, 0, acc, Wf2, 0);
+    phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, no_t{}, no_t{}, acc, Wf2, 0, acc, Wf2, 0);
     __syncthreads();
     write_planes(acc, b2);
     __syncthreads();
 
     // layer 3, h-part (k-steps 0..15 of Wf3), on top of the x-part
-    phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, integral_constant<bool, false>{}, acc3, Wf3, 0, acc3, Wf3, 0);
+    phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, no_t{}, no_t{}, acc3, Wf3, 0, acc3, Wf3, 0);
+    __syncthreads();                      // every wave has finished reading h2
+    if (LOGITS) {
+        write_planes(acc3, b3);           // h3 planes
+        __syncthreads();
+        const int n_tb = Mpad / 256;
+        for (int tb = 0; tb < n_tb; ++tb) {
+            zero(acc);
+            phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, no_t{}, yes_t{}, acc, Qf + (size_t)tb * (KH * 3 * 8 * 64), 0,
+                  acc, Qf, 0);
+            // tile: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 64 wave + 32 tg + lr
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                const int tok = tb * 256 + 64 * wave + 32 * tg + lr;
+                const bool tok_ok = tok < M;
+                const float rc = tok_ok ? rowc[(size_t)tok * rowc_ld] : 0.0f;
+                float vmax = -INFINITY;
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t ray = row0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float v = (acc[tg][rg][r] + rc) / divisor;
+                        acc[tg][rg][r] = v;
+                        vmax = fmaxf(vmax, ray < N ? v : -INFINITY);
+                    }
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+                float ssum = 0.0f;
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t ray0 = row0 + 32 * rg + 8 * q + 4 * lh;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ray0 + i < N) ssum += __expf(acc[tg][rg][4 * q + i] - vmax);
+                        if (tok_ok) {
+                            float* dst = logits + (size_t)tok * N + ray0;
+                            if (ray0 + 3 < N) {
+                                f4u o4 = {acc[tg][rg][4 * q], acc[tg][rg][4 * q + 1], acc[tg][rg][4 * q + 2], acc[tg][rg][4 * q + 3]};
+                                *reinterpret_cast<f4u*>(dst) = o4;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (ray0 + i < N) dst[i] = acc[tg][rg][4 * q + i];
+                            }
+                        }
+                    }
+                ssum += __shfl_xor(ssum, 32, 64);
+                if (lh == 0) part[(size_t)blockIdx.x * Mpad + tok] = make_float2(vmax, ssum);
+            }
+        }
+        return;
+    }
     // h3 = relu(. + b3).  A lane holds 4 consecutive features of one ray per register quad; the tile is transposed
     // through LDS (fp32 [ray][260]) so that every global store instruction writes one whole 1-KiB row of h3.
-    __syncthreads();                      // every wave has finished reading h2
     constexpr int OLD = TC + 4;           // 1040-B rows: an odd multiple of 16 B
     float* O = reinterpret_cast<float*>(&S[0][0][0]);
     static_assert(TR * OLD * 4 <= 3 * TR * SLD * 2, "output tile must fit in the activation planes");
@@ -680,8 +804,9 @@ static hipError_t trunk(const IdNetDev& n, const float* o, const float* d, const
         hipLaunchKernelGGL(k5_ray_input_planes, dim3(grid), dim3(256), 0, s, o, d, rgb, N, xp);
         hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return e0;
-        hipLaunchKernelGGL(k5_trunk, dim3((unsigned)((N + TR - 1) / TR)), dim3(256), 0, s, xp, N, (const uint4*)n.f1,
-                           (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, h3);
+        hipLaunchKernelGGL(k5_trunk<false>, dim3((unsigned)((N + TR - 1) / TR)), dim3(256), 0, s, xp, N, (const uint4*)n.f1,
+                           (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, h3, (const uint4*)nullptr,
+                           (const float*)nullptr, 0, 0, 1.0f, (float*)nullptr, (float2*)nullptr, 0);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k5_ray_input, dim3(grid), dim3(256), 0, s, o, d, rgb, N, x);
@@ -867,6 +992,54 @@ hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, 
     if (e != hipSuccess) return e;
     if (row_max && row_sumexp) {
         hipLaunchKernelGGL(k6_row_stats, dim3(M), dim3(256), 0, s, logits, N, row_max, row_sumexp);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+// One call from rays to logits (+ row statistics): ray_input -> trunk -> folded logits.  With feature_c = 256 and the
+// 3xBF16 mode this is k5_ray_input_planes + k5_trunk<true> (h3 never leaves the CU) + k6_merge_stats; otherwise the
+// layered trunk followed by launch_attn_logits_folded.
+static inline size_t up256z(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M) {
+    const size_t n_tb = (size_t)(M + 255) / 256, n_blk = (size_t)(N + TR - 1) / TR;
+    size_t fused = up256z((size_t)3 * N * XW * 2) + up256z(n_tb * (TC / 16) * 3 * 8 * 64 * 16) + up256z(n_blk * n_tb * 256 * 8);
+    size_t layered = up256z(ray_trunk_workspace_bytes(n, N)) + (size_t)N * n.feature_c * sizeof(float);
+    return (fused > layered ? fused : layered) + 256;
+}
+
+hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf,
+                                    int M, float divisor, float* logits, float* row_max, float* row_sumexp, void* ws,
+                                    size_t ws_bytes, hipStream_t s) {
+    if (N == 0 || M == 0) return hipSuccess;
+    if (ws_bytes < ray_logits_workspace_bytes(n, N, M)) return hipErrorInvalidValue;
+    const int C = n.feature_c;
+    if (!(n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk)) {
+        float* h3 = (float*)((char*)ws + up256z(ray_trunk_workspace_bytes(n, N)));
+        hipError_t e = launch_ray_trunk(n, o, d, rgb, N, h3, ws, ray_trunk_workspace_bytes(n, N), s);
+        if (e != hipSuccess) return e;
+        return launch_attn_logits_folded(qf, n.qf_ld, h3, M, N, C, divisor, logits, row_max, row_sumexp, s);
+    }
+    const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
+    const int64_t n_blk = (N + TR - 1) / TR;
+    char* base = (char*)ws;
+    __bf16* xp = (__bf16*)base;
+    __bf16* Qf = (__bf16*)(base + up256z((size_t)3 * N * XW * 2));
+    float2* part = (float2*)((char*)Qf + up256z((size_t)n_tb * (TC / 16) * 3 * 8 * 64 * 16));
+    int64_t tot = N * XW;
+    int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
+    hipLaunchKernelGGL(k5_ray_input_planes, dim3(grid), dim3(256), 0, s, o, d, rgb, N, xp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t nq = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;
+    hipLaunchKernelGGL(k_qf_frag, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, qf, n.qf_ld, M, Qf, n_tb);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k5_trunk<true>, dim3((unsigned)n_blk), dim3(256), 0, s, xp, N, (const uint4*)n.f1, (const uint4*)n.f2,
+                       (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M, divisor, logits,
+                       part, Mpad);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (row_max && row_sumexp) {
+        hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, part, (int)n_blk, Mpad, M, row_max, row_sumexp);
         e = hipGetLastError();
     }
     return e;

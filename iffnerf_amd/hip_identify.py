@@ -124,6 +124,26 @@ class IdNetHandle:
                                                     dptr(rmax), dptr(rsum), stream_ptr(self.device)), "iff_attn_logits_folded")
         return logits, rmax, rsum
 
+    def ray_logits_folded(self, qf, o, d, rgb, want_stats: bool = True):
+        """Rays + folded queries -> (logits [M,N], row_max, row_sumexp) in one call (``ray_trunk`` + ``attn_logits_folded``;
+        one fused launch for a 256-wide encoder)."""
+        qf = _gpu(qf, "qf")
+        o, d, rgb = _gpu(o, "rays_ori", 3), _gpu(d, "rays_dir", 3), _gpu(rgb, "rays_rgb", 3)
+        M, N = qf.shape[0], o.shape[0]
+        if d.shape[0] != N or rgb.shape[0] != N:
+            raise RuntimeError("rays_ori / rays_dir / rays_rgb must have the same number of rows")
+        L = _lib.lib()
+        logits = qf.new_empty(M, N)
+        rmax = qf.new_empty(M) if want_stats else None
+        rsum = qf.new_empty(M) if want_stats else None
+        ws_bytes = int(L.iff_ray_logits_folded_workspace(self._h, N, M))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=o.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_ray_logits_folded(self._h, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M, float(math.sqrt(self.fea)),
+                                          dptr(logits), dptr(rmax), dptr(rsum), ws.data_ptr(), ws_bytes,
+                                          stream_ptr(self.device)), "iff_ray_logits_folded")
+        return logits, rmax, rsum
+
     def k_proj(self, ray_features):
         """k_proj alone, for MultiHeadAttention called with already-encoded rays."""
         x = _gpu(ray_features, "ray_features", self.fea)

@@ -40,7 +40,7 @@ class PosePipeline:
     def logits(self, tokens, ori, dirs, rgb):
         """tokens [M, C+14] x rays -> (logits [M,N], row_max [M], row_sumexp [M])."""
         if self.fold_heads:
-            return self.idnet.attn_logits_folded(self.idnet.q_fold(tokens), self.idnet.ray_trunk(ori, dirs, rgb))
+            return self.idnet.ray_logits_folded(self.idnet.q_fold(tokens), ori, dirs, rgb)
         _, k = self.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
         return H.attn_logits(self.idnet.q_proj(tokens), k, gemm_mode=self.idnet.gemm_mode)
 

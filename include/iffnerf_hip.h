@@ -210,6 +210,14 @@ int32_t iff_q_fold_width(const iff_idnet* net);
 int iff_q_fold(const iff_idnet* net, const float* img, int32_t M, float* qf, void* stream);
 int iff_attn_logits_folded(const iff_idnet* net, const float* qf, const float* h3, int32_t M, int64_t N, float divisor,
                            float* logits, float* row_max, float* row_sumexp, void* stream);
+/* iff_ray_trunk + iff_attn_logits_folded as one call (ray_preprocessor.py:29-38 then multihead_attention.py:6-8,
+ * folded): o,d,rgb [N,3] and qf [M, iff_q_fold_width] -> logits [M,N], row_max [M], row_sumexp [M].  For a 256-wide
+ * encoder in IFF_GEMM_BF16X3 mode the encoder's hidden activations stay in LDS and the logits are their "fourth
+ * layer"; other configurations run the two calls above internally. */
+size_t iff_ray_logits_folded_workspace(const iff_idnet* net, int64_t N, int32_t M);
+int iff_ray_logits_folded(const iff_idnet* net, const float* o, const float* d, const float* rgb, int64_t N,
+                          const float* qf, int32_t M, float divisor, float* logits, float* row_max, float* row_sumexp,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* scaled_attention_product (multihead_attention.py:4-12, mask=None), split so that ray shards on several
  * GPUs can exchange row statistics between the two halves:

@@ -226,3 +226,39 @@ def test_folded_heads(golden, net, dev):
         idx, val = H.topk(score, 100)
         assert idx.cpu().tolist() == g[f"{tag}_top_idx"].tolist(), "folded path: top-100 ray indices must equal the reference's"
     assert net.ray_trunk(o[:0], d[:0], c[:0]).shape == (0, net.feature_c)
+
+
+def test_fused_ray_logits(golden, dev):
+    """iff_ray_logits_folded (trunk + logits + softmax partials in one launch) vs the two-call path and the golden vectors;
+    ragged ray tiles, token counts that are not multiples of the 256-token block, and more than one block."""
+    from iffnerf_amd import hip_identify as H
+    g = golden["g6_identify"]
+    w = synthetic.make_id_weights(seed=99)
+    net = H.IdNetHandle(w, dev)
+    layered = H.IdNetHandle(w, dev, gemm_mode=H.GEMM_BF16X3_LAYERED)     # runs the fallback inside the same entry point
+    o, d, c = (golden.t("g6_identify", k).to(dev) for k in ("ori", "dirs", "rgb"))
+    tok = synthetic.make_tokens(256, 384, seed=int(g["tokens_seed"])).to(dev)
+    for tag, t in (("m256", tok), ("m137", tok[:137].contiguous())):
+        qf = net.q_fold(t)
+        logits, rmax, rsum = net.ray_logits_folded(qf, o, d, c)
+        close(logits[:32, :64], g[f"{tag}_logits_tile"], TOL_LOGIT, what="fused logits")
+        close(rmax, g[f"{tag}_rowmax"], TOL_LOGIT, what="fused row max")
+        close(rsum, g[f"{tag}_rowsumexp"], 0.0, 2e-4, "fused row sum-exp")
+        ref, rm2, rs2 = net.attn_logits_folded(qf, net.ray_trunk(o, d, c))
+        assert float((logits - ref).abs().max()) < 2e-5
+        assert torch.equal(rmax, logits.max(-1).values)
+        torch.testing.assert_close(rsum, rs2, atol=0, rtol=2e-5)
+        l2, m2, s2 = layered.ray_logits_folded(layered.q_fold(t), o, d, c)      # layered h3: another fp32-accurate evaluation
+        assert float((l2 - ref).abs().max()) < TOL_LOGIT
+        score = H.attn_colsum(logits, rmax, rsum, write_attention=False)
+        idx, _ = H.topk(score, 100)
+        assert idx.cpu().tolist() == g[f"{tag}_top_idx"].tolist()
+    big = torch.cat([tok, tok * 0.9, tok[:11] * 1.1]).contiguous()          # 523 tokens: three blocks, last one ragged
+    for n in (o.shape[0], 1999, 63, 1):
+        qf = net.q_fold(big)
+        logits, rmax, rsum = net.ray_logits_folded(qf, o[:n], d[:n], c[:n])
+        ref, rm2, rs2 = net.attn_logits_folded(qf, net.ray_trunk(o[:n], d[:n], c[:n]))
+        assert logits.shape == (523, n)
+        assert float((logits - ref).abs().max()) < 2e-5, n
+        assert torch.equal(rmax, logits.max(-1).values)
+        torch.testing.assert_close(rsum, rs2, atol=0, rtol=2e-5)
