@@ -34,6 +34,11 @@ GEN_POINTS = 593          # -> 16 011 rays (27 per surface point)
 M_TOKENS = 256
 TOPK = 100
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+# fused encoder/logits launch: bf16 MFMA flops per ray = 6 products x 2 x 256 outputs x (160 + 160 + 256 + 256 encoder k
+# + 256 logits k per 256-token block)
+def trunk_flops(n_rays, m_tokens):
+    return n_rays * 12.0 * 256.0 * (160 + 160 + 256 + 256 + 256 * ((m_tokens + 255) // 256))
 # march: algorithmic bytes per sample = valid*1184 (8 mask bytes x4 + density taps) + shaded*3456 (appearance taps)
 # (SURVEY.md section 8d, fp32 tables); per-ray terms are added where the launches read / write them
 B_VALID, B_APP = 32 + 1152, 3456
@@ -160,6 +165,7 @@ def main():
         n_rep = 20
         stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "encoder_logits": 0.0, "score_topk_pose": 0.0}
         march_launch_ms = [0.0, 0.0, 0.0]      # K4a density+compositing, K4b appearance gather, K4c Ref shading
+        trunk_ms = []                          # k5_trunk<true>: encoder + logits + softmax partials
         bytes_a = bytes_b = 0.0
         from iffnerf_amd import hip_identify as H
         from iffnerf_amd.hip_field import isocell_emit
@@ -188,6 +194,7 @@ def main():
             counts = pipe.field.march(rays, 0, 20, want_alpha=False, want_counts=True, stage_ms=ms)[4].double().sum(0)
             for i in range(3):
                 march_launch_ms[i] += ms[i] / n_rep
+            pipe.idnet.ray_logits_folded(pipe.idnet.q_fold(tokens[0]), ori, dirs, rgb, trunk_ms=trunk_ms)
             R = rays.shape[0]
             bytes_a += (R * (24 + 8 + 20 * 4) + counts[0].item() * B_VALID) / n_rep           # rays in, acc/depth + weights out
             bytes_b += (R * (24 + 20 * 4 + 28 * 4) + counts[1].item() * B_APP) / n_rep          # rays + weights in, features out
@@ -201,10 +208,22 @@ def main():
                     "other_kernels": {"k4a_density_composite": {"avg_launch_ms": round(march_launch_ms[0], 4),
                                                                  "achieved_GBps": round(bytes_a / (march_launch_ms[0] * 1e-3) / 1e9, 1)},
                                       "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4)}}}
+        t_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
+        if t_ms > 0:
+            tf = trunk_flops(GEN_POINTS * 27, M_TOKENS) / (t_ms * 1e-3) / 1e12
+            roofline["other_kernels"]["k5_trunk (ray encoder + attention logits, 3xBF16 MFMA)"] = {
+                "bound": "mfma", "avg_launch_ms": round(t_ms, 4), "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
+                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                "note": "bf16 MFMA flops issued (6 per fp32-accurate product); = %.1f TFLOP/s of fp32-equivalent work" % (tf / 6)}
         try:   # HBM-side bytes per launch from the committed PMC passes (profiles/README.md), not measured live
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
-                roofline["traffic"] = json.load(fh)["k4b_appearance<27>"]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            with open(os.path.join(ROOT, "profiles", "r01v3_hbm_traffic.json")) as fh:
+                pmc = json.load(fh)
+                roofline["traffic"] = pmc["k4b_appearance<27>"]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01v3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction)"
+                for name, key in (("k4a_density_composite", "k4a_density_composite"), ("k_ref_shade", "k_ref_shade<27, true>"),
+                                  ("k5_trunk (ray encoder + attention logits, 3xBF16 MFMA)", "k5_trunk<true>")):
+                    if name in roofline["other_kernels"] and key in pmc:
+                        roofline["other_kernels"][name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         # warm path (rays resident, the reference's eval semantics): stage C only

@@ -496,7 +496,21 @@ extern "C" int iff_ray_logits_folded(const iff_idnet* n, const float* o, const f
         return fail(IFF_ERR_WORKSPACE, "iff_ray_logits_folded: workspace %zu < %zu bytes", workspace_bytes,
                     ray_logits_workspace_bytes(n->dev, N, M));
     IFF_HIP(launch_ray_logits_folded(n->dev, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes,
-                                     (hipStream_t)stream));
+                                     nullptr, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_ray_logits_folded_timed(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N,
+                                           const float* qf, int32_t M, float divisor, float* logits, float* row_max,
+                                           float* row_sumexp, void* workspace, size_t workspace_bytes, float* trunk_ms_host,
+                                           void* stream) {
+    IFF_REQUIRE(n && N >= 1 && M >= 1 && trunk_ms_host, "iff_ray_logits_folded_timed: bad argument");
+    IFF_REQUIRE(o && d && rgb && qf && logits && workspace, "iff_ray_logits_folded_timed: null buffer");
+    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_ray_logits_folded_timed: pass both row statistics or neither");
+    if (workspace_bytes < ray_logits_workspace_bytes(n->dev, N, M))
+        return fail(IFF_ERR_WORKSPACE, "iff_ray_logits_folded_timed: workspace too small");
+    IFF_HIP(launch_ray_logits_folded(n->dev, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes,
+                                     trunk_ms_host, (hipStream_t)stream));
     return 0;
 }
 

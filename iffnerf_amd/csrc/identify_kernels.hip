@@ -1010,12 +1010,13 @@ size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M) {
 
 hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf,
                                     int M, float divisor, float* logits, float* row_max, float* row_sumexp, void* ws,
-                                    size_t ws_bytes, hipStream_t s) {
+                                    size_t ws_bytes, float* trunk_ms_host, hipStream_t s) {
     if (N == 0 || M == 0) return hipSuccess;
     if (ws_bytes < ray_logits_workspace_bytes(n, N, M)) return hipErrorInvalidValue;
     const int C = n.feature_c;
     if (!(n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk)) {
         float* h3 = (float*)((char*)ws + up256z(ray_trunk_workspace_bytes(n, N)));
+        if (trunk_ms_host) *trunk_ms_host = -1.0f;        // no fused launch to time in this configuration
         hipError_t e = launch_ray_trunk(n, o, d, rgb, N, h3, ws, ray_trunk_workspace_bytes(n, N), s);
         if (e != hipSuccess) return e;
         return launch_attn_logits_folded(qf, n.qf_ld, h3, M, N, C, divisor, logits, row_max, row_sumexp, s);
@@ -1034,10 +1035,23 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
     const int64_t nq = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;
     hipLaunchKernelGGL(k_qf_frag, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, qf, n.qf_ld, M, Qf, n_tb);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (trunk_ms_host) {
+        for (auto& x : ev) if ((e = hipEventCreate(&x)) != hipSuccess) return e;
+        (void)hipEventRecord(ev[0], s);
+    }
     hipLaunchKernelGGL(k5_trunk<true>, dim3((unsigned)n_blk), dim3(256), 0, s, xp, N, (const uint4*)n.f1, (const uint4*)n.f2,
                        (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M, divisor, logits,
                        part, Mpad);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    e = hipGetLastError();
+    if (trunk_ms_host) {
+        (void)hipEventRecord(ev[1], s);
+        hipError_t es = hipEventSynchronize(ev[1]);
+        (void)hipEventElapsedTime(trunk_ms_host, ev[0], ev[1]);
+        for (auto& x : ev) (void)hipEventDestroy(x);
+        if (e == hipSuccess) e = es;
+    }
+    if (e != hipSuccess) return e;
     if (row_max && row_sumexp) {
         hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, part, (int)n_blk, Mpad, M, row_max, row_sumexp);
         e = hipGetLastError();

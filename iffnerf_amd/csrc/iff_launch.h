@@ -63,7 +63,7 @@ hipError_t launch_ray_trunk(const IdNetDev& n, const float* o, const float* d, c
 size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M);
 hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf,
                                     int M, float divisor, float* logits, float* row_max, float* row_sumexp, void* ws,
-                                    size_t ws_bytes, hipStream_t s);
+                                    size_t ws_bytes, float* trunk_ms_host, hipStream_t s);
 hipError_t launch_q_fold(const IdNetDev& n, const float* img, int M, float* qf, hipStream_t s);
 hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, int M, int64_t N, int C, float divisor,
                                      float* logits, float* row_max, float* row_sumexp, hipStream_t s);

@@ -124,7 +124,7 @@ class IdNetHandle:
                                                     dptr(rmax), dptr(rsum), stream_ptr(self.device)), "iff_attn_logits_folded")
         return logits, rmax, rsum
 
-    def ray_logits_folded(self, qf, o, d, rgb, want_stats: bool = True):
+    def ray_logits_folded(self, qf, o, d, rgb, want_stats: bool = True, trunk_ms: Optional[list] = None):
         """Rays + folded queries -> (logits [M,N], row_max, row_sumexp) in one call (``ray_trunk`` + ``attn_logits_folded``;
         one fused launch for a 256-wide encoder)."""
         qf = _gpu(qf, "qf")
@@ -139,6 +139,14 @@ class IdNetHandle:
         ws_bytes = int(L.iff_ray_logits_folded_workspace(self._h, N, M))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=o.device)
         with torch.cuda.device(self.device):
+            if trunk_ms is not None:          # synchronous, instrumented variant (bench.py roofline)
+                ms = (C.c_float * 1)()
+                check(L.iff_ray_logits_folded_timed(self._h, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M,
+                                                    float(math.sqrt(self.fea)), dptr(logits), dptr(rmax), dptr(rsum),
+                                                    ws.data_ptr(), ws_bytes, ms, stream_ptr(self.device)),
+                      "iff_ray_logits_folded_timed")
+                trunk_ms.append(float(ms[0]))
+                return logits, rmax, rsum
             check(L.iff_ray_logits_folded(self._h, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M, float(math.sqrt(self.fea)),
                                           dptr(logits), dptr(rmax), dptr(rsum), ws.data_ptr(), ws_bytes,
                                           stream_ptr(self.device)), "iff_ray_logits_folded")

@@ -121,8 +121,13 @@ class IdentificationModule(torch.nn.Module):
         call, exactly as the reference does per image (identification_module.py:164)."""
         from .. import hip_identify as H
         net = self._idnet()
-        _, k = net.ray_encode(rays_ori, rays_dir, rays_rgb, want_features=False, want_k=True)
-        logits, rmax, rsum = H.attn_logits(net.q_proj(features_img_w_pe_flat), k)
+        if getattr(self, "fold_heads", True):
+            # mlp2.2, k_proj and q_proj folded into one token-side Linear; encoder + logits in one launch
+            # (include/iffnerf_hip.h iff_ray_logits_folded; DESIGN.md section 3)
+            logits, rmax, rsum = net.ray_logits_folded(net.q_fold(features_img_w_pe_flat), rays_ori, rays_dir, rays_rgb)
+        else:
+            _, k = net.ray_encode(rays_ori, rays_dir, rays_rgb, want_features=False, want_k=True)
+            logits, rmax, rsum = H.attn_logits(net.q_proj(features_img_w_pe_flat), k)
         score = H.attn_colsum(logits, rmax, rsum, write_attention=materialize_map)
         return score, (logits if materialize_map else None)
 
