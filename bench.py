@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--in-flight", type=int, default=4, help="cold queries kept in flight on separate streams (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="draw the next query's surface points in a parallel branch of each query graph (shorter single-stream "
+                         "latency, 0.40 vs 0.54 ms; no gain with several graphs in flight: ROCm 7.2 serialises the branches of "
+                         "concurrently launched graphs)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (captured segments + all_gathers) at any world size, for rehearsal on one GPU")
     args = ap.parse_args()
@@ -131,7 +135,8 @@ def main():
     in_flight = max(1, args.in_flight)
     streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
     if not sharded:
-        graphs = [pipe.capture_query(tokens[0].shape, GEN_POINTS, seed=(g + 1) << 40, k=TOPK) for g in range(in_flight)]
+        graphs = [pipe.capture_query(tokens[0].shape, GEN_POINTS, seed=(g + 1) << 40, k=TOPK,
+                                     prefetch_emission=args.prefetch) for g in range(in_flight)]
         for g in graphs:
             g.tokens.copy_(tokens[0])
     else:

@@ -48,14 +48,22 @@ class PosePipeline:
     def emit(self, gen_points: int, seed: int, point_range: Optional[Tuple[int, int]] = None, seed_offset=None):
         """-> (ori [27P,3], dirs [27P,3], rgb [27P,3]).  ``point_range`` keeps a contiguous block of the surface points
         (ray sharding across GPUs: every rank draws the same samples from the same seed and colours only its block)."""
+        return self.emit_from_samples(self.sample_surface(gen_points, seed, seed_offset), point_range)
+
+    def sample_surface(self, gen_points: int, seed: int, seed_offset=None):
+        """Stage A, first half: the iterative surface sampler (sampling.py:509-532) -> samples [P,3]."""
         samples, _, stats = self.field.surface_sample(gen_points, self.rho, n_epochs=4, max_iterations=200, seed=seed,
                                                       seed_offset=seed_offset)
+        self.last_sampler_stats = stats
+        return samples
+
+    def emit_from_samples(self, samples, point_range: Optional[Tuple[int, int]] = None):
+        """Normals, 27-ray fans and their colours (sampling.py:535-541, :442-488) for given surface points."""
         if point_range is not None:
             samples = samples[point_range[0]:point_range[1]].contiguous()
         normals = self.field.point_normals(samples)
         ori, dirs, rays = isocell_emit(self.cells, samples, normals, want_rays6=True)
         rgb = self.field.march(rays, 0, 20, want_alpha=False)[0]
-        self.last_sampler_stats = stats
         return ori, dirs, rgb
 
     # ------------------------------------------------------------------ stage C  (test_image + pose solve)
@@ -75,8 +83,9 @@ class PosePipeline:
         ori, dirs, rgb = self.emit(gen_points, seed, seed_offset=seed_offset)
         return self.identify(tokens, ori, dirs, rgb, k, materialize_map)
 
-    def capture_query(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100) -> "CapturedQuery":
-        return CapturedQuery(self, tokens_shape, gen_points, seed, k)
+    def capture_query(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100,
+                      prefetch_emission: bool = False) -> "CapturedQuery":
+        return CapturedQuery(self, tokens_shape, gen_points, seed, k, prefetch_emission)
 
     # ------------------------------------------------------------------ ray-sharded batch of queries (multi-GPU)
     # Three local segments with one small exchange between each pair (distributed.py): the eager ``query_sharded`` and the
@@ -143,9 +152,11 @@ class CapturedQuery:
     ``idx`` / ``val`` out (valid after the replay's stream has been synchronised, until the next replay).
     """
 
-    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100):
+    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100,
+                 prefetch_emission: bool = False):
         dev = pipe.device
         self.pipe = pipe
+        self.prefetch_emission = bool(prefetch_emission)
         self.tokens = torch.zeros(tokens_shape, dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
@@ -156,9 +167,29 @@ class CapturedQuery:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
+        if not self.prefetch_emission:
+            with torch.cuda.graph(self.graph):
+                self.counter += 1
+                self.c2w, self.idx, self.val = pipe.query(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+            return
+        # Software-pipelined form: the graph has two branches -- the surface sampler drawing the NEXT replay's points
+        # (device counter + 1) and stages A2 + B + C of this replay on the points drawn during the previous one.  The
+        # emission does not depend on the query image, so the latency-bound sampler leaves the critical path; every
+        # replay still consumes one fresh draw and produces one.  Replay r uses the draw of seed offset r - 1
+        # (the first one comes from the eager call below).
+        self.samples = pipe.sample_surface(gen_points, seed, seed_offset=self.counter).clone()
+        torch.cuda.synchronize(dev)
+        self._side = torch.cuda.Stream(device=dev)
         with torch.cuda.graph(self.graph):
             self.counter += 1
-            self.c2w, self.idx, self.val = pipe.query(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+            main = torch.cuda.current_stream(dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                nxt = pipe.sample_surface(gen_points, seed, seed_offset=self.counter)
+            ori, dirs, rgb = pipe.emit_from_samples(self.samples)
+            self.c2w, self.idx, self.val = pipe.identify(self.tokens, ori, dirs, rgb, k, False)
+            main.wait_stream(self._side)
+            self.samples.copy_(nxt)
 
     def replay(self, tokens: Optional[torch.Tensor] = None):
         if tokens is not None:
