@@ -42,6 +42,7 @@ __device__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777
 constexpr int SAMPLER_MAX_EPOCHS = 64;
 constexpr int SAMPLER_MAX_ITERS = 4095;
 constexpr int SAMPLER_MAX_POINTS = 32768;          // the invalid list lives in LDS (4 B per sample)
+constexpr int SAMPLER_CACHE_POINTS = 4096;        // up to here alpha + positions are cached in LDS too (20 B per sample)
 struct SamplerWs {
     unsigned barrier_count;     // monotonic arrivals
     unsigned abort_flag;
@@ -116,6 +117,7 @@ struct SamplerArgs {
     unsigned char* ws;
     const int* occ_list;   // occupied mask voxel ids (z*H*W + y*W + x), ascending
     int n_occ;
+    int cache_lds;         // every workgroup keeps this epoch's alpha [P] and positions [P,3] in LDS (P <= SAMPLER_CACHE_POINTS)
 };
 
 // jittered candidate j of sample i (sampling.py:38-66): theta = 2 pi u, phi = arccos(1 - 2u), radius |N(0, rho)|
@@ -123,21 +125,24 @@ __device__ inline void candidate_position(const SamplerArgs& a, const float base
                                           float p[3], uint32_t& prio) {
     U4 c0 = U4{(uint32_t)i, (uint32_t)j, (uint32_t)(epoch * 4096 + it), 0xA5u};
     U4 r0 = philox4x32_10(c0, a.seed_lo, a.seed_hi);
-    float theta = 6.283185307179586f * u01(r0.x);
-    float phi = acosf(1.0f - 2.0f * u01(r0.y));
-    float sp = sinf(phi);
-    float dir[3] = {sp * cosf(theta), sp * sinf(theta), cosf(phi)};
+    // the same distribution with cheaper arithmetic: cos(phi) = 1 - 2u is the z component itself, sin(phi) its
+    // complement; sincospi/cospi need no range reduction; the four uniforms use the top 24 bits of each word, the
+    // selection priority the four low bytes (independent bits of the same draw)
+    float z = 1.0f - 2.0f * u01(r0.y);
+    float sp = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float st, ct;
+    sincospif(2.0f * u01(r0.x), &st, &ct);
+    float dir[3] = {sp * ct, sp * st, z};
     float u1 = 1.0f - u01(r0.z);                       // (0,1]
-    float g = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u01(r0.w));
+    float g = sqrtf(-2.0f * __logf(u1)) * cospif(2.0f * u01(r0.w));
     float dist = fabsf(g * a.rho);
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = base[c] + dir[c] * dist;
-    c0.w = 0xA6u;
-    prio = philox4x32_10(c0, a.seed_lo, a.seed_hi).x;
+    prio = (r0.x & 0xffu) | ((r0.y & 0xffu) << 8) | ((r0.z & 0xffu) << 16) | ((r0.w & 0xffu) << 24);
 }
 
 __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs a) {
-    extern __shared__ int s_list[];               // [P] still-invalid sample ids, ascending
+    extern __shared__ int s_list[];               // [P] still-invalid sample ids, ascending; then (cache_lds) alpha [P], pos [3P]
     if (a.seed_dev) {
         // agent-scope load: a scalar/L1-cached read can be stale when a graph node just before this one rewrote the word
         unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) +
@@ -149,6 +154,8 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
     SamplerWs* ws = (SamplerWs*)a.ws;
     unsigned long long* winners_base = (unsigned long long*)(a.ws + align_up(sizeof(SamplerWs), 256));
     const int P = (int)a.P;
+    float* s_alpha = reinterpret_cast<float*>(s_list + P);
+    float* s_pos = s_alpha + P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + tid;
     const int64_t gthreads = (int64_t)gridDim.x * blockDim.x;
@@ -197,13 +204,48 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
         unsigned long long* winners_next = winners_base + (size_t)((epoch + 1) & 1) * P;
         // ---------------- threshold = torch.quantile(alpha, 0.6), linear interpolation; every workgroup computes it
         float thresh;
+        const float* alpha_src = a.alpha;
+        if (a.cache_lds) {
+            // this epoch's alpha and positions (fixed until the apply step) once from global into LDS: the two radix
+            // selects (8 passes over alpha) and every candidate's base position then stay on the CU
+            for (int t = tid; t < P; t += 256) {
+                s_alpha[t] = a.alpha[t];
+                s_pos[3 * t] = a.samples[3 * t]; s_pos[3 * t + 1] = a.samples[3 * t + 1]; s_pos[3 * t + 2] = a.samples[3 * t + 2];
+            }
+            __syncthreads();
+            alpha_src = s_alpha;
+        }
         {
             float pos = 0.6f * (float)(P - 1);
             int lo = (int)floorf(pos);
             int hi = min(lo + 1, P - 1);
             float frac = pos - (float)lo;
-            float vlo = iff_order_key_inv(iff_wg_select_key<false>(a.alpha, P, lo + 1, hist));
-            float vhi = iff_order_key_inv(iff_wg_select_key<false>(a.alpha, P, hi + 1, hist));
+            // one radix select for rank lo; rank lo + 1 is either the same value (duplicates) or the smallest larger one:
+            // a single counting pass instead of a second four-pass select
+            const uint32_t klo = iff_wg_select_key<false>(alpha_src, P, lo + 1, hist);
+            int cnt_le = 0;
+            uint32_t kmin = 0xffffffffu;
+            for (int t = tid; t < P; t += 256) {
+                uint32_t key = iff_order_key(alpha_src[t]);
+                cnt_le += (key <= klo) ? 1 : 0;
+                kmin = (key > klo && key < kmin) ? key : kmin;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                cnt_le += __shfl_xor(cnt_le, off, 64);
+                uint32_t o = (uint32_t)__shfl_xor((int)kmin, off, 64);
+                kmin = o < kmin ? o : kmin;
+            }
+            if (lane == 0) { hist[wave] = cnt_le; hist[4 + wave] = (int)kmin; }
+            __syncthreads();
+            cnt_le = hist[0] + hist[1] + hist[2] + hist[3];
+            kmin = (uint32_t)hist[4];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) kmin = (uint32_t)hist[4 + w] < kmin ? (uint32_t)hist[4 + w] : kmin;
+            __syncthreads();
+            const uint32_t khi = (hi == lo || cnt_le >= hi + 1) ? klo : kmin;
+            float vlo = iff_order_key_inv(klo);
+            float vhi = iff_order_key_inv(khi);
             // torch.lerp: lo + w (hi - lo) for w < 0.5, hi - (hi - lo)(1 - w) otherwise
             thresh = (frac < 0.5f) ? (vlo + (vhi - vlo) * frac) : (vhi - (vhi - vlo) * (1.0f - frac));
         }
@@ -221,7 +263,8 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
                 int sub = (int)(t & 3);
                 int li = (int)(slot / m), j = (int)(slot - (int64_t)li * m);
                 int i = s_list[li];
-                float base[3] = {a.samples[3 * i], a.samples[3 * i + 1], a.samples[3 * i + 2]}, p[3];
+                const float* ps = a.cache_lds ? s_pos : a.samples;
+                float base[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]}, p[3];
                 uint32_t prio;
                 candidate_position(a, base, i, j, epoch, it, p, prio);
                 float al = alpha4(f, p, sub, live);
@@ -268,7 +311,8 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
                 unsigned long long wv = live ? __hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 bool moved = wv != 0ull;
                 int j = (int)(wv & 0xfffffull) - 1, wit = (int)((wv >> 20) & 0xfffull);
-                float base[3] = {a.samples[3 * i], a.samples[3 * i + 1], a.samples[3 * i + 2]}, p[3];
+                const float* ps = a.cache_lds ? s_pos : a.samples;
+                float base[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]}, p[3];
                 uint32_t prio;
                 candidate_position(a, base, i, moved ? j : 0, epoch, wit, p, prio);
                 float al = alpha4(f, p, sub, live && moved);
@@ -320,7 +364,8 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
     // one workgroup per CU at most, so the grid is co-resident and the in-kernel barriers cannot deadlock
     int64_t want = (5 * P * 4 + 255) / 256;
     int grid = (int)(want < 1 ? 1 : (want > n_cus ? n_cus : want));
-    const size_t lds = (size_t)P * sizeof(int);
+    a.cache_lds = P <= SAMPLER_CACHE_POINTS ? 1 : 0;
+    const size_t lds = (size_t)P * sizeof(int) * (a.cache_lds ? 5 : 1);
     if (lds > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_surface_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

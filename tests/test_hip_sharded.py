@@ -130,3 +130,36 @@ def test_captured_segments_with_a_real_rccl_group():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1, ROOT, str(port)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_large_ray_sets_keep_the_invariants(dev):
+    """BASELINE.json's larger configurations (32 k and 64 k candidate rays): size-independent properties of the path --
+    every attention row sums to one so the scores sum to M, top-k is sorted with valid distinct indices, the pose is a
+    rigid transform, and three emulated shards reproduce the unsharded top-k."""
+    from iffnerf_amd import distributed as D, hip_identify as H
+    from iffnerf_amd.pipeline import PosePipeline
+    pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.0, 0.0, 1.0))
+    tok = _tokens(dev, Q=2, M=256)
+    for P in (1186, 2400):                                   # 32 022 and 64 800 rays
+        ori, dirs, rgb = pipe.emit(P, seed=9)
+        assert ori.shape == (27 * P, 3) and int(pipe.last_sampler_stats[0, 3]) >= 0, "sampler timed out"
+        assert torch.isfinite(rgb).all() and float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 + 1e-5
+        logits, rmax, rsum = pipe.logits(tok[0], ori, dirs, rgb)
+        assert torch.equal(rmax, logits.max(-1).values)
+        score = H.attn_colsum(logits, rmax, rsum, write_attention=True)
+        assert abs(float(score.double().sum()) - 256.0) < 2e-2
+        torch.testing.assert_close(logits.sum(-1), torch.ones(256, device=dev), atol=2e-4, rtol=0)     # now the attention map
+        idx, val = H.topk(score, 100)
+        assert torch.equal(val, torch.sort(val, descending=True).values) and idx.unique().numel() == 100
+        assert int(idx.min()) >= 0 and int(idx.max()) < 27 * P and torch.equal(score[idx], val)
+        c2w = H.pose_from_topk(idx, val, ori, dirs, pipe.model_up).cpu().double()
+        R = c2w[:3, :3]
+        assert torch.allclose(R @ R.T, torch.eye(3, dtype=torch.float64), atol=1e-5) and torch.equal(c2w[3].float(), torch.tensor([0., 0., 0., 1.]))
+        want_pose, want_val, want_idx = pipe.query_sharded(tok, P, seed=9, k=100)
+        seg1 = [pipe.shard_local_logits(tok, P, 9, r, 3) for r in range(3)]
+        stats_all = torch.stack([s[3] for s in seg1])
+        cands = torch.stack([pipe.shard_local_candidates(s[2], stats_all, s[0], s[1], 2, 100, D.shard_points(P, r, 3)[0] * 27, False)
+                             for r, s in enumerate(seg1)])
+        poses, val3, idx3 = pipe.shard_global_poses(cands, 100)
+        assert torch.equal(idx3, want_idx)
+        torch.testing.assert_close(poses, want_pose, atol=1e-5, rtol=0)
