@@ -440,39 +440,6 @@ hipError_t launch_frag_order(const void* Wp, void* Wf, int Kp, hipStream_t s) {
     return hipGetLastError();
 }
 
-// encoder input as three bf16 planes [3][N][XW] (same values as k5_ray_input, split once here instead of per GEMM tile)
-__global__ void k5_ray_input_planes(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ c,
-                                    int64_t N, __bf16* __restrict__ xp) {
-    const int64_t tot = N * XW;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = t / XW;
-        int col = (int)(t - r * XW);
-        float v = 0.0f;
-        if (col < 3) v = o[3 * r + col];
-        else if (col < 6) v = d[3 * r + col - 3];
-        else if (col < 9) v = c[3 * r + col - 6];
-        else if (col < 141) {
-            int b = col - 9;
-            const float* src;
-            int F;
-            if (b < 48) { src = o; F = 8; }
-            else if (b < 96) { src = d; F = 8; b -= 48; }
-            else { src = c; F = 6; b -= 96; }
-            int half = F * 3;
-            bool is_cos = b >= half;
-            if (is_cos) b -= half;
-            int j = b / F, k = b - j * F;
-            float arg = src[3 * r + j] * (float)(1 << k);
-            v = is_cos ? cosf(arg) : sinf(arg);
-        }
-        __bf16 h0 = (__bf16)v;
-        float r1 = v - (float)h0;
-        __bf16 h1 = (__bf16)r1;
-        float r2 = r1 - (float)h1;
-        xp[t] = h0; xp[tot + t] = h1; xp[2 * tot + t] = (__bf16)r2;
-    }
-}
-
 struct WFrag { bf16x8 p[2][3]; };      // [feature group][plane]
 
 __device__ inline void trunk_load_w(WFrag& w, const uint4* __restrict__ Wf, int ks, int wave, int lane) {
@@ -566,7 +533,8 @@ __global__ void __launch_bounds__(256) k6_merge_stats(const float2* __restrict__
 // ("layer 4", multihead_attention.py:6-7 folded): logits [M][N] = (qf[:, :256] h3^T + qf[:, 256]) / divisor out, plus
 // this workgroup's softmax partials (max, sum exp over its 64 rays) per token.
 template <bool LOGITS>
-__global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, int64_t N, const uint4* __restrict__ Wf1,
+__global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                const float* __restrict__ ray_c, int64_t N, const uint4* __restrict__ Wf1,
                                                 const uint4* __restrict__ Wf2, const uint4* __restrict__ Wf3,
                                                 const float* __restrict__ b1, const float* __restrict__ b2,
                                                 const float* __restrict__ b3, float* __restrict__ h3,
@@ -578,27 +546,46 @@ __global__ void __launch_bounds__(256) k5_trunk(const __bf16* __restrict__ xp, i
     const int lr = lane & 31, lh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * TR;
 
-    // x planes -> LDS (rows beyond N are zero): 3 planes x 64 rays x 20 sixteen-byte chunks = 15 per thread, all
-    // requested before the first is stored (a rolled loop would pay the memory latency 15 times over)
+    // encoder input x (ray_preprocessor.py:30-37, tensorBase.py:14-20) straight into LDS as three bf16 planes:
+    // x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141 columns, zero-padded to 160; rows beyond N are zero).
+    // Work items per ray: 66 (source component, frequency) pairs -- one sincosf each serves the sin and the cos column --
+    // plus the 9 raw values and the 19 pad columns: 94 items x 64 rays over 256 threads.
     {
-        constexpr int CH = XW / 8, PER = 3 * TR * CH / 256;
-        static_assert(3 * TR * CH % 256 == 0, "x tile must divide over the workgroup");
-        uint4 v[PER];
+        auto put = [&](int ray, int col, float v) {
+            __bf16 h0 = (__bf16)v;
+            float r1 = v - (float)h0;
+            __bf16 h1 = (__bf16)r1;
+            float r2 = r1 - (float)h1;
+            S[0][ray][col] = h0; S[1][ray][col] = h1; S[2][ray][col] = (__bf16)r2;
+        };
+        const int ray = tid & 63;
+        const int64_t gr = row0 + ray;
+        const bool ok = gr < N;
+        float src[9];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            int cix = tid + 256 * u;
-            int pl = cix / (TR * CH), rem = cix - pl * (TR * CH);
-            int ray = rem / CH, ch = rem - ray * CH;
-            int64_t gr = row0 + ray;
-            v[u] = make_uint4(0, 0, 0, 0);
-            if (gr < N) v[u] = *reinterpret_cast<const uint4*>(xp + ((size_t)pl * N + gr) * XW + ch * 8);
+        for (int c = 0; c < 3; ++c) {
+            src[c] = ok ? ray_o[3 * gr + c] : 0.0f;
+            src[3 + c] = ok ? ray_d[3 * gr + c] : 0.0f;
+            src[6 + c] = ok ? ray_c[3 * gr + c] : 0.0f;
         }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            int cix = tid + 256 * u;
-            int pl = cix / (TR * CH), rem = cix - pl * (TR * CH);
-            int ray = rem / CH, ch = rem - ray * CH;
-            *reinterpret_cast<uint4*>(&S[pl][ray][ch * 8]) = v[u];
+        for (int item = tid >> 6; item < 94; item += 4) {            // wave-uniform item -> no divergence
+            if (item < 66) {
+                // blocks: PE(o) at column 9, PE(d) at 57, PE(rgb) at 105; each [sin (F*3) | cos (F*3)], component-major
+                int blk = item < 24 ? 0 : (item < 48 ? 1 : 2);
+                int b = item - 24 * blk;
+                int F = blk == 2 ? 6 : 8;
+                int j = b / F, k = b - j * F;
+                float arg = src[3 * blk + j] * (float)(1 << k);
+                float sv, cv;
+                sincosf(arg, &sv, &cv);               // one argument reduction for both columns
+                int col = 9 + 48 * blk + b;
+                put(ray, col, sv);
+                put(ray, col + 3 * F, cv);
+            } else if (item < 75) {
+                put(ray, item - 66, src[item - 66]);
+            } else {
+                put(ray, 141 + (item - 75), 0.0f);
+            }
         }
     }
     __syncthreads();
@@ -799,12 +786,7 @@ static hipError_t trunk(const IdNetDev& n, const float* o, const float* d, const
     int64_t tot = N * XW;
     int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
     if (n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk) {
-        // x planes (3 x N x 160 bf16 = 960 B per ray) fit in the fp32 x slot + h1 of the workspace
-        __bf16* xp = (__bf16*)x;
-        hipLaunchKernelGGL(k5_ray_input_planes, dim3(grid), dim3(256), 0, s, o, d, rgb, N, xp);
-        hipError_t e0 = hipGetLastError();
-        if (e0 != hipSuccess) return e0;
-        hipLaunchKernelGGL(k5_trunk<false>, dim3((unsigned)((N + TR - 1) / TR)), dim3(256), 0, s, xp, N, (const uint4*)n.f1,
+        hipLaunchKernelGGL(k5_trunk<false>, dim3((unsigned)((N + TR - 1) / TR)), dim3(256), 0, s, o, d, rgb, N, (const uint4*)n.f1,
                            (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, h3, (const uint4*)nullptr,
                            (const float*)nullptr, 0, 0, 1.0f, (float*)nullptr, (float2*)nullptr, 0);
         return hipGetLastError();
@@ -1003,7 +985,7 @@ hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, 
 static inline size_t up256z(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M) {
     const size_t n_tb = (size_t)(M + 255) / 256, n_blk = (size_t)(N + TR - 1) / TR;
-    size_t fused = up256z((size_t)3 * N * XW * 2) + up256z(n_tb * (TC / 16) * 3 * 8 * 64 * 16) + up256z(n_blk * n_tb * 256 * 8);
+    size_t fused = up256z(n_tb * (TC / 16) * 3 * 8 * 64 * 16) + up256z(n_blk * n_tb * 256 * 8);
     size_t layered = up256z(ray_trunk_workspace_bytes(n, N)) + (size_t)N * n.feature_c * sizeof(float);
     return (fused > layered ? fused : layered) + 256;
 }
@@ -1024,14 +1006,9 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
     const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
     const int64_t n_blk = (N + TR - 1) / TR;
     char* base = (char*)ws;
-    __bf16* xp = (__bf16*)base;
-    __bf16* Qf = (__bf16*)(base + up256z((size_t)3 * N * XW * 2));
+    __bf16* Qf = (__bf16*)base;
     float2* part = (float2*)((char*)Qf + up256z((size_t)n_tb * (TC / 16) * 3 * 8 * 64 * 16));
-    int64_t tot = N * XW;
-    int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
-    hipLaunchKernelGGL(k5_ray_input_planes, dim3(grid), dim3(256), 0, s, o, d, rgb, N, xp);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e;
     const int64_t nq = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;
     hipLaunchKernelGGL(k_qf_frag, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, qf, n.qf_ld, M, Qf, n_tb);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1040,7 +1017,7 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
         for (auto& x : ev) if ((e = hipEventCreate(&x)) != hipSuccess) return e;
         (void)hipEventRecord(ev[0], s);
     }
-    hipLaunchKernelGGL(k5_trunk<true>, dim3((unsigned)n_blk), dim3(256), 0, s, xp, N, (const uint4*)n.f1, (const uint4*)n.f2,
+    hipLaunchKernelGGL(k5_trunk<true>, dim3((unsigned)n_blk), dim3(256), 0, s, o, d, rgb, N, (const uint4*)n.f1, (const uint4*)n.f2,
                        (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M, divisor, logits,
                        part, Mpad);
     e = hipGetLastError();
