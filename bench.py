@@ -3,13 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W          (N = 1: plain process; N > 1: launched by torch.distributed.run)
 
-Step = one pass of the hot path over one batch of synthetic queries, COLD: every step re-runs stage A (device-side
+Step = one pass of the hot path over one batch of synthetic queries (`--batch`, default 4 query images, EACH with its own
+freshly drawn ray set), COLD: every step re-runs for every query of the batch stage A (device-side
 surface sampler + normals + 27-ray fans), stage B (20-sample VM march + Ref shading of every ray) and stage C (ray
 encoder + q/k projections (folded, include/iffnerf_hip.h), softmax over rays, column-sum score, top-100, closed-form pose).  Nothing is cached between
 steps except the model tables; the ray encoder is recomputed per step as the reference does per image
 (pose_estimation/identification_module.py:164).  Workload at N = 1 is BASELINE.json configs[1]: "lego 800x800, 16k
 candidate rays": a synthetic lego-shaped TensorVMSplit (300^3 grid, 16/48 components, 180^3 mask), gen_points = 593 ->
-16 011 rays, one query of M = 256 image tokens (the 800x800 image only feeds the out-of-path DINOv2 front end).
+16 011 rays per query, M = 256 image tokens per query (the 800x800 image only feeds the out-of-path DINOv2 front end).
+`value` counts poses: batch x steps / time.
 At N > 1 the same ray set is sharded over the ranks (contiguous blocks of surface points) and each step processes N
 queries (weak scaling: one more query per step per GPU), with the two RCCL all_gathers of iffnerf_amd/distributed.py.
 
@@ -88,6 +90,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--in-flight", type=int, default=4, help="cold queries kept in flight on separate streams (N = 1)")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="cold queries per step at N = 1, each with its own freshly drawn ray set, served by one set of launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true",
                     help="draw the next query's surface points in a parallel branch of each query graph (shorter single-stream "
@@ -108,8 +112,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    sharded = world_size > 1 or args.force_sharded
-    if sharded:
+    if world_size > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
@@ -118,7 +121,8 @@ def main():
 
     from iffnerf_amd import synthetic
     ck, idw, pipe = build_inputs(device)
-    Q = world_size
+    sharded = world_size > 1 or args.force_sharded
+    Q = world_size if sharded else max(1, args.batch)
     tokens = torch.stack([synthetic.make_tokens(M_TOKENS, 384, seed=7 + q) for q in range(Q)]).to(device)
 
     def barrier():
@@ -133,8 +137,14 @@ def main():
     # device-side counter that is added to the sampler seed: no two steps draw the same rays.  At N > 1 all steps use the
     # one default process group, so every rank issues the collectives in the same order.
     in_flight = max(1, args.in_flight)
+    # the persistent samplers of all in-flight steps must be co-resident (their workgroups meet at in-kernel barriers)
+    in_flight = min(in_flight, pipe.max_steps_in_flight(GEN_POINTS, 1 if (world_size > 1 or args.force_sharded) else max(1, args.batch)))
     streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
-    if not sharded:
+    if not sharded and Q > 1:
+        graphs = [pipe.capture_query_batch(tokens.shape, GEN_POINTS, seed=(g + 1) << 40, k=TOPK) for g in range(in_flight)]
+        for g in graphs:
+            g.tokens.copy_(tokens)
+    elif not sharded:
         graphs = [pipe.capture_query(tokens[0].shape, GEN_POINTS, seed=(g + 1) << 40, k=TOPK,
                                      prefetch_emission=args.prefetch) for g in range(in_flight)]
         for g in graphs:
@@ -257,10 +267,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "lego-shaped TensorVMSplit 300^3 (16/48 comps, 180^3 mask), gen_points=593 -> 16011 rays, "
                                    "M=256 tokens, top-100, cold path (A+B+C every step)",
-                       "queries_per_step": Q, "rays_total": GEN_POINTS * 27, "queries_in_flight": in_flight,
-                       "emissions_per_step": 1,
+                       "queries_per_step": Q, "rays_per_query": GEN_POINTS * 27, "steps_in_flight": in_flight,
+                       "emissions_per_step": 1 if sharded else Q,
                        "gemm": "3xBF16 split on the bf16 MFMA (fp32-accurate), fp32 accumulate; march and shading in fp32",
-                       "launch": "hipGraph replay per query" if not sharded else launch_mode,
+                       "launch": ("hipGraph replay per step (one graph = %d cold queries, each with its own ray set)" % Q)
+                                 if not sharded else launch_mode,
                        "parallelism": "single GPU" if not sharded else f"rays sharded over {world_size} ranks + 2 all_gathers"},
             "warm_poses_per_s": round(warm, 2),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

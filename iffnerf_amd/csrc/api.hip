@@ -283,16 +283,32 @@ extern "C" int iff_march_shade_timed(const iff_field* f, const float* rays, int3
 
 extern "C" size_t iff_surface_sample_workspace(int64_t P) { return P > 0 ? sampler_workspace_bytes(P) : 0; }
 
+extern "C" int iff_surface_sample_residency(const iff_field* f, int64_t P, int32_t* wgs_per_run, int32_t* device_capacity) {
+    IFF_REQUIRE(f && wgs_per_run && device_capacity, "iff_surface_sample_residency: null argument");
+    int w = 0, c = 0;
+    IFF_HIP(sampler_residency(P, f->n_cus, &w, &c));
+    *wgs_per_run = w; *device_capacity = c;
+    return 0;
+}
+
 extern "C" int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t max_iterations, uint64_t seed,
                                   const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha, int32_t* stats, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+    return iff_surface_sample_batched(f, 1, P, n_epochs, max_iterations, seed, seed_dev_opt, rho, samples, alpha, stats, workspace,
+                                      workspace_bytes, stream);
+}
+
+extern "C" int iff_surface_sample_batched(const iff_field* f, int32_t B, int64_t P, int32_t n_epochs, int32_t max_iterations,
+                                          uint64_t seed, const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha,
+                                          int32_t* stats, void* workspace, size_t workspace_bytes, void* stream) {
     IFF_REQUIRE(f && samples && alpha && stats && workspace, "iff_surface_sample: null argument");
-    IFF_REQUIRE(P >= 1, "iff_surface_sample: P must be >= 1");
-    if (workspace_bytes < sampler_workspace_bytes(P))
-        return fail(IFF_ERR_WORKSPACE, "iff_surface_sample: workspace %zu < %zu bytes", workspace_bytes, sampler_workspace_bytes(P));
+    IFF_REQUIRE(P >= 1 && B >= 1, "iff_surface_sample: P and the batch size must be >= 1");
+    if (workspace_bytes < sampler_workspace_bytes(P) * (size_t)B)
+        return fail(IFF_ERR_WORKSPACE, "iff_surface_sample: workspace %zu < %zu bytes", workspace_bytes,
+                    sampler_workspace_bytes(P) * (size_t)B);
     if (f->dev.mask && f->n_occ == 0) return fail(IFF_ERR_INVALID_ARGUMENT, "iff_surface_sample: the occupancy mask is empty");
-    IFF_HIP(launch_surface_sample_occ(f->dev, f->occ_list, f->n_occ, P, n_epochs, max_iterations, seed, seed_dev_opt, rho, samples, alpha,
-                                      stats, workspace, workspace_bytes, f->n_cus, (hipStream_t)stream));
+    IFF_HIP(launch_surface_sample_occ(f->dev, f->occ_list, f->n_occ, B, P, n_epochs, max_iterations, seed, seed_dev_opt, rho, samples,
+                                      alpha, stats, workspace, workspace_bytes, f->n_cus, (hipStream_t)stream));
     return 0;
 }
 
@@ -482,36 +498,47 @@ extern "C" int iff_attn_logits_folded(const iff_idnet* n, const float* qf, const
 }
 
 extern "C" size_t iff_ray_logits_folded_workspace(const iff_idnet* n, int64_t N, int32_t M) {
-    return (n && N > 0 && M > 0) ? ray_logits_workspace_bytes(n->dev, N, M) : 0;
+    return (n && N > 0 && M > 0) ? ray_logits_workspace_bytes(n->dev, N, M, 1) : 0;
+}
+extern "C" size_t iff_ray_logits_folded_batched_workspace(const iff_idnet* n, int32_t B, int64_t N, int32_t M) {
+    return (n && N > 0 && M > 0 && B > 0) ? ray_logits_workspace_bytes(n->dev, N, M, B) : 0;
+}
+
+static int ray_logits_common(const char* who, const iff_idnet* n, int32_t B, const float* o, const float* d, const float* rgb, int64_t N,
+                             const float* qf, int32_t M, float divisor, float* logits, float* row_max, float* row_sumexp,
+                             void* workspace, size_t workspace_bytes, float* trunk_ms_host, void* stream) {
+    IFF_REQUIRE(n && N >= 0 && M >= 0 && B >= 0, "%s: bad argument", who);
+    if (N == 0 || M == 0 || B == 0) return 0;
+    IFF_REQUIRE(o && d && rgb && qf && logits && workspace, "%s: null buffer", who);
+    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "%s: pass both row statistics or neither", who);
+    if (workspace_bytes < ray_logits_workspace_bytes(n->dev, N, M, B))
+        return fail(IFF_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, ray_logits_workspace_bytes(n->dev, N, M, B));
+    IFF_HIP(launch_ray_logits_folded(n->dev, o, d, rgb, N, qf, M, B, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes,
+                                     trunk_ms_host, (hipStream_t)stream));
+    return 0;
 }
 
 extern "C" int iff_ray_logits_folded(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf,
                                      int32_t M, float divisor, float* logits, float* row_max, float* row_sumexp, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-    IFF_REQUIRE(n && N >= 0 && M >= 0, "iff_ray_logits_folded: bad argument");
-    if (N == 0 || M == 0) return 0;
-    IFF_REQUIRE(o && d && rgb && qf && logits && workspace, "iff_ray_logits_folded: null buffer");
-    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_ray_logits_folded: pass both row statistics or neither");
-    if (workspace_bytes < ray_logits_workspace_bytes(n->dev, N, M))
-        return fail(IFF_ERR_WORKSPACE, "iff_ray_logits_folded: workspace %zu < %zu bytes", workspace_bytes,
-                    ray_logits_workspace_bytes(n->dev, N, M));
-    IFF_HIP(launch_ray_logits_folded(n->dev, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes,
-                                     nullptr, (hipStream_t)stream));
-    return 0;
+    return ray_logits_common("iff_ray_logits_folded", n, 1, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace,
+                             workspace_bytes, nullptr, stream);
+}
+
+extern "C" int iff_ray_logits_folded_batched(const iff_idnet* n, int32_t B, const float* o, const float* d, const float* rgb, int64_t N,
+                                             const float* qf, int32_t M, float divisor, float* logits, float* row_max,
+                                             float* row_sumexp, void* workspace, size_t workspace_bytes, void* stream) {
+    return ray_logits_common("iff_ray_logits_folded_batched", n, B, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp,
+                             workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int iff_ray_logits_folded_timed(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N,
                                            const float* qf, int32_t M, float divisor, float* logits, float* row_max,
                                            float* row_sumexp, void* workspace, size_t workspace_bytes, float* trunk_ms_host,
                                            void* stream) {
-    IFF_REQUIRE(n && N >= 1 && M >= 1 && trunk_ms_host, "iff_ray_logits_folded_timed: bad argument");
-    IFF_REQUIRE(o && d && rgb && qf && logits && workspace, "iff_ray_logits_folded_timed: null buffer");
-    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_ray_logits_folded_timed: pass both row statistics or neither");
-    if (workspace_bytes < ray_logits_workspace_bytes(n->dev, N, M))
-        return fail(IFF_ERR_WORKSPACE, "iff_ray_logits_folded_timed: workspace too small");
-    IFF_HIP(launch_ray_logits_folded(n->dev, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes,
-                                     trunk_ms_host, (hipStream_t)stream));
-    return 0;
+    IFF_REQUIRE(trunk_ms_host && N >= 1 && M >= 1, "iff_ray_logits_folded_timed: bad argument");
+    return ray_logits_common("iff_ray_logits_folded_timed", n, 1, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace,
+                             workspace_bytes, trunk_ms_host, stream);
 }
 
 extern "C" int iff_k_proj(const iff_idnet* n, const float* ray_features, int64_t N, float* k_out, void* stream) {

@@ -490,6 +490,8 @@ struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // 16-
 // tokens beyond M are zero
 __global__ void k_qf_frag(const float* __restrict__ qf, int ld, int M, __bf16* __restrict__ Qf, int n_tb) {
     const int64_t n = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;           // elements per plane
+    qf += (size_t)blockIdx.y * M * ld;                                   // blockIdx.y = query of a batch: qf [B*M][ld]
+    Qf += (size_t)blockIdx.y * 3 * n;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         int i = (int)(t & 7), lane = (int)((t >> 3) & 63), nb = (int)((t >> 9) & 7);
         int rest = (int)(t >> 12);
@@ -513,6 +515,7 @@ __global__ void __launch_bounds__(256) k6_merge_stats(const float2* __restrict__
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= M) return;
+    part += (size_t)blockIdx.y * n_blk * Mpad; row_max += (size_t)blockIdx.y * M; row_sumexp += (size_t)blockIdx.y * M;
     float m = -INFINITY, sacc = 0.0f;
     for (int b = lane; b < n_blk; b += 64) {
         float2 p = part[(size_t)b * Mpad + t];
@@ -545,6 +548,18 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * TR;
+    {   // blockIdx.y = query of a batch: its own rays [N,3], folded query planes, logits [M,N] and partials
+        const size_t qb = blockIdx.y;
+        ray_o += qb * N * 3; ray_d += qb * N * 3; ray_c += qb * N * 3;
+        if (LOGITS) {
+            Qf += qb * (size_t)(Mpad / 256) * (TC / 16) * 3 * 8 * 64;
+            rowc += qb * (size_t)M * rowc_ld;
+            logits += qb * (size_t)M * N;
+            part += qb * (size_t)gridDim.x * Mpad;
+        } else {
+            h3 += qb * N * TC;
+        }
+    }
 
     // encoder input x (ray_preprocessor.py:30-37, tensorBase.py:14-20) straight into LDS as three bf16 planes:
     // x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141 columns, zero-padded to 160; rows beyond N are zero).
@@ -983,43 +998,52 @@ hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, 
 // 3xBF16 mode this is k5_ray_input_planes + k5_trunk<true> (h3 never leaves the CU) + k6_merge_stats; otherwise the
 // layered trunk followed by launch_attn_logits_folded.
 static inline size_t up256z(size_t v) { return (v + 255) & ~(size_t)255; }
-size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M) {
+size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M, int B) {
     const size_t n_tb = (size_t)(M + 255) / 256, n_blk = (size_t)(N + TR - 1) / TR;
-    size_t fused = up256z(n_tb * (TC / 16) * 3 * 8 * 64 * 16) + up256z(n_blk * n_tb * 256 * 8);
+    size_t fused = up256z((size_t)B * n_tb * (TC / 16) * 3 * 8 * 64 * 16) + up256z((size_t)B * n_blk * n_tb * 256 * 8);
     size_t layered = up256z(ray_trunk_workspace_bytes(n, N)) + (size_t)N * n.feature_c * sizeof(float);
     return (fused > layered ? fused : layered) + 256;
 }
 
+// B queries, each with its own ray set and its own M tokens: o, d, rgb [B][N][3], qf [B*M][qf_ld] -> logits [B][M][N],
+// row_max / row_sumexp [B][M].
 hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf,
-                                    int M, float divisor, float* logits, float* row_max, float* row_sumexp, void* ws,
+                                    int M, int B, float divisor, float* logits, float* row_max, float* row_sumexp, void* ws,
                                     size_t ws_bytes, float* trunk_ms_host, hipStream_t s) {
-    if (N == 0 || M == 0) return hipSuccess;
-    if (ws_bytes < ray_logits_workspace_bytes(n, N, M)) return hipErrorInvalidValue;
+    if (N == 0 || M == 0 || B == 0) return hipSuccess;
+    if (ws_bytes < ray_logits_workspace_bytes(n, N, M, B)) return hipErrorInvalidValue;
     const int C = n.feature_c;
     if (!(n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk)) {
-        float* h3 = (float*)((char*)ws + up256z(ray_trunk_workspace_bytes(n, N)));
         if (trunk_ms_host) *trunk_ms_host = -1.0f;        // no fused launch to time in this configuration
-        hipError_t e = launch_ray_trunk(n, o, d, rgb, N, h3, ws, ray_trunk_workspace_bytes(n, N), s);
-        if (e != hipSuccess) return e;
-        return launch_attn_logits_folded(qf, n.qf_ld, h3, M, N, C, divisor, logits, row_max, row_sumexp, s);
+        float* h3 = (float*)((char*)ws + up256z(ray_trunk_workspace_bytes(n, N)));
+        for (int q = 0; q < B; ++q) {
+            hipError_t e = launch_ray_trunk(n, o + (size_t)q * N * 3, d + (size_t)q * N * 3, rgb + (size_t)q * N * 3, N, h3, ws,
+                                            ray_trunk_workspace_bytes(n, N), s);
+            if (e != hipSuccess) return e;
+            e = launch_attn_logits_folded(qf + (size_t)q * M * n.qf_ld, n.qf_ld, h3, M, N, C, divisor, logits + (size_t)q * M * N,
+                                          row_max ? row_max + (size_t)q * M : nullptr, row_sumexp ? row_sumexp + (size_t)q * M : nullptr, s);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
     const int64_t n_blk = (N + TR - 1) / TR;
+    if (B > 65535) return hipErrorInvalidValue;
     char* base = (char*)ws;
     __bf16* Qf = (__bf16*)base;
-    float2* part = (float2*)((char*)Qf + up256z((size_t)n_tb * (TC / 16) * 3 * 8 * 64 * 16));
+    float2* part = (float2*)((char*)Qf + up256z((size_t)B * n_tb * (TC / 16) * 3 * 8 * 64 * 16));
     hipError_t e;
     const int64_t nq = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;
-    hipLaunchKernelGGL(k_qf_frag, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, qf, n.qf_ld, M, Qf, n_tb);
+    hipLaunchKernelGGL(k_qf_frag, dim3((unsigned)((nq + 255) / 256), (unsigned)B), dim3(256), 0, s, qf, n.qf_ld, M, Qf, n_tb);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipEvent_t ev[2] = {nullptr, nullptr};
     if (trunk_ms_host) {
         for (auto& x : ev) if ((e = hipEventCreate(&x)) != hipSuccess) return e;
         (void)hipEventRecord(ev[0], s);
     }
-    hipLaunchKernelGGL(k5_trunk<true>, dim3((unsigned)n_blk), dim3(256), 0, s, o, d, rgb, N, (const uint4*)n.f1, (const uint4*)n.f2,
-                       (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M, divisor, logits,
-                       part, Mpad);
+    hipLaunchKernelGGL(k5_trunk<true>, dim3((unsigned)n_blk, (unsigned)B), dim3(256), 0, s, o, d, rgb, N, (const uint4*)n.f1,
+                       (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M,
+                       divisor, logits, part, Mpad);
     e = hipGetLastError();
     if (trunk_ms_host) {
         (void)hipEventRecord(ev[1], s);
@@ -1030,7 +1054,8 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
     }
     if (e != hipSuccess) return e;
     if (row_max && row_sumexp) {
-        hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, part, (int)n_blk, Mpad, M, row_max, row_sumexp);
+        hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4), (unsigned)B), dim3(256), 0, s, part, (int)n_blk, Mpad, M, row_max,
+                           row_sumexp);
         e = hipGetLastError();
     }
     return e;

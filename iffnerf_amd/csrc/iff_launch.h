@@ -30,7 +30,8 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
 
 // sampler_kernels.hip
 size_t sampler_workspace_bytes(int64_t P);
-hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int64_t P, int n_epochs,
+hipError_t sampler_residency(int64_t P, int n_cus, int* wgs_per_query, int* capacity);
+hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int B, int64_t P, int n_epochs,
                                      int max_iterations, uint64_t seed, const uint64_t* seed_dev, float rho, float* samples,
                                      float* alpha, int* stats, void* ws, size_t ws_bytes, int n_cus, hipStream_t s);
 
@@ -60,9 +61,9 @@ hipError_t launch_ray_encode(const IdNetDev& n, const float* o, const float* d, 
 size_t ray_trunk_workspace_bytes(const IdNetDev& n, int64_t N);
 hipError_t launch_ray_trunk(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, float* h3,
                             void* ws, size_t ws_bytes, hipStream_t s);
-size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M);
+size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M, int B);
 hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf,
-                                    int M, float divisor, float* logits, float* row_max, float* row_sumexp, void* ws,
+                                    int M, int B, float divisor, float* logits, float* row_max, float* row_sumexp, void* ws,
                                     size_t ws_bytes, float* trunk_ms_host, hipStream_t s);
 hipError_t launch_q_fold(const IdNetDev& n, const float* img, int M, float* qf, hipStream_t s);
 hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, int M, int64_t N, int C, float divisor,

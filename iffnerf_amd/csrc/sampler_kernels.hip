@@ -59,7 +59,7 @@ size_t sampler_workspace_bytes(int64_t P) { return align_up(sizeof(SamplerWs), 2
 // maintenance; correct when the only cross-workgroup traffic since the last fenced barrier went through atomics.
 // Spins are bounded: on timeout the abort flag is raised and every workgroup leaves at its next check.
 template <bool FENCED>
-__device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation) {
+__device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation, unsigned n_wg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores and no-return atomics of this wave are complete
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -68,7 +68,7 @@ __device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         generation += 1;
-        const unsigned target = generation * gridDim.x;
+        const unsigned target = generation * n_wg;      // workgroups of THIS query's group
         __hip_atomic_fetch_add(&ws->barrier_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // One agent-scope load per poll and ~0.2 us between polls: these loads are served at the memory side, all from one
         // address, so a tight spin from every workgroup saturates that memory channel and slows every other kernel on
@@ -117,6 +117,8 @@ struct SamplerArgs {
     unsigned char* ws;
     const int* occ_list;   // occupied mask voxel ids (z*H*W + y*W + x), ascending
     int n_occ;
+    int wgs_per_query;     // the grid is B consecutive groups of this many workgroups, one independent sampler each
+    size_t ws_stride;      // bytes between the queries' workspaces
     int cache_lds;         // every workgroup keeps this epoch's alpha [P] and positions [P,3] in LDS (P <= SAMPLER_CACHE_POINTS)
 };
 
@@ -143,12 +145,19 @@ __device__ inline void candidate_position(const SamplerArgs& a, const float base
 
 __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs a) {
     extern __shared__ int s_list[];               // [P] still-invalid sample ids, ascending; then (cache_lds) alpha [P], pos [3P]
-    if (a.seed_dev) {
+    // batch: query q = blockIdx.x / wgs_per_query owns its outputs, its workspace (barrier words, winners) and its seed
+    const int q_id = (int)(blockIdx.x / (unsigned)a.wgs_per_query);
+    const int wg_id = (int)(blockIdx.x - (unsigned)q_id * (unsigned)a.wgs_per_query);
+    {
+        unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) + (unsigned long long)q_id * 0x9E3779B97F4A7C15ull;
         // agent-scope load: a scalar/L1-cached read can be stale when a graph node just before this one rewrote the word
-        unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) +
-                                __hip_atomic_load(a.seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.seed_dev) sd += __hip_atomic_load(a.seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.seed_lo = (uint32_t)(sd & 0xffffffffull); a.seed_hi = (uint32_t)(sd >> 32);
     }
+    a.ws += (size_t)q_id * a.ws_stride;
+    a.samples += (size_t)q_id * a.P * 3;
+    a.alpha += (size_t)q_id * a.P;
+    a.stats += (size_t)q_id * 4 * (a.n_epochs > 0 ? a.n_epochs : 1);
     __shared__ int hist[264];
     __shared__ int s_tot[4];
     SamplerWs* ws = (SamplerWs*)a.ws;
@@ -157,11 +166,11 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
     float* s_alpha = reinterpret_cast<float*>(s_list + P);
     float* s_pos = s_alpha + P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + tid;
-    const int64_t gthreads = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = wg_id * (int64_t)blockDim.x + tid;
+    const int64_t gthreads = (int64_t)a.wgs_per_query * blockDim.x;
     unsigned generation = 0;
 #define IFF_SYNC_OR_ABORT(FENCED)                            \
-    if (!grid_sync<FENCED>(ws, generation)) {                \
+    if (!grid_sync<FENCED>(ws, generation, (unsigned)a.wgs_per_query)) { \
         if (gtid == 0) a.stats[3] = -1; /* timed out */      \
         return;                                              \
     }
@@ -341,19 +350,48 @@ __global__ void k_zero_u64(unsigned long long* p, int64_t n) {
     if (i < n) p[i] = 0ull;
 }
 
-hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int64_t P, int n_epochs,
+// workgroups one sampler run uses at P points, and how many sampler workgroups the device can hold at once (from the
+// kernel's own register / LDS footprint): callers that keep several launches in flight must stay below the second number
+// in total, or the in-kernel barriers of different launches could wait on each other until the spin timeout.
+hipError_t sampler_residency(int64_t P, int n_cus, int* wgs_per_query, int* capacity) {
+    if (P < 1 || P > SAMPLER_MAX_POINTS) return hipErrorInvalidValue;
+    const size_t lds = (size_t)P * sizeof(int) * (P <= SAMPLER_CACHE_POINTS ? 5 : 1);
+    if (lds > 48 * 1024) {
+        hipError_t ea = hipFuncSetAttribute((const void*)k_surface_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
+    }
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_surface_sample, 256, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) return hipErrorInvalidValue;
+    int64_t want = (5 * P * 4 + 255) / 256;
+    *wgs_per_query = (int)(want < 1 ? 1 : (want > n_cus ? n_cus : want));
+    *capacity = per_cu * n_cus;
+    return hipSuccess;
+}
+
+hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int B, int64_t P, int n_epochs,
                                      int max_iterations, uint64_t seed, const uint64_t* seed_dev, float rho, float* samples,
                                      float* alpha, int* stats, void* ws, size_t ws_bytes, int n_cus, hipStream_t s) {
     if (P < 1 || P > SAMPLER_MAX_POINTS || n_epochs < 0 || n_epochs > SAMPLER_MAX_EPOCHS || max_iterations < 0 ||
-        max_iterations > SAMPLER_MAX_ITERS)
+        max_iterations > SAMPLER_MAX_ITERS || B < 1)
         return hipErrorInvalidValue;
-    if (ws_bytes < sampler_workspace_bytes(P)) return hipErrorInvalidValue;
+    const size_t per_query = sampler_workspace_bytes(P);
+    if (ws_bytes < per_query * (size_t)B) return hipErrorInvalidValue;
+    // one group of workgroups per query; all groups must be co-resident (in-kernel barriers)
+    int wgs = 0, capacity = 0;
+    hipError_t e = sampler_residency(P, n_cus, &wgs, &capacity);
+    if (e != hipSuccess) return e;
+    if ((int64_t)wgs * B > capacity) {
+        wgs = capacity / B;
+        if (wgs < 1) return hipErrorInvalidValue;
+    }
     // barrier words + both winner buffers start at zero.  A kernel, not hipMemsetAsync: inside a captured hipGraph the
     // memset node did not reliably precede the sampler on replay (ROCm 7.2) -- the barrier counter then starts from the
     // previous replay's value and the grid barrier lets workgroups through early.
-    const int64_t n_words = (int64_t)(sampler_workspace_bytes(P) / 8);
+    const int64_t n_words = (int64_t)(per_query * (size_t)B / 8);
     hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, (unsigned long long*)ws, n_words);
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     SamplerArgs a;
     a.P = P; a.n_epochs = n_epochs; a.max_iterations = max_iterations;
@@ -361,15 +399,13 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
     a.seed_dev = (const unsigned long long*)seed_dev;
     a.rho = rho; a.samples = samples; a.alpha = alpha; a.stats = stats; a.ws = (unsigned char*)ws;
     a.occ_list = occ_list; a.n_occ = n_occ;
-    // one workgroup per CU at most, so the grid is co-resident and the in-kernel barriers cannot deadlock
-    int64_t want = (5 * P * 4 + 255) / 256;
-    int grid = (int)(want < 1 ? 1 : (want > n_cus ? n_cus : want));
+    a.wgs_per_query = wgs; a.ws_stride = per_query;
     a.cache_lds = P <= SAMPLER_CACHE_POINTS ? 1 : 0;
     const size_t lds = (size_t)P * sizeof(int) * (a.cache_lds ? 5 : 1);
     if (lds > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_surface_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_surface_sample, dim3(grid), dim3(256), lds, s, f, a);
+    hipLaunchKernelGGL(k_surface_sample, dim3((unsigned)(wgs * B)), dim3(256), lds, s, f, a);
     return hipGetLastError();
 }

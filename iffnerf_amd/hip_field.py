@@ -230,6 +230,41 @@ class FieldHandle:
         return samples, alpha, stats
 
 
+SAMPLER_SEED_STRIDE = 0x9E3779B97F4A7C15      # include/iffnerf_hip.h IFF_SAMPLER_SEED_STRIDE
+
+
+def _surface_sample_batched(self, batch: int, n_points: int, rho: float, n_epochs: int = 4, max_iterations: int = 200, seed: int = 0,
+                            seed_offset: Optional[torch.Tensor] = None):
+    """``batch`` independent sampler runs in one launch -> samples [B,P,3], alpha [B,P], stats [B,n_epochs,4].
+    Run b equals ``surface_sample`` with seed + b * SAMPLER_SEED_STRIDE (mod 2^64)."""
+    L = _lib.lib()
+    dev = self.device
+    ws_bytes = int(L.iff_surface_sample_workspace(n_points)) * batch
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    samples = torch.empty(batch, n_points, 3, dtype=torch.float32, device=dev)
+    alpha = torch.empty(batch, n_points, dtype=torch.float32, device=dev)
+    stats = torch.empty(batch, max(n_epochs, 1), 4, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(L.iff_surface_sample_batched(self._h, batch, n_points, n_epochs, max_iterations, int(seed) & (2 ** 64 - 1),
+                                           dptr(seed_offset, torch.int64, "seed_offset"), float(rho), dptr(samples), dptr(alpha),
+                                           dptr(stats, torch.int32), ws.data_ptr(), ws_bytes, stream_ptr(dev)),
+              "iff_surface_sample_batched")
+    return samples, alpha, stats
+
+
+def _sampler_residency(self, n_points: int):
+    """(workgroups one sampler run uses, sampler workgroups the device holds at once) -- see iff_surface_sample_residency."""
+    import ctypes as C
+    w, c = C.c_int32(0), C.c_int32(0)
+    with torch.cuda.device(self.device):
+        check(_lib.lib().iff_surface_sample_residency(self._h, n_points, C.byref(w), C.byref(c)), "iff_surface_sample_residency")
+    return int(w.value), int(c.value)
+
+
+FieldHandle.surface_sample_batched = _surface_sample_batched
+FieldHandle.sampler_residency = _sampler_residency
+
+
 def isocell_emit(cells: torch.Tensor, points: torch.Tensor, normals: torch.Tensor, want_rays6: bool = False):
     """rotate_isocell + renormalise + origin broadcast -> (ori [27P,3], dirs [27P,3]) (+ rays [27P,6] when asked)."""
     if not points.is_cuda:

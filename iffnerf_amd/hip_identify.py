@@ -152,6 +152,26 @@ class IdNetHandle:
                                           stream_ptr(self.device)), "iff_ray_logits_folded")
         return logits, rmax, rsum
 
+    def ray_logits_folded_batched(self, qf, o, d, rgb, batch: int, want_stats: bool = True):
+        """``batch`` queries, each with its own rays: qf [B*M, width], o/d/rgb [B*N, 3] (query-major) ->
+        (logits [B*M, N] = B blocks of [M, N], row_max [B*M], row_sumexp [B*M]) in one launch."""
+        qf = _gpu(qf, "qf")
+        o, d, rgb = _gpu(o, "rays_ori", 3), _gpu(d, "rays_dir", 3), _gpu(rgb, "rays_rgb", 3)
+        if batch < 1 or qf.shape[0] % batch or o.shape[0] % batch or d.shape[0] != o.shape[0] or rgb.shape[0] != o.shape[0]:
+            raise RuntimeError("token rows and ray rows must both be multiples of the batch size")
+        M, N = qf.shape[0] // batch, o.shape[0] // batch
+        L = _lib.lib()
+        logits = qf.new_empty(batch * M, N)
+        rmax = qf.new_empty(batch * M) if want_stats else None
+        rsum = qf.new_empty(batch * M) if want_stats else None
+        ws_bytes = int(L.iff_ray_logits_folded_batched_workspace(self._h, batch, N, M))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=o.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_ray_logits_folded_batched(self._h, batch, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M,
+                                                  float(math.sqrt(self.fea)), dptr(logits), dptr(rmax), dptr(rsum), ws.data_ptr(),
+                                                  ws_bytes, stream_ptr(self.device)), "iff_ray_logits_folded_batched")
+        return logits, rmax, rsum
+
     def k_proj(self, ray_features):
         """k_proj alone, for MultiHeadAttention called with already-encoded rays."""
         x = _gpu(ray_features, "ray_features", self.fea)

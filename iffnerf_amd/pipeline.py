@@ -83,6 +83,36 @@ class PosePipeline:
         ori, dirs, rgb = self.emit(gen_points, seed, seed_offset=seed_offset)
         return self.identify(tokens, ori, dirs, rgb, k, materialize_map)
 
+    # ------------------------------------------------------------------ a batch of cold queries in one set of launches
+    def query_batch(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None):
+        """``tokens`` [B,M,C+14]: B cold queries, each with its OWN freshly drawn ray set, served by one launch per stage
+        (batched sampler, one march over B*27P rays, one encoder/logits launch with grid.y = query, batched score / top-k
+        / pose).  Query b equals ``query(tokens[b], gen_points, seed + b * SAMPLER_SEED_STRIDE)`` bit for bit.
+        -> (c2w [B,4,4], idx [B,k], val [B,k])."""
+        B, M, C = tokens.shape
+        if not self.fold_heads:
+            raise RuntimeError("query_batch runs the folded path (fold_heads=True)")
+        samples, _, stats = self.field.surface_sample_batched(B, gen_points, self.rho, n_epochs=4, max_iterations=200, seed=seed,
+                                                              seed_offset=seed_offset)
+        self.last_sampler_stats = stats
+        ori, dirs, rgb = self.emit_from_samples(samples.reshape(B * gen_points, 3))          # query-major: [B * 27P, 3]
+        qf = self.idnet.q_fold(tokens.reshape(B * M, C))
+        logits, rmax, rsum = self.idnet.ray_logits_folded_batched(qf, ori, dirs, rgb, B)
+        score = H.attn_colsum_batched(logits, rmax, rsum, B, write_attention=False)
+        idx, val = H.topk_batched(score, k)
+        n = ori.shape[0] // B
+        c2w = H.pose_from_topk_batched(idx, val, ori.view(B, n, 3), dirs.view(B, n, 3), self.model_up)
+        return c2w, idx, val
+
+    def max_steps_in_flight(self, gen_points: int, batch: int = 1) -> int:
+        """How many query graphs (each running ``batch`` samplers) may be in flight at once: the persistent sampler's
+        workgroups meet at in-kernel barriers, so the samplers of ALL in-flight graphs must fit on the device together."""
+        wgs, capacity = self.field.sampler_residency(gen_points)
+        return max(1, capacity // max(1, wgs * batch))
+
+    def capture_query_batch(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100) -> "CapturedBatchQuery":
+        return CapturedBatchQuery(self, tokens_shape, gen_points, seed, k)
+
     def capture_query(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100,
                       prefetch_emission: bool = False) -> "CapturedQuery":
         return CapturedQuery(self, tokens_shape, gen_points, seed, k, prefetch_emission)
@@ -256,3 +286,32 @@ class CapturedShardedQuery:
         self._gather(self.cand_all, self.cand)
         self.g3.replay()
         return self.poses
+
+
+class CapturedBatchQuery:
+    """``PosePipeline.query_batch`` captured as one hipGraph: B cold queries per replay.  Static buffers: ``tokens`` [B,M,C]
+    in; ``c2w`` [B,4,4], ``idx`` / ``val`` [B,k] out.  Every replay adds 1 to the device-side seed counter; query b of replay r
+    draws with seed + r + b * SAMPLER_SEED_STRIDE, so no two queries ever share a random stream."""
+
+    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100):
+        dev = pipe.device
+        self.pipe = pipe
+        self.tokens = torch.zeros(tokens_shape, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                 # warm-up outside capture (lazy initialisations, allocator)
+            for _ in range(2):
+                pipe.query_batch(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.counter += 1
+            self.c2w, self.idx, self.val = pipe.query_batch(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+
+    def replay(self, tokens: Optional[torch.Tensor] = None):
+        if tokens is not None:
+            self.tokens.copy_(tokens, non_blocking=True)
+        self.graph.replay()
+        return self.c2w

@@ -158,6 +158,19 @@ size_t iff_surface_sample_workspace(int64_t P);
 int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t max_iterations, uint64_t seed,
                        const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha, int32_t* stats, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* B independent runs of the same process (pose_estimation/sampling.py:509-532) in ONE launch, for batches of cold
+ * queries: run b draws with seed + b * IFF_SAMPLER_SEED_STRIDE (mod 2^64) and is bit-identical to the single call
+ * with that seed.  samples [B,P,3], alpha [B,P], stats [B,n_epochs,4]; workspace B * iff_surface_sample_workspace(P). */
+#define IFF_SAMPLER_SEED_STRIDE 0x9E3779B97F4A7C15ull
+/* The sampler is one persistent launch whose workgroups meet at in-kernel barriers (sampling.py:143-213 is a loop of
+ * data-dependent length), so all of them must be resident together.  wgs_per_run = workgroups of one run at P points;
+ * device_capacity = sampler workgroups the device holds at once (from the kernel's register / LDS footprint).  A
+ * caller that keeps several sampler launches in flight (streams, graphs) must keep
+ * sum(B * wgs_per_run) <= device_capacity; one batched launch clamps itself. */
+int iff_surface_sample_residency(const iff_field* f, int64_t P, int32_t* wgs_per_run, int32_t* device_capacity);
+int iff_surface_sample_batched(const iff_field* f, int32_t B, int64_t P, int32_t n_epochs, int32_t max_iterations,
+                               uint64_t seed, const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha,
+                               int32_t* stats, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------ identification
  * Ray encoder + attention projections (weights of id_module.th, nn.Linear layouts [out,in]).
@@ -218,6 +231,13 @@ size_t iff_ray_logits_folded_workspace(const iff_idnet* net, int64_t N, int32_t 
 int iff_ray_logits_folded(const iff_idnet* net, const float* o, const float* d, const float* rgb, int64_t N,
                           const float* qf, int32_t M, float divisor, float* logits, float* row_max, float* row_sumexp,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* B cold queries at once, each with its own ray set and its own M tokens (the per-image loop of
+ * pose_estimation/test.py:67-91 around identification_module.py:162-165): o,d,rgb [B,N,3], qf [B*M, width] ->
+ * logits [B,M,N], row_max / row_sumexp [B,M].  One launch for the whole batch (grid.y = query). */
+size_t iff_ray_logits_folded_batched_workspace(const iff_idnet* net, int32_t B, int64_t N, int32_t M);
+int iff_ray_logits_folded_batched(const iff_idnet* net, int32_t B, const float* o, const float* d, const float* rgb,
+                                  int64_t N, const float* qf, int32_t M, float divisor, float* logits, float* row_max,
+                                  float* row_sumexp, void* workspace, size_t workspace_bytes, void* stream);
 /* Same call (ray_preprocessor.py:29-38 + multihead_attention.py:6-8), but SYNCHRONOUS and instrumented:
  * trunk_ms_host[1] receives the duration of the fused encoder/logits launch from hipEvents on `stream` (-1 when the
  * configuration has no fused launch).  Measurement aid for bench.py's roofline; not for the timed path. */

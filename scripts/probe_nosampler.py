@@ -49,30 +49,3 @@ for mode in ("full", "no sampler", "sampler only"):
     dt = time.perf_counter() - t0
     print(f"{mode:14s}: {dt / n * 1e6:.1f} us per replay, {n / dt:.0f}/s")
 
-# interference test: 4 streams of "no sampler" queries + one extra stream replaying sampler-only graphs all the time
-def build(mode):
-    counter = torch.zeros(1, dtype=torch.int64, device=dev)
-    gr = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        body(False, counter); pipe.field.surface_sample(593, pipe.rho, 4, 200, seed=1, seed_offset=counter)
-    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
-    with torch.cuda.graph(gr):
-        counter += 1
-        out = body(False, counter) if mode == "q" else pipe.field.surface_sample(593, pipe.rho, 4, 200, seed=1, seed_offset=counter)[0]
-    return gr, out
-qs = [build("q") for _ in range(4)]
-for ns in (0, 1, 2):
-    ss = [build("s") for _ in range(ns)]
-    st_q = [torch.cuda.Stream(dev) for _ in qs]; st_s = [torch.cuda.Stream(dev) for _ in ss]
-    torch.cuda.synchronize()
-    n = 400
-    t0 = time.perf_counter()
-    for i in range(n):
-        with torch.cuda.stream(st_q[i % 4]): qs[i % 4][0].replay()
-        for j in range(ns):
-            if i % 2 == 0:
-                with torch.cuda.stream(st_s[j]): ss[j][0].replay()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(f"4 no-sampler query streams + {ns} independent sampler stream(s): {dt / n * 1e6:.1f} us per query")

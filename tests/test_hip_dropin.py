@@ -160,3 +160,29 @@ def test_prefetching_captured_query(dev):
         assert int(cq.counter.item()) == r
         want = eager[r - 1]
         assert torch.equal(cq.idx, want[1]) and torch.equal(cq.val, want[2]) and torch.equal(cq.c2w, want[0]), r
+
+
+def test_batched_cold_queries_equal_single_queries(dev):
+    """query_batch: B cold queries per set of launches (batched sampler, grid.y = query in the encoder/logits launch).
+    Query b must equal the single-query path with seed + b * SAMPLER_SEED_STRIDE bit for bit; also as a captured graph."""
+    from iffnerf_amd.hip_field import SAMPLER_SEED_STRIDE
+    from iffnerf_amd.pipeline import PosePipeline
+    ck = util.ckpt("small")
+    pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
+    for M in (256, 137):
+        tok = torch.stack([synthetic.make_tokens(M, 384, seed=7 + b) for b in range(3)]).to(dev)
+        c2w, idx, val = pipe.query_batch(tok, 75, seed=900, k=100)
+        assert c2w.shape == (3, 4, 4) and idx.shape == (3, 100)
+        for b in range(3):
+            w_c2w, w_idx, w_val = pipe.query(tok[b], 75, seed=(900 + b * SAMPLER_SEED_STRIDE) % 2 ** 64, k=100)
+            assert torch.equal(idx[b], w_idx) and torch.equal(val[b], w_val) and torch.equal(c2w[b], w_c2w), (M, b)
+    assert not torch.equal(idx[0], idx[1])                      # different draws, different tokens
+    tok = torch.stack([synthetic.make_tokens(256, 384, seed=7 + b) for b in range(4)]).to(dev)
+    eager = {r: [t.clone() for t in pipe.query_batch(tok, 75, seed=900 + r, k=100)] for r in (1, 2)}
+    cq = pipe.capture_query_batch(tok.shape, 75, seed=900, k=100)
+    cq.tokens.copy_(tok)
+    torch.cuda.synchronize()
+    for r in (1, 2):
+        cq.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cq.idx, eager[r][1]) and torch.equal(cq.c2w, eager[r][0])
