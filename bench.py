@@ -187,27 +187,32 @@ def main():
         # ---- per-stage and dominant-kernel timing with events on the launch stream (outside the timed region)
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
         n_rep = 20
-        stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "encoder_logits": 0.0, "score_topk_pose": 0.0}
+        stage_ms = {"sampler": 0.0, "normals_emit": 0.0, "march": 0.0, "encoder_logits": 0.0, "score_topk_pose": 0.0}   # per launch set of QB queries, eager
         march_launch_ms = [0.0, 0.0, 0.0]      # K4a density+compositing, K4b appearance gather, K4c Ref shading
         trunk_ms = []                          # k5_trunk<true>: encoder + logits + softmax partials
         bytes_a = bytes_b = 0.0
         from iffnerf_amd import hip_identify as H
         from iffnerf_amd.hip_field import isocell_emit
+        # the instrumented launches have the shape of the timed region's: QB queries per launch (QB = --batch at N = 1)
+        QB = Q if not sharded else 1
+        tokb = tokens[:QB].reshape(QB * M_TOKENS, -1).contiguous()
         for r in range(n_rep):
             e = [ev() for _ in range(6)]
             e[0].record()
-            samples, _, _ = pipe.field.surface_sample(GEN_POINTS, pipe.rho, 4, 200, seed=5000 + r)
+            samples, _, _ = pipe.field.surface_sample_batched(QB, GEN_POINTS, pipe.rho, 4, 200, seed=5000 + r)
             e[1].record()
+            samples = samples.reshape(QB * GEN_POINTS, 3)
             normals = pipe.field.point_normals(samples)
             ori, dirs, rays = isocell_emit(pipe.cells, samples, normals, want_rays6=True)
             e[2].record()
             rgb = pipe.field.march(rays, 0, 20, want_alpha=False)[0]
             e[3].record()
-            logits, rmax, rsum = pipe.logits(tokens[0], ori, dirs, rgb)     # q_fold + ray_input + fused trunk/logits + stats merge
+            qf = pipe.idnet.q_fold(tokb)
+            logits, rmax, rsum = pipe.idnet.ray_logits_folded_batched(qf, ori, dirs, rgb, QB)   # fused trunk/logits + stats merge
             e[4].record()
-            score = H.attn_colsum(logits, rmax, rsum, write_attention=False)
-            idx, val = H.topk(score, TOPK)
-            H.pose_from_topk(idx, val, ori, dirs, pipe.model_up)
+            score = H.attn_colsum_batched(logits, rmax, rsum, QB, write_attention=False)
+            idx, val = H.topk_batched(score, TOPK)
+            H.pose_from_topk_batched(idx, val, ori.view(QB, -1, 3), dirs.view(QB, -1, 3), pipe.model_up)
             e[5].record()
             torch.cuda.synchronize(device)
             for name, a, b in zip(stage_ms, e[:-1], e[1:]):
@@ -218,12 +223,13 @@ def main():
             counts = pipe.field.march(rays, 0, 20, want_alpha=False, want_counts=True, stage_ms=ms)[4].double().sum(0)
             for i in range(3):
                 march_launch_ms[i] += ms[i] / n_rep
-            pipe.idnet.ray_logits_folded(pipe.idnet.q_fold(tokens[0]), ori, dirs, rgb, trunk_ms=trunk_ms)
+            pipe.idnet.ray_logits_folded_batched(qf, ori, dirs, rgb, QB, trunk_ms=trunk_ms)
             R = rays.shape[0]
             bytes_a += (R * (24 + 8 + 20 * 4) + counts[0].item() * B_VALID) / n_rep           # rays in, acc/depth + weights out
             bytes_b += (R * (24 + 20 * 4 + 28 * 4) + counts[1].item() * B_APP) / n_rep          # rays + weights in, features out
         dom_gbs = bytes_b / (march_launch_ms[1] * 1e-3) / 1e9
-        roofline = {"kernel": "k4b_appearance (appearance gather of TensorBase.forward)", "bound": "hbm",
+        roofline = {"kernel": "k4b_appearance (appearance gather of TensorBase.forward)", "queries_per_launch": QB,
+                    "rays_per_launch": QB * GEN_POINTS * 27, "bound": "hbm",
                     "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": round(bytes_b),
                     "avg_launch_ms": round(march_launch_ms[1], 4),
@@ -234,16 +240,16 @@ def main():
                                       "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4)}}}
         t_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
         if t_ms > 0:
-            tf = trunk_flops(GEN_POINTS * 27, M_TOKENS) / (t_ms * 1e-3) / 1e12
+            tf = QB * trunk_flops(GEN_POINTS * 27, M_TOKENS) / (t_ms * 1e-3) / 1e12
             roofline["other_kernels"]["k5_trunk (ray encoder + attention logits, 3xBF16 MFMA)"] = {
                 "bound": "mfma", "avg_launch_ms": round(t_ms, 4), "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                 "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                 "note": "bf16 MFMA flops issued (6 per fp32-accurate product); = %.1f TFLOP/s of fp32-equivalent work" % (tf / 6)}
         try:   # HBM-side bytes per launch from the committed PMC passes (profiles/README.md), not measured live
-            with open(os.path.join(ROOT, "profiles", "r01v3_hbm_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01v4_hbm_traffic.json")) as fh:
                 pmc = json.load(fh)
                 roofline["traffic"] = pmc["k4b_appearance<27>"]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01v3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction)"
+                roofline["traffic_source"] = "profiles/r01v4_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction)"
                 for name, key in (("k4a_density_composite", "k4a_density_composite"), ("k_ref_shade", "k_ref_shade<27, true>"),
                                   ("k5_trunk (ray encoder + attention logits, 3xBF16 MFMA)", "k5_trunk<true>")):
                     if name in roofline["other_kernels"] and key in pmc:

@@ -83,7 +83,7 @@ SIGNATURES = {
     "iff_ray_logits_folded": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_ray_logits_folded_batched_workspace": (_SZ, [_VP, _I32, _I64, _I32]),
     "iff_ray_logits_folded_batched": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
-    "iff_ray_logits_folded_timed": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, c_float_p, _VP]),
+    "iff_ray_logits_folded_timed": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, c_float_p, _VP]),
     "iff_attn_colsum": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
     "iff_topk_workspace": (_SZ, [_I64, _I32]),
     "iff_topk": (C.c_int, [_VP, _I64, _I32, _VP, _VP, _VP, _SZ, _VP]),

@@ -532,12 +532,12 @@ extern "C" int iff_ray_logits_folded_batched(const iff_idnet* n, int32_t B, cons
                              workspace, workspace_bytes, nullptr, stream);
 }
 
-extern "C" int iff_ray_logits_folded_timed(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N,
+extern "C" int iff_ray_logits_folded_timed(const iff_idnet* n, int32_t B, const float* o, const float* d, const float* rgb, int64_t N,
                                            const float* qf, int32_t M, float divisor, float* logits, float* row_max,
                                            float* row_sumexp, void* workspace, size_t workspace_bytes, float* trunk_ms_host,
                                            void* stream) {
-    IFF_REQUIRE(trunk_ms_host && N >= 1 && M >= 1, "iff_ray_logits_folded_timed: bad argument");
-    return ray_logits_common("iff_ray_logits_folded_timed", n, 1, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace,
+    IFF_REQUIRE(trunk_ms_host && N >= 1 && M >= 1 && B >= 1, "iff_ray_logits_folded_timed: bad argument");
+    return ray_logits_common("iff_ray_logits_folded_timed", n, B, o, d, rgb, N, qf, M, divisor, logits, row_max, row_sumexp, workspace,
                              workspace_bytes, trunk_ms_host, stream);
 }
 

@@ -141,7 +141,7 @@ class IdNetHandle:
         with torch.cuda.device(self.device):
             if trunk_ms is not None:          # synchronous, instrumented variant (bench.py roofline)
                 ms = (C.c_float * 1)()
-                check(L.iff_ray_logits_folded_timed(self._h, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M,
+                check(L.iff_ray_logits_folded_timed(self._h, 1, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M,
                                                     float(math.sqrt(self.fea)), dptr(logits), dptr(rmax), dptr(rsum),
                                                     ws.data_ptr(), ws_bytes, ms, stream_ptr(self.device)),
                       "iff_ray_logits_folded_timed")
@@ -152,7 +152,7 @@ class IdNetHandle:
                                           stream_ptr(self.device)), "iff_ray_logits_folded")
         return logits, rmax, rsum
 
-    def ray_logits_folded_batched(self, qf, o, d, rgb, batch: int, want_stats: bool = True):
+    def ray_logits_folded_batched(self, qf, o, d, rgb, batch: int, want_stats: bool = True, trunk_ms: Optional[list] = None):
         """``batch`` queries, each with its own rays: qf [B*M, width], o/d/rgb [B*N, 3] (query-major) ->
         (logits [B*M, N] = B blocks of [M, N], row_max [B*M], row_sumexp [B*M]) in one launch."""
         qf = _gpu(qf, "qf")
@@ -167,6 +167,14 @@ class IdNetHandle:
         ws_bytes = int(L.iff_ray_logits_folded_batched_workspace(self._h, batch, N, M))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=o.device)
         with torch.cuda.device(self.device):
+            if trunk_ms is not None:          # synchronous, instrumented variant (bench.py roofline)
+                ms = (C.c_float * 1)()
+                check(L.iff_ray_logits_folded_timed(self._h, batch, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M,
+                                                    float(math.sqrt(self.fea)), dptr(logits), dptr(rmax), dptr(rsum),
+                                                    ws.data_ptr(), ws_bytes, ms, stream_ptr(self.device)),
+                      "iff_ray_logits_folded_timed")
+                trunk_ms.append(float(ms[0]))
+                return logits, rmax, rsum
             check(L.iff_ray_logits_folded_batched(self._h, batch, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M,
                                                   float(math.sqrt(self.fea)), dptr(logits), dptr(rmax), dptr(rsum), ws.data_ptr(),
                                                   ws_bytes, stream_ptr(self.device)), "iff_ray_logits_folded_batched")

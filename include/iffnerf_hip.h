@@ -238,10 +238,10 @@ size_t iff_ray_logits_folded_batched_workspace(const iff_idnet* net, int32_t B, 
 int iff_ray_logits_folded_batched(const iff_idnet* net, int32_t B, const float* o, const float* d, const float* rgb,
                                   int64_t N, const float* qf, int32_t M, float divisor, float* logits, float* row_max,
                                   float* row_sumexp, void* workspace, size_t workspace_bytes, void* stream);
-/* Same call (ray_preprocessor.py:29-38 + multihead_attention.py:6-8), but SYNCHRONOUS and instrumented:
+/* The batched call (ray_preprocessor.py:29-38 + multihead_attention.py:6-8), but SYNCHRONOUS and instrumented:
  * trunk_ms_host[1] receives the duration of the fused encoder/logits launch from hipEvents on `stream` (-1 when the
  * configuration has no fused launch).  Measurement aid for bench.py's roofline; not for the timed path. */
-int iff_ray_logits_folded_timed(const iff_idnet* net, const float* o, const float* d, const float* rgb, int64_t N,
+int iff_ray_logits_folded_timed(const iff_idnet* net, int32_t B, const float* o, const float* d, const float* rgb, int64_t N,
                                 const float* qf, int32_t M, float divisor, float* logits, float* row_max,
                                 float* row_sumexp, void* workspace, size_t workspace_bytes, float* trunk_ms_host,
                                 void* stream);
