@@ -1081,8 +1081,20 @@ __global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int
     const int r0 = g * per, r1 = min(M, r0 + per);
     float acc = 0.0f;
     if (j < N) {
-#pragma unroll 8
-        for (int i = r0; i < r1; ++i) {
+        // 16 rows requested before the first is used: with one wave per SIMD the loop is latency-bound otherwise
+        int i = r0;
+        for (; i + 16 <= r1; i += 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = logits[(int64_t)(i + u) * N + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                float a = expf(x[u] - s_stats[i + u]) / s_stats[M + i + u];
+                if (write_attention) logits[(int64_t)(i + u) * N + j] = a;
+                acc += a;
+            }
+        }
+        for (; i < r1; ++i) {
             float a = expf(logits[(int64_t)i * N + j] - s_stats[i]) / s_stats[M + i];
             if (write_attention) logits[(int64_t)i * N + j] = a;
             acc += a;
