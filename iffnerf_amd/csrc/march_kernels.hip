@@ -115,7 +115,8 @@ __device__ inline float z_of(const FieldDev& f, int mode, int S, float t0, int s
 
 // ---- K4a: density gather + alpha compositing.  Writes the per-sample weights for K4b.
 __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchArgs a) {
-    __shared__ float s_sigma[RPB * CH];
+    __shared__ float s_sigma[RPB * CH];   // validity flag per sample (+1 / -1)
+    __shared__ float s_alpha[RPB * CH];
     __shared__ float s_ray[RPB * 8];      // o(3) d(3) t0 last
     const int tid = threadIdx.x;
     const int S = a.S;
@@ -153,16 +154,27 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
                 const float* sr = s_ray + rl * 8;
                 float z = z_of(f, a.mode, S, sr[6], s_base + sl);
                 float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
-                bool valid = live && (ray0 + rl < a.R) && inside_aabb(f, p);
-                if (valid && f.mask) valid = mask_value(f, p) > 0.0f;
-                float part = 0.0f;
-                if (valid) {
+                const bool inside = live && (ray0 + rl < a.R) && inside_aabb(f, p);
+                // the occupancy bytes and the density taps are requested together (both are safe for any coordinate);
+                // the mask decides afterwards which points count -- one memory round trip per pass instead of two
+                float part = 0.0f, mv = 1.0f;
+                if (inside) {
                     float xn[3];
                     field_normalize(f, p, xn);
+                    if (f.mask) mv = mask_value(f, p);
                     part = density_partial(f, xn, lsub);
                 }
-                float feat = sum4(part);
-                if (live && lsub == 0) s_sigma[rl * CH + sl] = valid ? feature2density(f, feat) : -1.0f;  // -1: invalid
+                const bool valid = inside && (mv > 0.0f);
+                float feat = sum4(valid ? part : 0.0f);
+                if (live && lsub == 0) {
+                    // sigma and, already here, alpha (tensorBase.py:25,849): the sequential pass below keeps only the
+                    // transmittance product
+                    const int s = s_base + sl;
+                    float sigma = valid ? feature2density(f, feat) : 0.0f;
+                    float dist = (s + 1 < S) ? (z_of(f, a.mode, S, sr[6], s + 1) - z) : 0.0f;       // tensorBase.py:800-803
+                    s_alpha[rl * CH + sl] = 1.0f - expf(-sigma * (dist * f.distance_scale));
+                    s_sigma[rl * CH + sl] = valid ? 1.0f : -1.0f;                                     // validity flag
+                }
             }
             __syncthreads();
             // ---------------- compositing, one lane per ray
@@ -171,12 +183,9 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
                 int64_t r = ray0 + tid;
                 for (int sl = 0; sl < ns; ++sl) {
                     int s = s_base + sl;
-                    float sg = s_sigma[tid * CH + sl];
-                    bool valid = sg >= 0.0f;
-                    float sigma = valid ? sg : 0.0f;
+                    bool valid = s_sigma[tid * CH + sl] >= 0.0f;
                     float z = z_of(f, a.mode, S, sr[6], s);
-                    float dist = (s + 1 < S) ? (z_of(f, a.mode, S, sr[6], s + 1) - z) : 0.0f;   // tensorBase.py:800-803
-                    float alpha = 1.0f - expf(-sigma * (dist * f.distance_scale));              // tensorBase.py:25,849
+                    float alpha = s_alpha[tid * CH + sl];
                     float w = alpha * run_T;
                     run_T = run_T * ((1.0f - alpha) + 1e-10f);                                   // tensorBase.py:27-32
                     run_acc += w;
