@@ -227,35 +227,49 @@ def main():
             R = rays.shape[0]
             bytes_a += (R * (24 + 8 + 20 * 4) + counts[0].item() * B_VALID) / n_rep           # rays in, acc/depth + weights out
             bytes_b += (R * (24 + 20 * 4 + 28 * 4) + counts[1].item() * B_APP) / n_rep          # rays + weights in, features out
-        dom_gbs = bytes_b / (march_launch_ms[1] * 1e-3) / 1e9
-        roofline = {"kernel": "k4b_appearance (appearance gather of TensorBase.forward)", "queries_per_launch": QB,
-                    "rays_per_launch": QB * GEN_POINTS * 27, "bound": "hbm",
-                    "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
-                    "traffic": None, "algorithmic_bytes_per_launch": round(bytes_b),
-                    "avg_launch_ms": round(march_launch_ms[1], 4),
-                    "note": "tables (71 MB) are Infinity-Cache resident, so the algorithmic rate may exceed the HBM peak; "
-                            "HBM-side bytes from PMC counters are in profiles/",
-                    "other_kernels": {"k4a_density_composite": {"avg_launch_ms": round(march_launch_ms[0], 4),
-                                                                 "achieved_GBps": round(bytes_a / (march_launch_ms[0] * 1e-3) / 1e9, 1)},
-                                      "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4)}}}
-        t_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
-        if t_ms > 0:
-            tf = QB * trunk_flops(GEN_POINTS * 27, M_TOKENS) / (t_ms * 1e-3) / 1e12
-            roofline["other_kernels"]["k5_trunk (ray encoder + attention logits, 3xBF16 MFMA)"] = {
-                "bound": "mfma", "avg_launch_ms": round(t_ms, 4), "achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
-                "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                "note": "bf16 MFMA flops issued (6 per fp32-accurate product); = %.1f TFLOP/s of fp32-equivalent work" % (tf / 6)}
+        # ---- roofline of the dominant kernel (largest share of GPU time in profiles/r01_bench_kernel_stats_v4*.csv):
+        # k5_trunk<true>, the fused ray encoder + attention logits, bound by the bf16 matrix cores.  The two gather
+        # kernels of the march follow in `other_kernels` with their HBM-side view.
         try:   # HBM-side bytes per launch from the committed PMC passes (profiles/README.md), not measured live
             with open(os.path.join(ROOT, "profiles", "r01v4_hbm_traffic.json")) as fh:
                 pmc = json.load(fh)
-                roofline["traffic"] = pmc["k4b_appearance<27>"]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01v4_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction)"
-                for name, key in (("k4a_density_composite", "k4a_density_composite"), ("k_ref_shade", "k_ref_shade<27, true>"),
-                                  ("k5_trunk (ray encoder + attention logits, 3xBF16 MFMA)", "k5_trunk<true>")):
-                    if name in roofline["other_kernels"] and key in pmc:
-                        roofline["other_kernels"][name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        except (OSError, ValueError):
+            pmc = {}
+        traffic = lambda key: pmc.get(key, {}).get("hbm_bytes_per_launch")     # noqa: E731
+        n_rays = QB * GEN_POINTS * 27
+        t_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
+        issued = QB * trunk_flops(GEN_POINTS * 27, M_TOKENS)                    # bf16 MFMA flops the kernel issues
+        tf = issued / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+        # the reference's fp32 chain is 898 048 FLOP per ray for the encoder + 2*384*M for the logits
+        ref_flops = n_rays * (898048.0 + 2.0 * 384.0 * M_TOKENS)
+        dom_gbs = bytes_b / (march_launch_ms[1] * 1e-3) / 1e9
+        roofline = {
+            "kernel": "k5_trunk<true> (ray encoder + attention logits + softmax partials, one launch)",
+            "queries_per_launch": QB, "rays_per_launch": n_rays,
+            "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic("k5_trunk<true>"),
+            "avg_launch_ms": round(t_ms, 4), "flops_per_launch": round(issued),
+            "note": "achieved = bf16 MFMA flops issued / launch time: 12 x 256 x (832 encoder + 256 logits k) per ray, i.e. the "
+                    "folded algorithm (2 x 256 x 1088 = 557 kFLOP per ray) times the 6 bf16 products that make one "
+                    "fp32-accurate product; peak = dense bf16.  The reference's unfolded fp32 chain (SURVEY 8d) would be "
+                    "%.1f GFLOP per launch = %.0f TFLOP/s at this duration (fp32-MFMA peak: 157)"
+                    % (ref_flops / 1e9, ref_flops / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0),
+            "traffic_source": "profiles/r01v4_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction)",
+            "other_kernels": {
+                "k4b_appearance (appearance gather of TensorBase.forward)": {
+                    "bound": "hbm", "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance<27>"),
+                    "algorithmic_bytes_per_launch": round(bytes_b), "avg_launch_ms": round(march_launch_ms[1], 4),
+                    "note": "3456 B per shaded sample (SURVEY 8d) x the kernel's own shaded-sample counter; the tables (71 MB) "
+                            "are Infinity-Cache resident, so the algorithmic rate exceeds the HBM peak while only `traffic` "
+                            "bytes cross the L2's memory side: the kernel is bound by the on-chip gather path and its "
+                            "vector arithmetic, not by HBM"},
+                "k4a_density_composite": {
+                    "bound": "hbm", "achieved": round(bytes_a / (march_launch_ms[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(bytes_a / (march_launch_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "traffic": traffic("k4a_density_composite"), "algorithmic_bytes_per_launch": round(bytes_a),
+                    "avg_launch_ms": round(march_launch_ms[0], 4)},
+                "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>")}}}
         # warm path (rays resident, the reference's eval semantics): stage C only
         ori, dirs, rgb = pipe.emit(GEN_POINTS, seed=42)
         for _ in range(5):
