@@ -235,7 +235,11 @@ def main():
                 pmc = json.load(fh)
         except (OSError, ValueError):
             pmc = {}
-        traffic = lambda key: pmc.get(key, {}).get("hbm_bytes_per_launch")     # noqa: E731
+        def traffic(*keys):
+            for key in keys:
+                if key in pmc:
+                    return pmc[key].get("hbm_bytes_per_launch")
+            return None
         n_rays = QB * GEN_POINTS * 27
         t_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
         issued = QB * trunk_flops(GEN_POINTS * 27, M_TOKENS)                    # bf16 MFMA flops the kernel issues
@@ -258,7 +262,7 @@ def main():
             "other_kernels": {
                 "k4b_appearance (appearance gather of TensorBase.forward)": {
                     "bound": "hbm", "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance<27>"),
+                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance<27, true>", "k4b_appearance<27>"),
                     "algorithmic_bytes_per_launch": round(bytes_b), "avg_launch_ms": round(march_launch_ms[1], 4),
                     "note": "3456 B per shaded sample (SURVEY 8d) x the kernel's own shaded-sample counter; the tables (71 MB) "
                             "are Infinity-Cache resident, so the algorithmic rate exceeds the HBM peak while only `traffic` "

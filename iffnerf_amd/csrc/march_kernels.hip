@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
 // 16 lanes per ray: lanes 0..11 each own one 16-B quarter of the 192-B appearance texels (12 plane*line products per
 // lane), lanes 12..15 shadow lane 11.  Samples are taken in order, so the accumulation is deterministic.  Output: the
 // per-ray feature vector [R][28] (27 features + a "has shaded samples" flag) for K4c.
-template <int APP>
+template <int APP, bool SHORT>
 __global__ void __launch_bounds__(256, 4) k4b_appearance(FieldDev f, MarchArgs a) {
     extern __shared__ __align__(16) float smem[];
     constexpr int NL = 12;                         // n_app / 4 gather lanes per ray
@@ -239,17 +239,39 @@ __global__ void __launch_bounds__(256, 4) k4b_appearance(FieldDev f, MarchArgs a
 #pragma unroll
         for (int i = 0; i < 12; ++i) accp[i] = 0.0f;
         bool any = false;
-        for (int s = 0; s < S; ++s) {
-            float w = live ? a.weights[r * S + s] : 0.0f;
-            if (w > f.weight_thres) {                                                  // tensorBase.py:851
-                any = true;
-                float z = z_of(f, a.mode, S, t0, s);
-                float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z}, xn[3];
-                field_normalize(f, p, xn);
-                float prod[12];
-                app_products_lane(f, xn, c, prod);
+        auto shade_sample = [&](int s, float w) {
+            float z = z_of(f, a.mode, S, t0, s);
+            float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z}, xn[3];
+            field_normalize(f, p, xn);
+            float prod[12];
+            app_products_lane(f, xn, c, prod);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) accp[i] = fmaf(w, prod[i], accp[i]);
+            for (int i = 0; i < 12; ++i) accp[i] = fmaf(w, prod[i], accp[i]);
+        };
+        if (SHORT) {
+            // short rays (S <= 32) (the 20-sample point-centred sampler): the 16 lanes of a ray fetch its weights once (lane l holds
+            // samples l and l + 16), a ballot turns "weight > threshold" (tensorBase.py:851) into a bit mask per ray, and
+            // every ray then visits exactly its shaded samples, in order -- no trip spent on a sample no ray of the wave shades,
+            // no weight load inside the loop
+            const float w_lo = (live && l16 < S) ? a.weights[r * S + l16] : 0.0f;
+            const float w_hi = (live && l16 + 16 < S) ? a.weights[r * S + l16 + 16] : 0.0f;
+            const unsigned long long b_lo = __ballot(w_lo > f.weight_thres), b_hi = __ballot(w_hi > f.weight_thres);
+            const int g0 = (tid & 63) & ~15;                       // first lane of this ray's group inside the wave
+            unsigned mask = (unsigned)((b_lo >> g0) & 0xffffull) | ((unsigned)((b_hi >> g0) & 0xffffull) << 16);
+            any = mask != 0u;
+            while (mask) {
+                const int sidx = __ffs((int)mask) - 1;
+                mask &= mask - 1u;
+                const float v_lo = __shfl(w_lo, g0 + (sidx & 15), 64), v_hi = __shfl(w_hi, g0 + (sidx & 15), 64);
+                shade_sample(sidx, sidx < 16 ? v_lo : v_hi);
+            }
+        } else {
+            for (int s = 0; s < S; ++s) {
+                float w = live ? a.weights[r * S + s] : 0.0f;
+                if (w > f.weight_thres) {                                              // tensorBase.py:851
+                    any = true;
+                    shade_sample(s, w);
+                }
             }
         }
         // basis_mat on the weighted sums: every lane contributes its 12 channels to all APP outputs, xor-butterfly over
@@ -298,7 +320,8 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
     grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
-    hipLaunchKernelGGL((k4b_appearance<27>), dim3((unsigned)grid), dim3(256), lds, s, f, a);
+    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true>), dim3((unsigned)grid), dim3(256), lds, s, f, a);
+    else hipLaunchKernelGGL((k4b_appearance<27, false>), dim3((unsigned)grid), dim3(256), lds, s, f, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);
