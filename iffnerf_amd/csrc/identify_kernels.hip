@@ -706,6 +706,7 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
         write_planes(acc3, b3);           // h3 planes
         __syncthreads();
         const int n_tb = Mpad / 256;
+        const float inv_div = 1.0f / divisor;
         for (int tb = 0; tb < n_tb; ++tb) {
             zero(acc);
             phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, no_t{}, yes_t{}, acc, Qf + (size_t)tb * (KH * 3 * 8 * 64), 0,
@@ -722,7 +723,11 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t ray = row0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        float v = (acc[tg][rg][r] + rc) / divisor;
+                        // (acc + rc) / divisor, correctly rounded, without the ten-instruction division sequence: quotient
+                        // estimate by the (correctly rounded) reciprocal, exact remainder, one correction
+                        const float num = acc[tg][rg][r] + rc;
+                        const float q1 = num * inv_div;
+                        float v = fmaf(fmaf(-q1, divisor, num), inv_div, q1);
                         acc[tg][rg][r] = v;
                         vmax = fmaxf(vmax, ray < N ? v : -INFINITY);
                     }
