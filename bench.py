@@ -46,10 +46,11 @@ def trunk_flops(n_rays, m_tokens):
 B_VALID, B_APP = 32 + 1152, 3456
 
 
-def build_inputs(device):
+def build_inputs(device, grid=300):
     from iffnerf_amd import synthetic
     from iffnerf_amd.pipeline import PosePipeline
-    ck = synthetic.make_field_ckpt(grid=(300, 300, 300), mask_res=(180, 180, 180), seed=1234, step_ratio=0.5, peak=20.0)
+    mask = max(32, int(round(grid * 0.6)))
+    ck = synthetic.make_field_ckpt(grid=(grid, grid, grid), mask_res=(mask, mask, mask), seed=1234, step_ratio=0.5, peak=20.0)
     idw = synthetic.make_id_weights(seed=99)
     pipe = PosePipeline.from_checkpoints(ck, idw, device, model_up=(0.0, 0.0, 1.0))
     return ck, idw, pipe
@@ -92,6 +93,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4, help="cold queries kept in flight on separate streams (N = 1)")
     ap.add_argument("--batch", type=int, default=4,
                     help="cold queries per step at N = 1, each with its own freshly drawn ray set, served by one set of launches")
+    ap.add_argument("--grid", type=int, default=300,
+                    help="side of the synthetic VM grid; 300 is the BASELINE lego-sized model (71 MB of tables, Infinity-Cache "
+                         "resident), 640 a 320 MB model whose gathers go to HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefetch", action="store_true",
                     help="draw the next query's surface points in a parallel branch of each query graph (shorter single-stream "
@@ -120,7 +124,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     from iffnerf_amd import synthetic
-    ck, idw, pipe = build_inputs(device)
+    ck, idw, pipe = build_inputs(device, args.grid)
     sharded = world_size > 1 or args.force_sharded
     Q = world_size if sharded else max(1, args.batch)
     tokens = torch.stack([synthetic.make_tokens(M_TOKENS, 384, seed=7 + q) for q in range(Q)]).to(device)
@@ -289,8 +293,8 @@ def main():
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "lego-shaped TensorVMSplit 300^3 (16/48 comps, 180^3 mask), gen_points=593 -> 16011 rays, "
-                                   "M=256 tokens, top-100, cold path (A+B+C every step)",
+            "config": {"workload": "lego-shaped TensorVMSplit %d^3 (16/48 comps, %d^3 mask), gen_points=593 -> 16011 rays, "
+                                   "M=256 tokens, top-100, cold path (A+B+C every step)" % (args.grid, max(32, int(round(args.grid * 0.6)))),
                        "queries_per_step": Q, "rays_per_query": GEN_POINTS * 27, "steps_in_flight": in_flight,
                        "emissions_per_step": 1 if sharded else Q,
                        "gemm": "3xBF16 split on the bf16 MFMA (fp32-accurate), fp32 accumulate; march and shading in fp32",

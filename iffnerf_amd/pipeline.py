@@ -273,7 +273,8 @@ class CapturedShardedQuery:
     def _gather(self, out, src):
         import torch.distributed as dist
         if self.collective:
-            dist.all_gather_into_tensor(out, src, group=self.group)
+            # `out` is [world, *src.shape]; pass it as the concatenation along dim 0, the form every backend accepts
+            dist.all_gather_into_tensor(out.view((-1,) + tuple(src.shape[1:])), src, group=self.group)
         else:
             out.copy_(src[None])
 

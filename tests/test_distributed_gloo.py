@@ -62,7 +62,22 @@ def _worker(rank, world_size, port, out_dir):
             v, i = torch.topk(score, min(k, score.shape[0]))
             lval[q, :len(v)], lidx[q, :len(v)] = v, i + lo * 27
             pay[q, :len(v), :3], pay[q, :len(v), 3:] = o[i], d[i]
-        val, idx, pay = D.merge_topk(lval, lidx, pay, k)
+        val, idx, pay_m = D.merge_topk(lval, lidx, pay, k)
+        # the packed single-message form the captured segments use (pipeline.CapturedShardedQuery.replay): statistics
+        # and candidates travel through all_gather_into_tensor, indices as int32 bits inside the f32 message
+        stats_local = torch.stack((rmax, rsum), dim=-1).contiguous()
+        stats_all = torch.empty((world_size,) + tuple(stats_local.shape))
+        dist.all_gather_into_tensor(stats_all.view((-1,) + tuple(stats_local.shape[1:])), stats_local)
+        gmax2, gsum2 = D.merge_row_stats_gathered(stats_all)
+        assert torch.equal(gmax2, gmax) and torch.equal(gsum2, gsum)
+        lidx32 = torch.where(lidx >= 2 ** 31, torch.full_like(lidx, 2 ** 31 - 1), lidx)      # pipeline's sentinel for empty slots
+        cand = D.pack_candidates(lval, lidx32, pay)
+        cand_all = torch.empty((world_size,) + tuple(cand.shape))
+        dist.all_gather_into_tensor(cand_all.view((-1,) + tuple(cand.shape[1:])), cand)
+        v2, i2, p2 = D.unpack_candidates(cand_all)
+        val2, idx2, pay2 = D.merge_topk_gathered(v2, i2, p2, k)
+        assert torch.equal(val2, val) and torch.equal(idx2, idx) and torch.equal(pay2, pay_m)
+        pay = pay_m
         counts = [(D.shard_points(P, r, world_size)[1] - D.shard_points(P, r, world_size)[0]) * 27 for r in range(world_size)]
         full = D.gather_scores(torch.stack(scores), counts)
         torch.save({"val": val, "idx": idx, "pay": pay, "full": full}, os.path.join(out_dir, f"rank{rank}.pt"))
