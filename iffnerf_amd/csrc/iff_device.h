@@ -217,6 +217,28 @@ __device__ inline float density_partial(const FieldDev& f, const float xn[3], in
     return acc;
 }
 
+// The whole density feature by ONE lane (the taps of a plane are computed once for all 16 channels instead of once per
+// channel quarter), in the summation order of the 4-lane form: the four quarter partials are formed separately, each
+// over plane 0, 1, 2 in turn, and added the way the xor butterfly of sum4 adds them, (p0 + p1) + (p2 + p3) -- the
+// result is bit-identical to sum4(density_partial(.., sub)).
+__device__ inline float density_full(const FieldDev& f, const float xn[3]) {
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int C = f.n_density;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Taps t;
+        make_taps(f, xn, i, t);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+            for (int ch = 4 * sub; ch < C; ch += 16) {
+                float4 p = lerp_plane4(f.dplane[i], C, t, ch);
+                float4 l = lerp_line4(f.dline[i], C, t, ch);
+                part[sub] = part[sub] + (p.x * l.x + p.y * l.y + p.z * l.z + p.w * l.w);
+            }
+    }
+    return (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // xor-butterfly sum over the 4 lanes that share a point (lanes 4k..4k+3)
 __device__ inline float sum4(float v) {
     v += __shfl_xor(v, 1, 64);

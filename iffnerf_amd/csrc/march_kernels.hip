@@ -17,6 +17,7 @@
 // ~1000-sample slab sampler share the code.
 #include "iff_device.h"
 #include "iff_launch.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ K3
 // 27 iso-cell directions (pose_estimation/isocell.py:6-68, N0=3, isrand=-1) are passed in by the host mirror, which
@@ -114,14 +115,19 @@ __device__ inline float z_of(const FieldDev& f, int mode, int S, float t0, int s
 }
 
 // ---- K4a: density gather + alpha compositing.  Writes the per-sample weights for K4b.
-__global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchArgs a) {
+// LPS = lanes per sample: 4 (each lane one 16-B quarter of every 64-B texel, 16-ray tiles) or 1 (one lane gathers all 16
+// channels: the tap arithmetic, which dominates this kernel's instruction count, is done once per sample instead of
+// four times; 64-ray tiles).  Both produce the same bits (density_full).
+template <int LPS>
+__global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchArgs a, int64_t n_tiles) {
+    constexpr int RPB = LPS == 4 ? 16 : 64;
     __shared__ float s_sigma[RPB * CH];   // validity flag per sample (+1 / -1)
     __shared__ float s_alpha[RPB * CH];
     __shared__ float s_ray[RPB * 8];      // o(3) d(3) t0 last
     const int tid = threadIdx.x;
     const int S = a.S;
     const int n_chunks = (S + CH - 1) / CH;
-    for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t ray0 = tile * RPB;
         __syncthreads();   // previous tile's readers are done with s_ray
         if (tid < RPB) {
@@ -144,12 +150,12 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
         for (int c = 0; c < n_chunks; ++c) {
             const int s_base = c * CH;
             const int ns = min(CH, S - s_base);
-            // ---------------- sigma for RPB x ns points, 4 lanes per point
-            const int n_lane_tasks = RPB * ns * 4;
+            // ---------------- sigma and alpha for RPB x ns points, LPS lanes per point
+            const int n_lane_tasks = RPB * ns * LPS;
             for (int t = tid; t < ((n_lane_tasks + 63) & ~63); t += 256) {
                 bool live = t < n_lane_tasks;
-                int ps = live ? (t >> 2) : 0;
-                int lsub = t & 3;
+                int ps = live ? (t / LPS) : 0;
+                int lsub = t % LPS;
                 int rl = ps / ns, sl = ps - rl * ns;
                 const float* sr = s_ray + rl * 8;
                 float z = z_of(f, a.mode, S, sr[6], s_base + sl);
@@ -162,10 +168,10 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
                     float xn[3];
                     field_normalize(f, p, xn);
                     if (f.mask) mv = mask_value(f, p);
-                    part = density_partial(f, xn, lsub);
+                    part = (LPS == 4) ? density_partial(f, xn, lsub) : density_full(f, xn);
                 }
                 const bool valid = inside && (mv > 0.0f);
-                float feat = sum4(valid ? part : 0.0f);
+                float feat = (LPS == 4) ? sum4(valid ? part : 0.0f) : (valid ? part : 0.0f);
                 if (live && lsub == 0) {
                     // sigma and, already here, alpha (tensorBase.py:25,849): the sequential pass below keeps only the
                     // transmittance product
@@ -313,8 +319,13 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     a.rgb = rgb; a.depth = depth; a.acc = acc; a.alpha = alpha; a.counts = counts; a.weights = (float*)ws; a.feat = (float*)((char*)ws + march_feat_offset(R, S));
     a.n_tiles = (R + RPB - 1) / RPB;
     if (a.n_tiles == 0) return hipSuccess;
-    int64_t grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
-    hipLaunchKernelGGL(k4a_density_composite, dim3((unsigned)grid), dim3(256), 0, s, f, a);
+    // one lane per sample when the density texel is one 64-B line (n_density = 16, every reference config)
+    static const int lps_env = getenv("IFF_K4A_LPS") ? atoi(getenv("IFF_K4A_LPS")) : 0;      // A/B switch for tests
+    const bool one_lane = f.n_density == 16 && lps_env != 4;
+    const int64_t tiles_a = one_lane ? (R + 63) / 64 : a.n_tiles;
+    int64_t grid = tiles_a < 256 * 8 ? tiles_a : 256 * 8;
+    if (one_lane) hipLaunchKernelGGL((k4a_density_composite<1>), dim3((unsigned)grid), dim3(256), 0, s, f, a, tiles_a);
+    else hipLaunchKernelGGL((k4a_density_composite<4>), dim3((unsigned)grid), dim3(256), 0, s, f, a, tiles_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
