@@ -293,6 +293,24 @@ __device__ inline void app_products_lane(const FieldDev& f, const float xn[3], i
     }
 }
 
+// The same for Q consecutive quarters c0 .. c0+Q-1 by one lane: the taps of a plane are computed once for all of them.
+template <int Q>
+__device__ inline void app_products_quads(const FieldDev& f, const float xn[3], int c0, float (&prod)[Q][12]) {
+    const int C = f.n_app;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Taps t;
+        make_taps(f, xn, i, t);
+#pragma unroll
+        for (int cc = 0; cc < Q; ++cc) {
+            float4 p = lerp_plane4(f.aplane[i], C, t, 4 * (c0 + cc));
+            float4 l = lerp_line4(f.aline[i], C, t, 4 * (c0 + cc));
+            prod[cc][4 * i + 0] = p.x * l.x; prod[cc][4 * i + 1] = p.y * l.y;
+            prod[cc][4 * i + 2] = p.z * l.z; prod[cc][4 * i + 3] = p.w * l.w;
+        }
+    }
+}
+
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ inline float softplusf_(float x) { return (x > 20.0f) ? x : log1pf(expf(x)); }
 

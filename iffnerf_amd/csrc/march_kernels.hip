@@ -216,24 +216,31 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
 }
 
 // ---- K4b: appearance gather for the samples that pass the weight threshold, then basis_mat on the weighted sums.
-// 16 lanes per ray: lanes 0..11 each own one 16-B quarter of the 192-B appearance texels (12 plane*line products per
-// lane), lanes 12..15 shadow lane 11.  Samples are taken in order, so the accumulation is deterministic.  Output: the
-// per-ray feature vector [R][28] (27 features + a "has shaded samples" flag) for K4c.
-template <int APP, bool SHORT>
-__global__ void __launch_bounds__(256, 4) k4b_appearance(FieldDev f, MarchArgs a) {
+// A ray is served by a group of G = 16 / Q lanes, 12 / Q of them active; each active lane owns Q consecutive 16-B quarters
+// of the 192-B appearance texels (12 plane*line products per quarter).  Q = 1: 12 lanes per ray, 16 rays per workgroup;
+// Q = 2: 6 lanes, 32 rays; Q = 4: 3 lanes, 64 rays -- the tap arithmetic (which, not the gathers, is most of this
+// kernel's instructions) is done once per lane, so fewer lanes per ray means less of it.  Samples are taken in order and
+// the basis_mat sum keeps the Q = 1 butterfly's pairing at every level, so all forms produce the same bits.
+// Output: the per-ray feature vector [R][28] (27 features + a "has shaded samples" flag) for K4c.
+template <int APP, bool SHORT, int Q>
+__global__ void __launch_bounds__(256, (Q == 1 ? 4 : (Q == 2 ? 2 : 1))) k4b_appearance(FieldDev f, MarchArgs a, int64_t n_tiles) {
     extern __shared__ __align__(16) float smem[];
-    constexpr int NL = 12;                         // n_app / 4 gather lanes per ray
+    constexpr int NL = 12;                         // n_app / 4 texel quarters
+    constexpr int G = 16 / Q;                      // lanes per ray group
+    constexpr int NA = NL / Q;                     // active lanes per group
+    constexpr int RB = 256 / G;                    // rays per workgroup tile
+    constexpr int NW = (32 + G - 1) / G;           // weight registers per lane for S <= 32
     constexpr int LD = (APP + 3) & ~3;
     float* s_basis = smem;                         // [APP][NL][12]
     const int tid = threadIdx.x;
     for (int i = tid; i < APP * NL * 12; i += 256) s_basis[i] = f.basis_l12[i];
     __syncthreads();
     const int S = a.S;
-    const int ray_l = tid >> 4, l16 = tid & 15;
-    const int c = l16 < NL ? l16 : NL - 1;         // lanes 12..15 shadow lane 11's addresses (coalesced away)
-    const float lane_on = l16 < NL ? 1.0f : 0.0f;
-    for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int64_t r = tile * RPB + ray_l;
+    const int ray_l = tid / G, lg = tid % G;
+    const int c0 = (lg < NA ? lg : NA - 1) * Q;    // idle lanes shadow the last active lane's addresses (coalesced away)
+    const float lane_on = lg < NA ? 1.0f : 0.0f;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r = tile * RB + ray_l;
         const bool live = r < a.R;
         float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
         if (live) {
@@ -241,35 +248,49 @@ __global__ void __launch_bounds__(256, 4) k4b_appearance(FieldDev f, MarchArgs a
             o[0] = rp[0]; o[1] = rp[1]; o[2] = rp[2]; d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
         }
         const float t0 = (a.mode == 1) ? slab_entry(f, o, d) : 0.0f;
-        float accp[12];
+        float accp[Q][12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) accp[i] = 0.0f;
+        for (int cc = 0; cc < Q; ++cc)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) accp[cc][i] = 0.0f;
         bool any = false;
         auto shade_sample = [&](int s, float w) {
             float z = z_of(f, a.mode, S, t0, s);
             float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z}, xn[3];
             field_normalize(f, p, xn);
-            float prod[12];
-            app_products_lane(f, xn, c, prod);
+            float prod[Q][12];
+            app_products_quads<Q>(f, xn, c0, prod);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) accp[i] = fmaf(w, prod[i], accp[i]);
+            for (int cc = 0; cc < Q; ++cc)
+#pragma unroll
+                for (int i = 0; i < 12; ++i) accp[cc][i] = fmaf(w, prod[cc][i], accp[cc][i]);
         };
         if (SHORT) {
-            // short rays (S <= 32) (the 20-sample point-centred sampler): the 16 lanes of a ray fetch its weights once (lane l holds
-            // samples l and l + 16), a ballot turns "weight > threshold" (tensorBase.py:851) into a bit mask per ray, and
-            // every ray then visits exactly its shaded samples, in order -- no trip spent on a sample no ray of the wave shades,
-            // no weight load inside the loop
-            const float w_lo = (live && l16 < S) ? a.weights[r * S + l16] : 0.0f;
-            const float w_hi = (live && l16 + 16 < S) ? a.weights[r * S + l16 + 16] : 0.0f;
-            const unsigned long long b_lo = __ballot(w_lo > f.weight_thres), b_hi = __ballot(w_hi > f.weight_thres);
-            const int g0 = (tid & 63) & ~15;                       // first lane of this ray's group inside the wave
-            unsigned mask = (unsigned)((b_lo >> g0) & 0xffffull) | ((unsigned)((b_hi >> g0) & 0xffffull) << 16);
+            // short rays (S <= 32: the 20-sample point-centred sampler): the lanes of a ray fetch its weights once (lane l
+            // holds samples l, l + G, ...), ballots turn "weight > threshold" (tensorBase.py:851) into a bit mask per ray,
+            // and every ray then visits exactly its shaded samples, in order -- no trip spent on a sample no ray of the wave
+            // shades, no weight load inside the loop
+            float wreg[NW];
+            unsigned mask = 0u;
+            const int g0 = (tid & 63) / G * G;                     // first lane of this ray's group inside the wave
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int sj = lg + G * j;
+                wreg[j] = (live && sj < S) ? a.weights[r * S + sj] : 0.0f;
+                const unsigned long long bj = __ballot(wreg[j] > f.weight_thres);
+                mask |= (unsigned)((bj >> g0) & ((1ull << G) - 1ull)) << (G * j);
+            }
             any = mask != 0u;
             while (mask) {
                 const int sidx = __ffs((int)mask) - 1;
                 mask &= mask - 1u;
-                const float v_lo = __shfl(w_lo, g0 + (sidx & 15), 64), v_hi = __shfl(w_hi, g0 + (sidx & 15), 64);
-                shade_sample(sidx, sidx < 16 ? v_lo : v_hi);
+                float w = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const float vj = __shfl(wreg[j], g0 + (sidx % G), 64);
+                    w = (sidx / G == j) ? vj : w;
+                }
+                shade_sample(sidx, w);
             }
         } else {
             for (int s = 0; s < S; ++s) {
@@ -280,20 +301,30 @@ __global__ void __launch_bounds__(256, 4) k4b_appearance(FieldDev f, MarchArgs a
                 }
             }
         }
-        // basis_mat on the weighted sums: every lane contributes its 12 channels to all APP outputs, xor-butterfly over
-        // the 16 lanes of the ray (fixed order)
+        // basis_mat on the weighted sums: quarter c contributes a 12-term fmaf chain to each of the APP outputs; the
+        // quarters are then added pairwise -- inside the lane for its own Q quarters, across the group by xor butterfly
         const float* basis_tile = s_basis;
         asm volatile("" : "+v"(basis_tile));   // opaque per tile: keeps LLVM from hoisting the 324 weight reads out of the tile loop
 #pragma unroll 1
         for (int oo = 0; oo < APP; ++oo) {
-            const float* bl = basis_tile + (oo * NL + c) * 12;
-            float v = 0.0f;
+            float vq[Q];
 #pragma unroll
-            for (int kk = 0; kk < 12; ++kk) v = fmaf(bl[kk], accp[kk], v);
-            v = sum16(v * lane_on);
-            if (l16 == 0 && live) a.feat[r * LD + oo] = v;
+            for (int cc = 0; cc < Q; ++cc) {
+                const float* bl = basis_tile + (oo * NL + c0 + cc) * 12;
+                float v = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < 12; ++kk) v = fmaf(bl[kk], accp[cc][kk], v);
+                vq[cc] = v * lane_on;
+            }
+            float v;
+            if (Q == 1) v = vq[0];
+            else if (Q == 2) v = vq[0] + vq[1];
+            else v = (vq[0] + vq[Q > 1 ? 1 : 0]) + (vq[Q > 2 ? 2 : 0] + vq[Q > 3 ? 3 : 0]);
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (lg == 0 && live) a.feat[r * LD + oo] = v;
         }
-        if (l16 == 0 && live) a.feat[r * LD + APP] = any ? 1.0f : 0.0f;
+        if (lg == 0 && live) a.feat[r * LD + APP] = any ? 1.0f : 0.0f;
     }
 }
 
@@ -331,8 +362,18 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
     grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
-    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true>), dim3((unsigned)grid), dim3(256), lds, s, f, a);
-    else hipLaunchKernelGGL((k4b_appearance<27, false>), dim3((unsigned)grid), dim3(256), lds, s, f, a);
+    // lanes per ray: 12 / Q (see k4b_appearance)
+    static const int q_env = getenv("IFF_K4B_Q") ? atoi(getenv("IFF_K4B_Q")) : 0;         // A/B switch for tests and tuning
+    // measured at 4 x 16 011 rays: Q = 1 221 us (127 VGPR, 4 waves/SIMD), Q = 2 220 us (229 VGPR, 2 waves), Q = 4 349 us:
+    // unlike K4a, the fewer tap computations are paid back in occupancy, so the 12-lane form stays the default
+    const int Qsel = (q_env == 1 || q_env == 2 || q_env == 4) ? q_env : 1;
+    const int rb = 256 / (16 / Qsel);
+    const int64_t tiles_b = (R + rb - 1) / rb;
+    grid = tiles_b < 256 * 8 ? tiles_b : 256 * 8;
+#define IFF_K4B(SH, QQ) hipLaunchKernelGGL((k4b_appearance<27, SH, QQ>), dim3((unsigned)grid), dim3(256), lds, s, f, a, tiles_b)
+    if (S <= 32) { if (Qsel == 1) IFF_K4B(true, 1); else if (Qsel == 2) IFF_K4B(true, 2); else IFF_K4B(true, 4); }
+    else { if (Qsel == 1) IFF_K4B(false, 1); else if (Qsel == 2) IFF_K4B(false, 2); else IFF_K4B(false, 4); }
+#undef IFF_K4B
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);

@@ -192,3 +192,21 @@ def test_one_lane_density_gather_is_bit_identical_to_the_four_lane_form(tmp_path
         assert len(one[k]) == len(four[k]) >= 5
         for x, y in zip(one[k], four[k]):
             assert torch.equal(x, y), k
+
+
+def test_appearance_gather_lane_groupings_are_bit_identical(tmp_path):
+    """K4b with 12, 6 or 3 lanes per ray (IFF_K4B_Q = 1, 2, 4 texel quarters per lane): the per-channel arithmetic is the
+    same and the basis_mat sum keeps the 12-lane butterfly's pairing, so rgb / depth / acc / alpha are equal bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for q in ("1", "2", "4"):
+        path = str(tmp_path / f"q{q}.pt")
+        r = subprocess.run([sys.executable, "-c", _MARCH_DUMP, root, path], capture_output=True, text=True, timeout=600,
+                           env={**os.environ, "IFF_K4B_Q": q})
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(torch.load(path))
+    for other in outs[1:]:
+        for k in outs[0]:
+            for x, y in zip(outs[0][k], other[k]):
+                assert torch.equal(x, y), k
