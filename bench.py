@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W          (N = 1: plain process; N > 1: launched by torch.distributed.run)
 
-Step = one pass of the hot path over one batch of synthetic queries (`--batch`, default 4 query images, EACH with its own
+Step = one pass of the hot path over one batch of synthetic queries (`--batch`, default 16 query images, EACH with its own
 freshly drawn ray set), COLD: every step re-runs for every query of the batch stage A (device-side
 surface sampler + normals + 27-ray fans), stage B (20-sample VM march + Ref shading of every ray) and stage C (ray
 encoder + q/k projections (folded, include/iffnerf_hip.h), softmax over rays, column-sum score, top-100, closed-form pose).  Nothing is cached between
@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--in-flight", type=int, default=4, help="cold queries kept in flight on separate streams (N = 1)")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=16,
                     help="cold queries per step at N = 1, each with its own freshly drawn ray set, served by one set of launches")
     ap.add_argument("--grid", type=int, default=300,
                     help="side of the synthetic VM grid; 300 is the BASELINE lego-sized model (71 MB of tables, Infinity-Cache "

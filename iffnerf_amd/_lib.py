@@ -64,7 +64,7 @@ SIGNATURES = {
     "iff_march_shade_timed": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, c_float_p, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, c_float_p, _VP]),
     "iff_surface_sample_workspace": (_SZ, [_I64]),
     "iff_surface_sample": (C.c_int, [_VP, _I64, _I32, _I32, _U64, _VP, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
-    "iff_surface_sample_residency": (C.c_int, [_VP, _I64, _VP, _VP]),
+    "iff_surface_sample_residency": (C.c_int, [_VP, _I32, _I64, _VP, _VP]),
     "iff_surface_sample_batched": (C.c_int, [_VP, _I32, _I64, _I32, _I32, _U64, _VP, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_idnet_create": (C.c_int, [C.POINTER(IdNetDesc), _VP, C.POINTER(_VP)]),
     "iff_idnet_destroy": (None, [_VP]),

@@ -20,6 +20,7 @@
 #include "iff_device.h"
 #include "iff_launch.h"
 #include "iff_select.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 struct U4 { uint32_t x, y, z, w; };
@@ -94,6 +95,18 @@ __device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation, unsigned n
 
 // alpha = compute_alpha(p, length=1) by the 4 lanes that share the point (all 4 return it).  The occupancy test and the
 // density taps are issued together (both are safe for any coordinate); the result is selected afterwards.
+// alpha by ONE lane (density_full: taps once for all 16 channels, the 4-lane form's summation order -- same bits).
+// Used when n_density == 16; LPC = lanes per candidate is then 1 and a run needs a quarter of the workgroups.
+__device__ inline float alpha1(const FieldDev& f, const float p[3], bool live) {
+    float xn[3];
+    field_normalize(f, p, xn);
+    float mv = f.mask ? mask_value(f, p) : 1.0f;
+    float part = density_full(f, xn);
+    bool valid = live && (mv > 0.0f);
+    float sigma = valid ? feature2density(f, valid ? part : 0.0f) : 0.0f;
+    return 1.0f - expf(-sigma * 1.0f);
+}
+
 __device__ inline float alpha4(const FieldDev& f, const float p[3], int sub, bool live) {
     float xn[3];
     field_normalize(f, p, xn);
@@ -119,6 +132,7 @@ struct SamplerArgs {
     int n_occ;
     int wgs_per_query;     // the grid is B consecutive groups of this many workgroups, one independent sampler each
     size_t ws_stride;      // bytes between the queries' workspaces
+    int lpc;               // lanes per candidate / point: 4 (one texel quarter each) or 1 (n_density == 16)
     int cache_lds;         // every workgroup keeps this epoch's alpha [P] and positions [P,3] in LDS (P <= SAMPLER_CACHE_POINTS)
 };
 
@@ -169,6 +183,7 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
     const int64_t gtid = wg_id * (int64_t)blockDim.x + tid;
     const int64_t gthreads = (int64_t)a.wgs_per_query * blockDim.x;
     unsigned generation = 0;
+    const int lpc = a.lpc, lsh = (a.lpc == 4) ? 2 : 0;
 #define IFF_SYNC_OR_ABORT(FENCED)                            \
     if (!grid_sync<FENCED>(ws, generation, (unsigned)a.wgs_per_query)) { \
         if (gtid == 0) a.stats[3] = -1; /* timed out */      \
@@ -179,11 +194,11 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
     // ---------------- seeds (sampling.py:78-116,131-140)
     {
         const int W = f.mask_dims[2], H = f.mask_dims[1], D = f.mask_dims[0];
-        const int64_t nt = (int64_t)P * 4;
+        const int64_t nt = (int64_t)P * lpc;
         for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
             bool live = t < nt;
-            int i = live ? (int)(t >> 2) : 0;
-            int sub = (int)(t & 3);
+            int i = live ? (int)(t >> lsh) : 0;
+            int sub = (int)(t & (lpc - 1));
             U4 r = philox4x32_10(U4{(uint32_t)i, 0u, 0u, 0x5eedu}, a.seed_lo, a.seed_hi);
             float p[3];
             if (f.mask && a.n_occ > 0) {
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) p[c] = u[c] * (f.aabb_hi[c] - f.aabb_lo[c]) + f.aabb_lo[c];
             }
-            float al = alpha4(f, p, sub, live);
+            float al = (lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live);
             if (live && sub == 0) {
                 a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
                 a.alpha[i] = al;
@@ -265,18 +280,18 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
             // ---------------- candidates: m per invalid sample, 4 lanes each
             const int m = (5 * P) / K;
             m_last = m;
-            const int64_t nt = (int64_t)K * m * 4;
+            const int64_t nt = (int64_t)K * m * lpc;
             for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
                 bool live = t < nt;
-                int64_t slot = live ? (t >> 2) : 0;
-                int sub = (int)(t & 3);
+                int64_t slot = live ? (t >> lsh) : 0;
+                int sub = (int)(t & (lpc - 1));
                 int li = (int)(slot / m), j = (int)(slot - (int64_t)li * m);
                 int i = s_list[li];
                 const float* ps = a.cache_lds ? s_pos : a.samples;
                 float base[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]}, p[3];
                 uint32_t prio;
                 candidate_position(a, base, i, j, epoch, it, p, prio);
-                float al = alpha4(f, p, sub, live);
+                float al = (lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live);
                 if (live && sub == 0 && al > thresh) {
                     unsigned long long key = ((unsigned long long)prio << 32) | ((unsigned long long)it << 20) |
                                              (unsigned long long)(unsigned)(j + 1);
@@ -312,11 +327,11 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
         }
         // ---------------- apply: the accepted samples move to their winning candidate (re-derived from the stream)
         {
-            const int64_t nt = (int64_t)P * 4;
+            const int64_t nt = (int64_t)P * lpc;
             for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
                 bool live = t < nt;
-                int i = live ? (int)(t >> 2) : 0;
-                int sub = (int)(t & 3);
+                int i = live ? (int)(t >> lsh) : 0;
+                int sub = (int)(t & (lpc - 1));
                 unsigned long long wv = live ? __hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 bool moved = wv != 0ull;
                 int j = (int)(wv & 0xfffffull) - 1, wit = (int)((wv >> 20) & 0xfffull);
@@ -324,7 +339,7 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
                 float base[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]}, p[3];
                 uint32_t prio;
                 candidate_position(a, base, i, moved ? j : 0, epoch, wit, p, prio);
-                float al = alpha4(f, p, sub, live && moved);
+                float al = (lpc == 1) ? alpha1(f, p, live && moved) : alpha4(f, p, sub, live && moved);
                 if (live && sub == 0) {
                     if (moved) {
                         a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
@@ -353,7 +368,19 @@ __global__ void k_zero_u64(unsigned long long* p, int64_t n) {
 // workgroups one sampler run uses at P points, and how many sampler workgroups the device can hold at once (from the
 // kernel's own register / LDS footprint): callers that keep several launches in flight must stay below the second number
 // in total, or the in-kernel barriers of different launches could wait on each other until the spin timeout.
-hipError_t sampler_residency(int64_t P, int n_cus, int* wgs_per_query, int* capacity) {
+// lanes per candidate.  Both forms draw the same samples bit for bit; they trade latency for footprint.  Four lanes (one
+// texel quarter each): 47 workgroups per run at P = 593, 245 us -- best for single queries and small batches.  One lane
+// (needs a density texel of one 64-B line, i.e. n_density = 16): 12 workgroups per run, 340 us -- four times as many runs
+// fit on the device at once, which is what large batches in flight need (measured: 16 queries per launch x 4 launches in
+// flight 6790 poses/s against 6190 for the best four-lane configuration).  IFF_SAMPLER_LPC = 1 | 4 forces a form (A/B tests).
+int sampler_lpc(const FieldDev& f, int B) {
+    static const int lpc_env = getenv("IFF_SAMPLER_LPC") ? atoi(getenv("IFF_SAMPLER_LPC")) : 0;
+    if (f.n_density != 16 || lpc_env == 4) return 4;
+    if (lpc_env == 1) return 1;
+    return B >= 8 ? 1 : 4;
+}
+
+hipError_t sampler_residency(int64_t P, int n_cus, int lpc, int* wgs_per_query, int* capacity) {
     if (P < 1 || P > SAMPLER_MAX_POINTS) return hipErrorInvalidValue;
     const size_t lds = (size_t)P * sizeof(int) * (P <= SAMPLER_CACHE_POINTS ? 5 : 1);
     if (lds > 48 * 1024) {
@@ -364,7 +391,7 @@ hipError_t sampler_residency(int64_t P, int n_cus, int* wgs_per_query, int* capa
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_surface_sample, 256, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) return hipErrorInvalidValue;
-    int64_t want = (5 * P * 4 + 255) / 256;
+    int64_t want = (5 * P * lpc + 255) / 256;
     *wgs_per_query = (int)(want < 1 ? 1 : (want > n_cus ? n_cus : want));
     *capacity = per_cu * n_cus;
     return hipSuccess;
@@ -380,7 +407,8 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
     if (ws_bytes < per_query * (size_t)B) return hipErrorInvalidValue;
     // one group of workgroups per query; all groups must be co-resident (in-kernel barriers)
     int wgs = 0, capacity = 0;
-    hipError_t e = sampler_residency(P, n_cus, &wgs, &capacity);
+    const int lpc = sampler_lpc(f, B);
+    hipError_t e = sampler_residency(P, n_cus, lpc, &wgs, &capacity);
     if (e != hipSuccess) return e;
     if ((int64_t)wgs * B > capacity) {
         wgs = capacity / B;
@@ -399,7 +427,7 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
     a.seed_dev = (const unsigned long long*)seed_dev;
     a.rho = rho; a.samples = samples; a.alpha = alpha; a.stats = stats; a.ws = (unsigned char*)ws;
     a.occ_list = occ_list; a.n_occ = n_occ;
-    a.wgs_per_query = wgs; a.ws_stride = per_query;
+    a.wgs_per_query = wgs; a.ws_stride = per_query; a.lpc = lpc;
     a.cache_lds = P <= SAMPLER_CACHE_POINTS ? 1 : 0;
     const size_t lds = (size_t)P * sizeof(int) * (a.cache_lds ? 5 : 1);
     if (lds > 48 * 1024) {

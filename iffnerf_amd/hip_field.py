@@ -252,12 +252,14 @@ def _surface_sample_batched(self, batch: int, n_points: int, rho: float, n_epoch
     return samples, alpha, stats
 
 
-def _sampler_residency(self, n_points: int):
-    """(workgroups one sampler run uses, sampler workgroups the device holds at once) -- see iff_surface_sample_residency."""
+def _sampler_residency(self, n_points: int, batch: int = 1):
+    """(workgroups one sampler run uses inside a launch of ``batch`` runs, sampler workgroups the device holds at once)
+    -- see iff_surface_sample_residency."""
     import ctypes as C
     w, c = C.c_int32(0), C.c_int32(0)
     with torch.cuda.device(self.device):
-        check(_lib.lib().iff_surface_sample_residency(self._h, n_points, C.byref(w), C.byref(c)), "iff_surface_sample_residency")
+        check(_lib.lib().iff_surface_sample_residency(self._h, batch, n_points, C.byref(w), C.byref(c)),
+              "iff_surface_sample_residency")
     return int(w.value), int(c.value)
 
 

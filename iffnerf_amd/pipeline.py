@@ -107,7 +107,7 @@ class PosePipeline:
     def max_steps_in_flight(self, gen_points: int, batch: int = 1) -> int:
         """How many query graphs (each running ``batch`` samplers) may be in flight at once: the persistent sampler's
         workgroups meet at in-kernel barriers, so the samplers of ALL in-flight graphs must fit on the device together."""
-        wgs, capacity = self.field.sampler_residency(gen_points)
+        wgs, capacity = self.field.sampler_residency(gen_points, batch)
         return max(1, capacity // max(1, wgs * batch))
 
     def capture_query_batch(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100) -> "CapturedBatchQuery":

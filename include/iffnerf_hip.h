@@ -163,11 +163,12 @@ int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t 
  * with that seed.  samples [B,P,3], alpha [B,P], stats [B,n_epochs,4]; workspace B * iff_surface_sample_workspace(P). */
 #define IFF_SAMPLER_SEED_STRIDE 0x9E3779B97F4A7C15ull
 /* The sampler is one persistent launch whose workgroups meet at in-kernel barriers (sampling.py:143-213 is a loop of
- * data-dependent length), so all of them must be resident together.  wgs_per_run = workgroups of one run at P points;
- * device_capacity = sampler workgroups the device holds at once (from the kernel's register / LDS footprint).  A
- * caller that keeps several sampler launches in flight (streams, graphs) must keep
- * sum(B * wgs_per_run) <= device_capacity; one batched launch clamps itself. */
-int iff_surface_sample_residency(const iff_field* f, int64_t P, int32_t* wgs_per_run, int32_t* device_capacity);
+ * data-dependent length), so all of them must be resident together.  wgs_per_run = workgroups of one run at P points
+ * inside a launch of B runs (large batches use a form with a quarter of the workgroups per run); device_capacity =
+ * sampler workgroups the device holds at once (from the kernel's register / LDS footprint).  A caller that keeps
+ * several sampler launches in flight (streams, graphs) must keep sum(B * wgs_per_run) <= device_capacity; one batched
+ * launch clamps itself. */
+int iff_surface_sample_residency(const iff_field* f, int32_t B, int64_t P, int32_t* wgs_per_run, int32_t* device_capacity);
 int iff_surface_sample_batched(const iff_field* f, int32_t B, int64_t P, int32_t n_epochs, int32_t max_iterations,
                                uint64_t seed, const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha,
                                int32_t* stats, void* workspace, size_t workspace_bytes, void* stream);
