@@ -235,7 +235,7 @@ def main():
         # k5_trunk<true>, the fused ray encoder + attention logits, bound by the bf16 matrix cores.  The two gather
         # kernels of the march follow in `other_kernels` with their HBM-side view.
         try:   # HBM-side bytes per launch from the committed PMC passes (profiles/README.md), not measured live
-            with open(os.path.join(ROOT, "profiles", "r01v4_hbm_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01v5_hbm_traffic.json")) as fh:
                 pmc = json.load(fh)
         except (OSError, ValueError):
             pmc = {}
@@ -262,11 +262,11 @@ def main():
                     "fp32-accurate product; peak = dense bf16.  The reference's unfolded fp32 chain (SURVEY 8d) would be "
                     "%.1f GFLOP per launch = %.0f TFLOP/s at this duration (fp32-MFMA peak: 157)"
                     % (ref_flops / 1e9, ref_flops / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0),
-            "traffic_source": "profiles/r01v4_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction)",
+            "traffic_source": "profiles/r01v5_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2x FETCH correction)",
             "other_kernels": {
                 "k4b_appearance (appearance gather of TensorBase.forward)": {
                     "bound": "hbm", "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance<27, true>", "k4b_appearance<27>"),
+                    "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance<27, true, 1>", "k4b_appearance<27, true>", "k4b_appearance<27>"),
                     "algorithmic_bytes_per_launch": round(bytes_b), "avg_launch_ms": round(march_launch_ms[1], 4),
                     "note": "3456 B per shaded sample (SURVEY 8d) x the kernel's own shaded-sample counter; the tables (71 MB) "
                             "are Infinity-Cache resident, so the algorithmic rate exceeds the HBM peak while only `traffic` "
@@ -275,7 +275,7 @@ def main():
                 "k4a_density_composite": {
                     "bound": "hbm", "achieved": round(bytes_a / (march_launch_ms[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(bytes_a / (march_launch_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "traffic": traffic("k4a_density_composite"), "algorithmic_bytes_per_launch": round(bytes_a),
+                    "traffic": traffic("k4a_density_composite<1>", "k4a_density_composite"), "algorithmic_bytes_per_launch": round(bytes_a),
                     "avg_launch_ms": round(march_launch_ms[0], 4)},
                 "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>")}}}
         # warm path (rays resident, the reference's eval semantics): stage C only
