@@ -222,8 +222,11 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
 // kernel's instructions) is done once per lane, so fewer lanes per ray means less of it.  Samples are taken in order and
 // the basis_mat sum keeps the Q = 1 butterfly's pairing at every level, so all forms produce the same bits.
 // Output: the per-ray feature vector [R][28] (27 features + a "has shaded samples" flag) for K4c.
+#ifndef K4B_WAVES
+#define K4B_WAVES 4
+#endif
 template <int APP, bool SHORT, int Q>
-__global__ void __launch_bounds__(256, (Q == 1 ? 4 : (Q == 2 ? 2 : 1))) k4b_appearance(FieldDev f, MarchArgs a, int64_t n_tiles) {
+__global__ void __launch_bounds__(256, (Q == 1 ? K4B_WAVES : (Q == 2 ? 2 : 1))) k4b_appearance(FieldDev f, MarchArgs a, int64_t n_tiles) {
     extern __shared__ __align__(16) float smem[];
     constexpr int NL = 12;                         // n_app / 4 texel quarters
     constexpr int G = 16 / Q;                      // lanes per ray group
