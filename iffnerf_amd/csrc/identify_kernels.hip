@@ -417,6 +417,9 @@ static hipError_t gemm_bf3(const float* A1, int lda1, int K1, const float* A2, i
 // LDS stores and h3 with 16-byte global stores.  The x-part of layer 3 is accumulated together with layer 1 (both read
 // x), which lets h1/h2 reuse x's LDS: 99 KiB, one workgroup (4 waves) per CU, two barriers per layer boundary and none
 // inside the k loops.  Per launch at 16 011 rays: 251 workgroups, 52 k-steps x 24 MFMA per wave.
+#ifndef TRUNK_FG
+#define TRUNK_FG 1
+#endif
 constexpr int TR = 64;            // rays per workgroup
 constexpr int SLD = 264;          // bf16 per LDS row: 256 + 8 -> 528 B, an odd multiple of 16 B (conflict-free 16-B reads)
 constexpr int TC = 256;           // feature_c this kernel is built for
@@ -440,22 +443,27 @@ hipError_t launch_frag_order(const void* Wp, void* Wf, int Kp, hipStream_t s) {
     return hipGetLastError();
 }
 
-struct WFrag { bf16x8 p[2][3]; };      // [feature group][plane]
+// FG = 32-feature groups per wave: 2 -> four waves of 64 features (256 threads), 1 -> eight waves of 32 features (512
+// threads, two waves per SIMD: the non-MFMA phases -- encoder input, plane writes, logits epilogue -- are spread over
+// twice the waves and one wave's waits hide behind the other's MFMAs).  Same arithmetic per output element either way.
+template <int FG> struct WFrag { bf16x8 p[FG][3]; };      // [feature group][plane]
 
-__device__ inline void trunk_load_w(WFrag& w, const uint4* __restrict__ Wf, int ks, int wave, int lane) {
+template <int FG>
+__device__ inline void trunk_load_w(WFrag<FG>& w, const uint4* __restrict__ Wf, int ks, int wave, int lane) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int fg = 0; fg < 2; ++fg) {
-            uint4 v = Wf[(((size_t)ks * 3 + pl) * 8 + 2 * wave + fg) * 64 + lane];
+        for (int fg = 0; fg < FG; ++fg) {
+            uint4 v = Wf[(((size_t)ks * 3 + pl) * 8 + FG * wave + fg) * 64 + lane];
             w.p[fg][pl] = *reinterpret_cast<bf16x8*>(&v);
         }
 }
 
 // acc[fg][rg] += W(fg) * act(rg) over one 16-wide k-step, six bf16 products per tile, smallest contributions first
-__device__ inline void trunk_mfma(f32x16 (&acc)[2][2], const WFrag& w, const bf16x8 (&a)[2][3]) {
+template <int FG>
+__device__ inline void trunk_mfma(f32x16 (&acc)[FG][2], const WFrag<FG>& w, const bf16x8 (&a)[2][3]) {
 #pragma unroll
-    for (int fg = 0; fg < 2; ++fg)
+    for (int fg = 0; fg < FG; ++fg)
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
             acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p[fg][2], a[rg][0], acc[fg][rg], 0, 0, 0);
@@ -469,9 +477,10 @@ __device__ inline void trunk_mfma(f32x16 (&acc)[2][2], const WFrag& w, const bf1
 
 // acc[tg][rg] += act(rg) * Q(tg): rows = rays, columns = tokens (the logits tile; operands swapped so that the softmax
 // reduction over rays runs down a lane's registers instead of across lanes)
-__device__ inline void trunk_mfma_t(f32x16 (&acc)[2][2], const WFrag& w, const bf16x8 (&a)[2][3]) {
+template <int FG>
+__device__ inline void trunk_mfma_t(f32x16 (&acc)[FG][2], const WFrag<FG>& w, const bf16x8 (&a)[2][3]) {
 #pragma unroll
-    for (int tg = 0; tg < 2; ++tg)
+    for (int tg = 0; tg < FG; ++tg)
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
             acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rg][0], w.p[tg][2], acc[tg][rg], 0, 0, 0);
@@ -535,8 +544,8 @@ __global__ void __launch_bounds__(256) k6_merge_stats(const float2* __restrict__
 // LOGITS = false: h3 [N][256] out.  LOGITS = true: h3 stays in LDS and is multiplied with the folded query planes Qf
 // ("layer 4", multihead_attention.py:6-7 folded): logits [M][N] = (qf[:, :256] h3^T + qf[:, 256]) / divisor out, plus
 // this workgroup's softmax partials (max, sum exp over its 64 rays) per token.
-template <bool LOGITS>
-__global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+template <bool LOGITS, int FG>
+__global__ void __launch_bounds__(FG == 2 ? 256 : 512) k5_trunk(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                 const float* __restrict__ ray_c, int64_t N, const uint4* __restrict__ Wf1,
                                                 const uint4* __restrict__ Wf2, const uint4* __restrict__ Wf3,
                                                 const float* __restrict__ b1, const float* __restrict__ b2,
@@ -583,21 +592,29 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
             src[3 + c] = ok ? ray_d[3 * gr + c] : 0.0f;
             src[6 + c] = ok ? ray_c[3 * gr + c] : 0.0f;
         }
-        for (int item = tid >> 6; item < 94; item += 4) {            // wave-uniform item -> no divergence
+        for (int item = tid >> 6; item < 94; item += 8 / FG) {       // wave-uniform item -> no divergence
             if (item < 66) {
                 // blocks: PE(o) at column 9, PE(d) at 57, PE(rgb) at 105; each [sin (F*3) | cos (F*3)], component-major
                 int blk = item < 24 ? 0 : (item < 48 ? 1 : 2);
                 int b = item - 24 * blk;
                 int F = blk == 2 ? 6 : 8;
                 int j = b / F, k = b - j * F;
-                float arg = src[3 * blk + j] * (float)(1 << k);
+                // select instead of src[3 * blk + j]: a dynamically indexed local array would live in scratch memory
+                const float c0 = blk == 0 ? src[0] : (blk == 1 ? src[3] : src[6]);
+                const float c1 = blk == 0 ? src[1] : (blk == 1 ? src[4] : src[7]);
+                const float c2 = blk == 0 ? src[2] : (blk == 1 ? src[5] : src[8]);
+                float arg = (j == 0 ? c0 : (j == 1 ? c1 : c2)) * (float)(1 << k);
                 float sv, cv;
                 sincosf(arg, &sv, &cv);               // one argument reduction for both columns
                 int col = 9 + 48 * blk + b;
                 put(ray, col, sv);
                 put(ray, col + 3 * F, cv);
             } else if (item < 75) {
-                put(ray, item - 66, src[item - 66]);
+                const int ci = item - 66;
+                float rv = src[0];
+#pragma unroll
+                for (int u = 1; u < 9; ++u) rv = (ci == u) ? src[u] : rv;
+                put(ray, ci, rv);
             } else {
                 put(ray, 141 + (item - 75), 0.0f);
             }
@@ -612,12 +629,12 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
             for (int pl = 0; pl < 3; ++pl) a[rg][pl] = *reinterpret_cast<const bf16x8*>(&S[pl][32 * rg + lr][16 * ks + 8 * lh]);
     };
     // relu(acc + bias) -> three bf16 planes of this wave's 64 features for all 64 rays
-    auto write_planes = [&](const f32x16 (&acc)[2][2], const float* __restrict__ bias) {
+    auto write_planes = [&](const f32x16 (&acc)[FG][2], const float* __restrict__ bias) {
 #pragma unroll
-        for (int fg = 0; fg < 2; ++fg)
+        for (int fg = 0; fg < FG; ++fg)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int f0 = 64 * wave + 32 * fg + 8 * q + 4 * lh;          // features f0..f0+3 <- registers 4q..4q+3
+                const int f0 = 32 * FG * wave + 32 * fg + 8 * q + 4 * lh;     // features f0..f0+3 <- registers 4q..4q+3
                 const float4 bv = *reinterpret_cast<const float4*>(bias + f0);
                 const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
@@ -638,27 +655,27 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
                 }
             }
     };
-    auto zero = [](f32x16 (&acc)[2][2]) {
+    auto zero = [](f32x16 (&acc)[FG][2]) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < FG; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     };
 
-    f32x16 acc[2][2], acc3[2][2];
+    f32x16 acc[FG][2], acc3[FG][2];
     zero(acc); zero(acc3);
     constexpr int KX = XW / 16, KH = TC / 16;
 
     // One k loop, software-pipelined in registers: the weight fragments of k-step ks + DEPTH - 1 are requested before
     // k-step ks is multiplied (an L2 hit under load takes longer than one k-step's 24 MFMAs).  DUAL: two weight streams
     // over the same activations (layer 1 and the x-part of layer 3).
-    auto phase = [&](auto nk_c, auto depth_c, auto dual_c, auto swap_c, f32x16 (&accA)[2][2], const uint4* __restrict__ WA,
-                     int ksA, f32x16 (&accB)[2][2], const uint4* __restrict__ WB, int ksB) {
+    auto phase = [&](auto nk_c, auto depth_c, auto dual_c, auto swap_c, f32x16 (&accA)[FG][2], const uint4* __restrict__ WA,
+                     int ksA, f32x16 (&accB)[FG][2], const uint4* __restrict__ WB, int ksB) {
         constexpr int NK = decltype(nk_c)::value, DEPTH = decltype(depth_c)::value;
         constexpr bool DUAL = decltype(dual_c)::value, SWAP = decltype(swap_c)::value;
-        WFrag wa[DEPTH], wb[DUAL ? DEPTH : 1];
+        WFrag<FG> wa[DEPTH], wb[DUAL ? DEPTH : 1];
         bf16x8 act[2][2][3];                   // activations one k-step ahead as well (LDS latency)
         load_act(act[0], 0);
 #pragma unroll
@@ -711,10 +728,10 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
             zero(acc);
             phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, no_t{}, yes_t{}, acc, Qf + (size_t)tb * (KH * 3 * 8 * 64), 0,
                   acc, Qf, 0);
-            // tile: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 64 wave + 32 tg + lr
+            // tile: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 32 FG wave + 32 tg + lr
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
-                const int tok = tb * 256 + 64 * wave + 32 * tg + lr;
+            for (int tg = 0; tg < FG; ++tg) {
+                const int tok = tb * 256 + 32 * FG * wave + 32 * tg + lr;
                 const bool tok_ok = tok < M;
                 const float rc = tok_ok ? rowc[(size_t)tok * rowc_ld] : 0.0f;
                 float vmax = -INFINITY;
@@ -765,10 +782,10 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
     float* O = reinterpret_cast<float*>(&S[0][0][0]);
     static_assert(TR * OLD * 4 <= 3 * TR * SLD * 2, "output tile must fit in the activation planes");
 #pragma unroll
-    for (int fg = 0; fg < 2; ++fg)
+    for (int fg = 0; fg < FG; ++fg)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int f0 = 64 * wave + 32 * fg + 8 * q + 4 * lh;
+            const int f0 = 32 * FG * wave + 32 * fg + 8 * q + 4 * lh;
             const float4 bv = *reinterpret_cast<const float4*>(b3 + f0);
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
@@ -782,8 +799,8 @@ __global__ void __launch_bounds__(256) k5_trunk(const float* __restrict__ ray_o,
         }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TR / 4; ++i) {
-        const int ray = wave * (TR / 4) + i;
+    for (int i = 0; i < TR * FG / 8; ++i) {
+        const int ray = wave * (TR * FG / 8) + i;
         const int64_t gr = row0 + ray;
         if (gr < N) *reinterpret_cast<float4*>(h3 + gr * TC + 4 * lane) = *reinterpret_cast<const float4*>(&O[ray * OLD + 4 * lane]);
     }
@@ -806,7 +823,7 @@ static hipError_t trunk(const IdNetDev& n, const float* o, const float* d, const
     int64_t tot = N * XW;
     int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
     if (n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk) {
-        hipLaunchKernelGGL(k5_trunk<false>, dim3((unsigned)((N + TR - 1) / TR)), dim3(256), 0, s, o, d, rgb, N, (const uint4*)n.f1,
+        hipLaunchKernelGGL((k5_trunk<false, TRUNK_FG>), dim3((unsigned)((N + TR - 1) / TR)), dim3(64 * 8 / TRUNK_FG), 0, s, o, d, rgb, N, (const uint4*)n.f1,
                            (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, h3, (const uint4*)nullptr,
                            (const float*)nullptr, 0, 0, 1.0f, (float*)nullptr, (float2*)nullptr, 0);
         return hipGetLastError();
@@ -1046,7 +1063,7 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
         for (auto& x : ev) if ((e = hipEventCreate(&x)) != hipSuccess) return e;
         (void)hipEventRecord(ev[0], s);
     }
-    hipLaunchKernelGGL(k5_trunk<true>, dim3((unsigned)n_blk, (unsigned)B), dim3(256), 0, s, o, d, rgb, N, (const uint4*)n.f1,
+    hipLaunchKernelGGL((k5_trunk<true, TRUNK_FG>), dim3((unsigned)n_blk, (unsigned)B), dim3(64 * 8 / TRUNK_FG), 0, s, o, d, rgb, N, (const uint4*)n.f1,
                        (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M,
                        divisor, logits, part, Mpad);
     e = hipGetLastError();
