@@ -255,7 +255,7 @@ def main():
             "kernel": "k5_trunk<true> (ray encoder + attention logits + softmax partials, one launch)",
             "queries_per_launch": QB, "rays_per_launch": n_rays,
             "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic("k5_trunk<true>"),
+            "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic("k5_trunk<true, 1>", "k5_trunk<true, 2>", "k5_trunk<true>"),
             "avg_launch_ms": round(t_ms, 4), "flops_per_launch": round(issued),
             "note": "achieved = bf16 MFMA flops issued / launch time: 12 x 256 x (832 encoder + 256 logits k) per ray, i.e. the "
                     "folded algorithm (2 x 256 x 1088 = 557 kFLOP per ray) times the 6 bf16 products that make one "

@@ -40,7 +40,7 @@ def main():
         w = wr.get(k, (0, 0.0, 0, 0))[1]
         js[k] = {"fetch_KiB_raw": round(f, 1), "write_KiB": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
     json.dump(js, open(f"{out}_hbm_traffic.json", "w"), indent=1, sort_keys=True)
-    for k in ("k4b_appearance<27, true, 1>", "k4b_appearance<27, true>", "k4b_appearance<27>", "k4a_density_composite<1>", "k4a_density_composite", "k_ref_shade<27, true>", "k5_trunk<true>", "k6_colsum", "k_surface_sample"):
+    for k in ("k4b_appearance<27, true, 1>", "k4b_appearance<27, true>", "k4b_appearance<27>", "k4a_density_composite<1>", "k4a_density_composite", "k_ref_shade<27, true>", "k5_trunk<true, 1>", "k5_trunk<true>", "k6_colsum", "k_surface_sample"):
         if k in js:
             print(k, js[k])
 
