@@ -134,3 +134,25 @@ def test_one_lane_candidates_draw_the_same_samples(tmp_path):
     for k in outs[0]:
         for x, y in zip(outs[0][k], outs[1][k]):
             assert torch.equal(x, y), k
+
+
+def test_batched_runs_large_point_counts_and_residency(small, dev):
+    """Batched launches: every run equals the single call with its strided seed, at point counts below and above the
+    LDS-cache limit (4096) and in both lane forms (batches of 8 or more switch to one lane per candidate); the
+    residency query bounds how many launches may be in flight."""
+    from iffnerf_amd.hip_field import SAMPLER_SEED_STRIDE
+    rho = rho_of(util.ckpt("small"))
+    for B, P in ((3, 700), (8, 300), (2, 5000)):
+        s, a, st = small.surface_sample_batched(B, P, rho, n_epochs=3, max_iterations=200, seed=77)
+        assert s.shape == (B, P, 3) and a.shape == (B, P) and st.shape == (B, 3, 4)
+        assert (st[..., 3] != -1).all(), "in-kernel barrier timed out"
+        for b in range(B):
+            s1, a1, st1 = small.surface_sample(P, rho, n_epochs=3, max_iterations=200, seed=(77 + b * SAMPLER_SEED_STRIDE) % 2 ** 64)
+            assert torch.equal(s[b], s1) and torch.equal(a[b], a1) and torch.equal(st[b], st1), (B, P, b)
+        assert torch.equal(small.point_alpha(s.reshape(-1, 3)), a.reshape(-1))
+        assert not torch.equal(s[0], s[1])
+    w1, cap = small.sampler_residency(593, 1)
+    w16, cap16 = small.sampler_residency(593, 16)
+    assert cap == cap16 and cap >= 256 and w1 == 47 and w16 == 12          # 4 lanes / 1 lane per candidate at P = 593
+    w_big, _ = small.sampler_residency(20000, 1)
+    assert w_big <= 256                                                     # never more than one workgroup per CU and run
