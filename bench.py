@@ -38,10 +38,10 @@ TOPK = 100
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 L2_GATHER_GBS = 17800.0   # MI355X_MICROARCH.md "Indexed rows": rows served from the XCDs' L2 gather at 16.8-18.8 TB/s chip-wide
-# fused encoder/logits launch: bf16 MFMA flops per ray = 6 products x 2 x 256 outputs x (160 + 160 + 256 + 256 encoder k
-# + 256 logits k per 256-token block)
+# fused encoder/logits launch: bf16 MFMA flops per ray = 6 products x 2 x 256 outputs x (144 + 144 + 256 + 256 encoder k
+# (the 141 input columns in 9 k-steps of 16, twice: layer 1 and the x-part of layer 3) + 256 logits k per 256-token block)
 def trunk_flops(n_rays, m_tokens):
-    return n_rays * 12.0 * 256.0 * (160 + 160 + 256 + 256 + 256 * ((m_tokens + 255) // 256))
+    return n_rays * 12.0 * 256.0 * (144 + 144 + 256 + 256 + 256 * ((m_tokens + 255) // 256))
 # march: algorithmic bytes per sample = valid*1184 (8 mask bytes x4 + density taps) + shaded*3456 (appearance taps)
 # (SURVEY.md section 8d, fp32 tables); per-ray terms are added where the launches read / write them
 B_VALID, B_APP = 32 + 1152, 3456
@@ -258,8 +258,8 @@ def main():
             "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic("k5_trunk<true, 1>", "k5_trunk<true, 2>", "k5_trunk<true>"),
             "avg_launch_ms": round(t_ms, 4), "flops_per_launch": round(issued),
-            "note": "achieved = bf16 MFMA flops issued / launch time: 12 x 256 x (832 encoder + 256 logits k) per ray, i.e. the "
-                    "folded algorithm (2 x 256 x 1088 = 557 kFLOP per ray) times the 6 bf16 products that make one "
+            "note": "achieved = bf16 MFMA flops issued / launch time: 12 x 256 x (800 encoder + 256 logits k) per ray, i.e. the "
+                    "folded algorithm (2 x 256 x 1056 = 541 kFLOP per ray) times the 6 bf16 products that make one "
                     "fp32-accurate product; peak = dense bf16.  The reference's unfolded fp32 chain (SURVEY 8d) would be "
                     "%.1f GFLOP per launch = %.0f TFLOP/s at this duration (fp32-MFMA peak: 157)"
                     % (ref_flops / 1e9, ref_flops / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0),

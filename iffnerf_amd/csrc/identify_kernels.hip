@@ -666,7 +666,9 @@ __global__ void __launch_bounds__(FG == 2 ? 256 : 512) k5_trunk(const float* __r
 
     f32x16 acc[FG][2], acc3[FG][2];
     zero(acc); zero(acc3);
-    constexpr int KX = XW / 16, KH = TC / 16;
+    // x has 141 real columns: 9 k-steps cover them (columns 144..159 of the padded layout are zero in x and are skipped)
+    constexpr int KX = (141 + 15) / 16, KH = TC / 16;
+    static_assert(KX * 16 <= XW, "x planes are laid out for XW columns");
 
     // One k loop, software-pipelined in registers: the weight fragments of k-step ks + DEPTH - 1 are requested before
     // k-step ks is multiplied (an L2 hit under load takes longer than one k-step's 24 MFMAs).  DUAL: two weight streams
