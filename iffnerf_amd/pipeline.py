@@ -77,6 +77,16 @@ class PosePipeline:
         idx, val = H.topk(score, k)
         return H.pose_from_topk(idx, val, ori, dirs, self.model_up), idx, val
 
+    def identify_batch(self, tokens, ori, dirs, rgb, k: int = 100):
+        """Warm path for a batch of query images against ONE resident ray set (the reference's eval loop,
+        train_eval_pose_est.py:131-149 + pose_estimation/test.py:67-91: rays emitted once per model, then every image):
+        tokens [Q,M,C+14] -> (c2w [Q,4,4], idx [Q,k], val [Q,k]).  Query q equals ``identify(tokens[q], ...)``."""
+        Q, M, C = tokens.shape
+        logits, rmax, rsum = self.logits(tokens.reshape(Q * M, C), ori, dirs, rgb)
+        score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
+        idx, val = H.topk_batched(score, k)
+        return H.pose_from_topk_batched(idx, val, ori, dirs, self.model_up), idx, val
+
     def query(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None, materialize_map: bool = False):
         """Cold per-query path: emission + identification + pose -> (c2w, top-k idx, top-k val).  The attention map is not
         part of the result, so by default it is not written back (scores come straight from logits + row statistics)."""

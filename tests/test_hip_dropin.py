@@ -186,3 +186,16 @@ def test_batched_cold_queries_equal_single_queries(dev):
         cq.replay()
         torch.cuda.synchronize()
         assert torch.equal(cq.idx, eager[r][1]) and torch.equal(cq.c2w, eager[r][0])
+
+
+def test_warm_batch_equals_per_image_identification(dev):
+    """identify_batch: Q query images against one resident ray set in one set of launches == identify per image."""
+    from iffnerf_amd.pipeline import PosePipeline
+    pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
+    ori, dirs, rgb = pipe.emit(75, seed=3)
+    for M in (256, 137):
+        tok = torch.stack([synthetic.make_tokens(M, 384, seed=20 + q) for q in range(5)]).to(dev)
+        c2w, idx, val = pipe.identify_batch(tok, ori, dirs, rgb, 100)
+        for q in range(5):
+            w_c2w, w_idx, w_val = pipe.identify(tok[q], ori, dirs, rgb, 100, materialize_map=False)
+            assert torch.equal(idx[q], w_idx) and torch.equal(val[q], w_val) and torch.equal(c2w[q], w_c2w), (M, q)
