@@ -89,8 +89,8 @@ def cpu_baseline(ck, idw, tokens_cpu, max_seconds=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--in-flight", type=int, default=4, help="cold queries kept in flight on separate streams (N = 1)")
     ap.add_argument("--batch", type=int, default=16,
                     help="cold queries per step at N = 1, each with its own freshly drawn ray set, served by one set of launches")
