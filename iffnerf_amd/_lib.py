@@ -16,6 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
 _lib = None
+ABI_VERSION = 2          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -29,7 +30,7 @@ class FieldDesc(C.Structure):
         ("basis", C.c_void_p), ("mask_volume", C.c_void_p), ("mask_dims", C.c_int32 * 3), ("mask_aabb", C.c_float * 6),
         ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
         ("step_size", C.c_float), ("n_samples", C.c_int32), ("near_far", C.c_float * 2),
-        ("softplus", C.c_int32), ("unisphere", C.c_int32),
+        ("softplus", C.c_int32), ("unisphere", C.c_int32), ("density_lanes", C.c_int32),
         ("normal_w", C.c_void_p), ("normal_b", C.c_void_p), ("tint_w", C.c_void_p), ("tint_b", C.c_void_p),
         ("rough_w", C.c_void_p), ("rough_b", C.c_void_p), ("diffuse_w", C.c_void_p), ("diffuse_b", C.c_void_p),
         ("bottleneck_w", C.c_void_p), ("bottleneck_b", C.c_void_p), ("specular_w", C.c_void_p), ("specular_b", C.c_void_p),
@@ -108,6 +109,9 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
+        if h.iff_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {h.iff_abi_version()}, this binding expects {ABI_VERSION}: "
+                               "rebuild it with `python -m iffnerf_amd.build`")
         _lib = h
     return _lib
 

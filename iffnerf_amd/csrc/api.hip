@@ -67,6 +67,8 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
         return fail(IFF_ERR_UNSUPPORTED, "only appearance_n_comp = 48 and app_dim = 27 are built (got %d, %d)", d->n_app,
                     d->app_dim);
     IFF_REQUIRE(d->n_density >= 4 && d->n_density % 4 == 0 && d->n_density <= 64, "density_n_comp = %d unsupported", d->n_density);
+    IFF_REQUIRE(d->density_lanes == 0 || d->density_lanes == 4 || (d->density_lanes == 1 && d->n_density == 16),
+                "density_lanes = %d: must be 0 (auto), 4, or 1 with density_n_comp = 16", d->density_lanes);
     IFF_REQUIRE(d->feature_c >= 16 && d->feature_c <= 512 && d->feature_c % 16 == 0, "featureC = %d unsupported", d->feature_c);
     IFF_REQUIRE(d->basis && d->normal_w && d->normal_b && d->tint_w && d->tint_b && d->rough_w && d->rough_b && d->diffuse_w &&
                     d->diffuse_b && d->bottleneck_w && d->bottleneck_b && d->specular_w && d->specular_b && d->ide_mat,
@@ -162,6 +164,7 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     v.density_shift = d->density_shift; v.distance_scale = d->distance_scale; v.weight_thres = d->weight_thres;
     v.step_size = d->step_size; v.near = d->near_far[0]; v.far = d->near_far[1];
     v.n_samples = d->n_samples; v.softplus = d->softplus; v.unisphere = d->unisphere;
+    v.density_lanes = d->density_lanes;
     v.n_density = d->n_density; v.n_app = d->n_app; v.app_dim = d->app_dim; v.feature_c = d->feature_c;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -577,7 +580,7 @@ extern "C" int iff_attn_logits(const float* q, const float* k, int32_t M, int64_
 
 extern "C" int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const float* row_max, const float* row_sumexp,
                                int32_t write_attention, float* score, void* stream) {
-    IFF_REQUIRE(M >= 1 && M <= 8192 && N >= 0, "iff_attn_colsum: bad shape");
+    IFF_REQUIRE(M >= 1 && M <= 8064 && N >= 0, "iff_attn_colsum: bad shape (1 <= M <= 8064: the row statistics live in 64 KiB of LDS)");
     if (N == 0) return 0;
     IFF_REQUIRE(logits_inout && row_max && row_sumexp && score, "iff_attn_colsum: null buffer");
     IFF_HIP(launch_attn_colsum(logits_inout, 1, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));
@@ -586,7 +589,7 @@ extern "C" int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const 
 
 extern "C" int iff_attn_colsum_batched(float* logits_inout, int32_t Q, int32_t M, int64_t N, const float* row_max,
                                        const float* row_sumexp, int32_t write_attention, float* score, void* stream) {
-    IFF_REQUIRE(Q >= 0 && Q <= 65535 && M >= 1 && M <= 8192 && N >= 0, "iff_attn_colsum_batched: bad shape");
+    IFF_REQUIRE(Q >= 0 && Q <= 65535 && M >= 1 && M <= 8064 && N >= 0, "iff_attn_colsum_batched: bad shape (1 <= M <= 8064)");
     if (N == 0 || Q == 0) return 0;
     IFF_REQUIRE(logits_inout && row_max && row_sumexp && score, "iff_attn_colsum_batched: null buffer");
     IFF_HIP(launch_attn_colsum(logits_inout, Q, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));

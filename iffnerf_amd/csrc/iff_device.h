@@ -29,6 +29,7 @@ struct FieldDev {
     float mask_lo[3], mask_hi[3], mask_inv[3];        // mask_inv = (1/size)*2 (tensorBase.py:59)
     float density_shift, distance_scale, weight_thres, step_size, near, far;
     int n_samples, softplus, unisphere;
+    int density_lanes;          // 0 auto, 1 or 4 forced (iff_field_desc.density_lanes)
     int n_density, n_app, app_dim, feature_c;
 };
 
@@ -290,24 +291,6 @@ __device__ inline void app_products_lane(const FieldDev& f, const float xn[3], i
         float4 p = lerp_plane4(f.aplane[i], C, t, 4 * c);
         float4 l = lerp_line4(f.aline[i], C, t, 4 * c);
         prod[4 * i + 0] = p.x * l.x; prod[4 * i + 1] = p.y * l.y; prod[4 * i + 2] = p.z * l.z; prod[4 * i + 3] = p.w * l.w;
-    }
-}
-
-// The same for Q consecutive quarters c0 .. c0+Q-1 by one lane: the taps of a plane are computed once for all of them.
-template <int Q>
-__device__ inline void app_products_quads(const FieldDev& f, const float xn[3], int c0, float (&prod)[Q][12]) {
-    const int C = f.n_app;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        Taps t;
-        make_taps(f, xn, i, t);
-#pragma unroll
-        for (int cc = 0; cc < Q; ++cc) {
-            float4 p = lerp_plane4(f.aplane[i], C, t, 4 * (c0 + cc));
-            float4 l = lerp_line4(f.aline[i], C, t, 4 * (c0 + cc));
-            prod[cc][4 * i + 0] = p.x * l.x; prod[cc][4 * i + 1] = p.y * l.y;
-            prod[cc][4 * i + 2] = p.z * l.z; prod[cc][4 * i + 3] = p.w * l.w;
-        }
     }
 }
 

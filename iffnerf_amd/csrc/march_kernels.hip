@@ -17,7 +17,6 @@
 // ~1000-sample slab sampler share the code.
 #include "iff_device.h"
 #include "iff_launch.h"
-#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ K3
 // 27 iso-cell directions (pose_estimation/isocell.py:6-68, N0=3, isrand=-1) are passed in by the host mirror, which
@@ -216,21 +215,18 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
 }
 
 // ---- K4b: appearance gather for the samples that pass the weight threshold, then basis_mat on the weighted sums.
-// A ray is served by a group of G = 16 / Q lanes, 12 / Q of them active; each active lane owns Q consecutive 16-B quarters
-// of the 192-B appearance texels (12 plane*line products per quarter).  Q = 1: 12 lanes per ray, 16 rays per workgroup;
-// Q = 2: 6 lanes, 32 rays; Q = 4: 3 lanes, 64 rays -- the tap arithmetic (which, not the gathers, is most of this
-// kernel's instructions) is done once per lane, so fewer lanes per ray means less of it.  Samples are taken in order and
-// the basis_mat sum keeps the Q = 1 butterfly's pairing at every level, so all forms produce the same bits.
+// A ray is served by a group of 16 lanes, 12 of them active; each active lane owns one 16-B quarter of the 192-B
+// appearance texels (12 plane*line products).  Regroupings with 6 or 3 lanes per ray (2 / 4 quarters per lane, fewer tap
+// computations) were measured slower -- what they save in tap arithmetic they lose in occupancy.
 // Output: the per-ray feature vector [R][28] (27 features + a "has shaded samples" flag) for K4c.
 #ifndef K4B_WAVES
 #define K4B_WAVES 4
 #endif
-template <int APP, bool SHORT, int Q>
-__global__ void __launch_bounds__(256, (Q == 1 ? K4B_WAVES : (Q == 2 ? 2 : 1))) k4b_appearance(FieldDev f, MarchArgs a, int64_t n_tiles) {
+template <int APP, bool SHORT>
+__global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance(FieldDev f, MarchArgs a, int64_t n_tiles) {
     extern __shared__ __align__(16) float smem[];
-    constexpr int NL = 12;                         // n_app / 4 texel quarters
-    constexpr int G = 16 / Q;                      // lanes per ray group
-    constexpr int NA = NL / Q;                     // active lanes per group
+    constexpr int NL = 12;                         // n_app / 4 texel quarters = active lanes per group
+    constexpr int G = 16;                          // lanes per ray group
     constexpr int RB = 256 / G;                    // rays per workgroup tile
     constexpr int NW = (32 + G - 1) / G;           // weight registers per lane for S <= 32
     constexpr int LD = (APP + 3) & ~3;
@@ -240,8 +236,8 @@ __global__ void __launch_bounds__(256, (Q == 1 ? K4B_WAVES : (Q == 2 ? 2 : 1))) 
     __syncthreads();
     const int S = a.S;
     const int ray_l = tid / G, lg = tid % G;
-    const int c0 = (lg < NA ? lg : NA - 1) * Q;    // idle lanes shadow the last active lane's addresses (coalesced away)
-    const float lane_on = lg < NA ? 1.0f : 0.0f;
+    const int c0 = lg < NL ? lg : NL - 1;          // idle lanes shadow the last active lane's addresses (coalesced away)
+    const float lane_on = lg < NL ? 1.0f : 0.0f;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t r = tile * RB + ray_l;
         const bool live = r < a.R;
@@ -251,22 +247,18 @@ __global__ void __launch_bounds__(256, (Q == 1 ? K4B_WAVES : (Q == 2 ? 2 : 1))) 
             o[0] = rp[0]; o[1] = rp[1]; o[2] = rp[2]; d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
         }
         const float t0 = (a.mode == 1) ? slab_entry(f, o, d) : 0.0f;
-        float accp[Q][12];
+        float accp[12];
 #pragma unroll
-        for (int cc = 0; cc < Q; ++cc)
-#pragma unroll
-            for (int i = 0; i < 12; ++i) accp[cc][i] = 0.0f;
+        for (int i = 0; i < 12; ++i) accp[i] = 0.0f;
         bool any = false;
         auto shade_sample = [&](int s, float w) {
             float z = z_of(f, a.mode, S, t0, s);
             float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z}, xn[3];
             field_normalize(f, p, xn);
-            float prod[Q][12];
-            app_products_quads<Q>(f, xn, c0, prod);
+            float prod[12];
+            app_products_lane(f, xn, c0, prod);
 #pragma unroll
-            for (int cc = 0; cc < Q; ++cc)
-#pragma unroll
-                for (int i = 0; i < 12; ++i) accp[cc][i] = fmaf(w, prod[cc][i], accp[cc][i]);
+            for (int i = 0; i < 12; ++i) accp[i] = fmaf(w, prod[i], accp[i]);
         };
         if (SHORT) {
             // short rays (S <= 32: the 20-sample point-centred sampler): the lanes of a ray fetch its weights once (lane l
@@ -305,24 +297,16 @@ __global__ void __launch_bounds__(256, (Q == 1 ? K4B_WAVES : (Q == 2 ? 2 : 1))) 
             }
         }
         // basis_mat on the weighted sums: quarter c contributes a 12-term fmaf chain to each of the APP outputs; the
-        // quarters are then added pairwise -- inside the lane for its own Q quarters, across the group by xor butterfly
+        // quarters are then added across the group by xor butterfly (fixed order: deterministic)
         const float* basis_tile = s_basis;
         asm volatile("" : "+v"(basis_tile));   // opaque per tile: keeps LLVM from hoisting the 324 weight reads out of the tile loop
 #pragma unroll 1
         for (int oo = 0; oo < APP; ++oo) {
-            float vq[Q];
+            const float* bl = basis_tile + (oo * NL + c0) * 12;
+            float v = 0.0f;
 #pragma unroll
-            for (int cc = 0; cc < Q; ++cc) {
-                const float* bl = basis_tile + (oo * NL + c0 + cc) * 12;
-                float v = 0.0f;
-#pragma unroll
-                for (int kk = 0; kk < 12; ++kk) v = fmaf(bl[kk], accp[cc][kk], v);
-                vq[cc] = v * lane_on;
-            }
-            float v;
-            if (Q == 1) v = vq[0];
-            else if (Q == 2) v = vq[0] + vq[1];
-            else v = (vq[0] + vq[Q > 1 ? 1 : 0]) + (vq[Q > 2 ? 2 : 0] + vq[Q > 3 ? 3 : 0]);
+            for (int kk = 0; kk < 12; ++kk) v = fmaf(bl[kk], accp[kk], v);
+            v = v * lane_on;
 #pragma unroll
             for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
             if (lg == 0 && live) a.feat[r * LD + oo] = v;
@@ -354,8 +338,7 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     a.n_tiles = (R + RPB - 1) / RPB;
     if (a.n_tiles == 0) return hipSuccess;
     // one lane per sample when the density texel is one 64-B line (n_density = 16, every reference config)
-    static const int lps_env = getenv("IFF_K4A_LPS") ? atoi(getenv("IFF_K4A_LPS")) : 0;      // A/B switch for tests
-    const bool one_lane = f.n_density == 16 && lps_env != 4;
+    const bool one_lane = f.n_density == 16 && f.density_lanes != 4;
     const int64_t tiles_a = one_lane ? (R + 63) / 64 : a.n_tiles;
     int64_t grid = tiles_a < 256 * 8 ? tiles_a : 256 * 8;
     if (one_lane) hipLaunchKernelGGL((k4a_density_composite<1>), dim3((unsigned)grid), dim3(256), 0, s, f, a, tiles_a);
@@ -365,18 +348,8 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
     grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
-    // lanes per ray: 12 / Q (see k4b_appearance)
-    static const int q_env = getenv("IFF_K4B_Q") ? atoi(getenv("IFF_K4B_Q")) : 0;         // A/B switch for tests and tuning
-    // measured at 4 x 16 011 rays: Q = 1 221 us (127 VGPR, 4 waves/SIMD), Q = 2 220 us (229 VGPR, 2 waves), Q = 4 349 us:
-    // unlike K4a, the fewer tap computations are paid back in occupancy, so the 12-lane form stays the default
-    const int Qsel = (q_env == 1 || q_env == 2 || q_env == 4) ? q_env : 1;
-    const int rb = 256 / (16 / Qsel);
-    const int64_t tiles_b = (R + rb - 1) / rb;
-    grid = tiles_b < 256 * 8 ? tiles_b : 256 * 8;
-#define IFF_K4B(SH, QQ) hipLaunchKernelGGL((k4b_appearance<27, SH, QQ>), dim3((unsigned)grid), dim3(256), lds, s, f, a, tiles_b)
-    if (S <= 32) { if (Qsel == 1) IFF_K4B(true, 1); else if (Qsel == 2) IFF_K4B(true, 2); else IFF_K4B(true, 4); }
-    else { if (Qsel == 1) IFF_K4B(false, 1); else if (Qsel == 2) IFF_K4B(false, 2); else IFF_K4B(false, 4); }
-#undef IFF_K4B
+    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
+    else hipLaunchKernelGGL((k4b_appearance<27, false>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);

@@ -20,7 +20,6 @@
 #include "iff_device.h"
 #include "iff_launch.h"
 #include "iff_select.h"
-#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 struct U4 { uint32_t x, y, z, w; };
@@ -372,11 +371,10 @@ __global__ void k_zero_u64(unsigned long long* p, int64_t n) {
 // texel quarter each): 47 workgroups per run at P = 593, 245 us -- best for single queries and small batches.  One lane
 // (needs a density texel of one 64-B line, i.e. n_density = 16): 12 workgroups per run, 340 us -- four times as many runs
 // fit on the device at once, which is what large batches in flight need (measured: 16 queries per launch x 4 launches in
-// flight 6790 poses/s against 6190 for the best four-lane configuration).  IFF_SAMPLER_LPC = 1 | 4 forces a form (A/B tests).
+// flight 6790 poses/s against 6190 for the best four-lane configuration).  iff_field_desc.density_lanes forces a form.
 int sampler_lpc(const FieldDev& f, int B) {
-    static const int lpc_env = getenv("IFF_SAMPLER_LPC") ? atoi(getenv("IFF_SAMPLER_LPC")) : 0;
-    if (f.n_density != 16 || lpc_env == 4) return 4;
-    if (lpc_env == 1) return 1;
+    if (f.n_density != 16 || f.density_lanes == 4) return 4;
+    if (f.density_lanes == 1) return 1;
     return B >= 8 ? 1 : 4;
 }
 

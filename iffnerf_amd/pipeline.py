@@ -16,11 +16,25 @@ from .hip_field import FieldHandle, field_handle_from_ckpt, isocell_emit
 from .pose_estimation.isocell import isocell_distribution
 
 
-def jitter_scale_from_kwargs(kw: dict) -> float:
-    """rho of reference pose_estimation/sampling.py:518-521 from checkpoint kwargs (mask present)."""
+def jitter_scale_from_kwargs(kw: dict, has_mask: bool = True) -> float:
+    """rho of reference pose_estimation/sampling.py:518-523 from checkpoint kwargs: 10 % of the grid in voxel units when
+    the model carries an occupancy mask, the aabb diagonal otherwise."""
     g = torch.tensor([int(v) for v in kw["gridSize"]], dtype=torch.long)
     aabb = torch.as_tensor(kw["aabb"]).float().cpu()
+    if not has_mask:
+        return float(torch.linalg.norm(aabb[1] - aabb[0]))
     return float((torch.max(g) * 0.1) * torch.max((aabb[1] - aabb[0]) / g))
+
+
+def check_sampler_stats(stats: torch.Tensor) -> None:
+    """Raise RuntimeError when a surface-sampler run reported an in-kernel barrier timeout (``stats[..., 0, 3] == -1``,
+    include/iffnerf_hip.h iff_surface_sample): its samples are unconverged and every pose derived from them is invalid.
+    One device->host read; call it outside timed / captured regions."""
+    s = stats.reshape(-1, stats.shape[-2], 4)
+    bad = (s[:, 0, 3] == -1).nonzero().flatten().tolist()
+    if bad:
+        raise RuntimeError(f"surface sampler: in-kernel grid barrier timed out in run(s) {bad} "
+                           "(more sampler workgroups in flight than the device holds, or the device is shared)")
 
 
 class PosePipeline:
@@ -35,7 +49,7 @@ class PosePipeline:
     def from_checkpoints(cls, field_ckpt: dict, id_weights: Dict[str, torch.Tensor], device, model_up=(0.0, 0.0, 1.0),
                          fold_heads: bool = True):
         return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device),
-                   jitter_scale_from_kwargs(field_ckpt["kwargs"]), model_up, fold_heads)
+                   jitter_scale_from_kwargs(field_ckpt["kwargs"], "alphaMask.aabb" in field_ckpt), model_up, fold_heads)
 
     def logits(self, tokens, ori, dirs, rgb):
         """tokens [M, C+14] x rays -> (logits [M,N], row_max [M], row_sumexp [M])."""
@@ -123,9 +137,8 @@ class PosePipeline:
     def capture_query_batch(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100) -> "CapturedBatchQuery":
         return CapturedBatchQuery(self, tokens_shape, gen_points, seed, k)
 
-    def capture_query(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100,
-                      prefetch_emission: bool = False) -> "CapturedQuery":
-        return CapturedQuery(self, tokens_shape, gen_points, seed, k, prefetch_emission)
+    def capture_query(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100) -> "CapturedQuery":
+        return CapturedQuery(self, tokens_shape, gen_points, seed, k)
 
     # ------------------------------------------------------------------ ray-sharded batch of queries (multi-GPU)
     # Three local segments with one small exchange between each pair (distributed.py): the eager ``query_sharded`` and the
@@ -192,11 +205,9 @@ class CapturedQuery:
     ``idx`` / ``val`` out (valid after the replay's stream has been synchronised, until the next replay).
     """
 
-    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100,
-                 prefetch_emission: bool = False):
+    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100):
         dev = pipe.device
         self.pipe = pipe
-        self.prefetch_emission = bool(prefetch_emission)
         self.tokens = torch.zeros(tokens_shape, dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
@@ -207,29 +218,14 @@ class CapturedQuery:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        if not self.prefetch_emission:
-            with torch.cuda.graph(self.graph):
-                self.counter += 1
-                self.c2w, self.idx, self.val = pipe.query(self.tokens, gen_points, seed, k, seed_offset=self.counter)
-            return
-        # Software-pipelined form: the graph has two branches -- the surface sampler drawing the NEXT replay's points
-        # (device counter + 1) and stages A2 + B + C of this replay on the points drawn during the previous one.  The
-        # emission does not depend on the query image, so the latency-bound sampler leaves the critical path; every
-        # replay still consumes one fresh draw and produces one.  Replay r uses the draw of seed offset r - 1
-        # (the first one comes from the eager call below).
-        self.samples = pipe.sample_surface(gen_points, seed, seed_offset=self.counter).clone()
-        torch.cuda.synchronize(dev)
-        self._side = torch.cuda.Stream(device=dev)
         with torch.cuda.graph(self.graph):
             self.counter += 1
-            main = torch.cuda.current_stream(dev)
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                nxt = pipe.sample_surface(gen_points, seed, seed_offset=self.counter)
-            ori, dirs, rgb = pipe.emit_from_samples(self.samples)
-            self.c2w, self.idx, self.val = pipe.identify(self.tokens, ori, dirs, rgb, k, False)
-            main.wait_stream(self._side)
-            self.samples.copy_(nxt)
+            self.c2w, self.idx, self.val = pipe.query(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+            self.sampler_stats = pipe.last_sampler_stats
+
+    def check(self) -> None:
+        """After a synchronised replay: raise if this instance's last sampler run timed out (see check_sampler_stats)."""
+        check_sampler_stats(self.sampler_stats)
 
     def replay(self, tokens: Optional[torch.Tensor] = None):
         if tokens is not None:
@@ -273,6 +269,8 @@ class CapturedShardedQuery:
             self.counter += 1
             ori, dirs, logits, self.stats = pipe.shard_local_logits(self.tokens, gen_points, seed, self.rank, self.ws,
                                                                     seed_offset=self.counter)
+            self.sampler_stats = pipe.last_sampler_stats
+        self._seg1 = (ori, dirs, logits)      # g2 reads these blocks of g1's private pool: keep them allocated
         self.stats_all = self.stats.new_zeros((self.ws,) + tuple(self.stats.shape))
         with torch.cuda.graph(self.g2, **opts):
             self.cand = pipe.shard_local_candidates(logits, self.stats_all, ori, dirs, Q, k, lo * 27, materialize_map=False)
@@ -287,6 +285,10 @@ class CapturedShardedQuery:
             dist.all_gather_into_tensor(out.view((-1,) + tuple(src.shape[1:])), src, group=self.group)
         else:
             out.copy_(src[None])
+
+    def check(self) -> None:
+        """After a synchronised replay: raise if this instance's last sampler run timed out (see check_sampler_stats)."""
+        check_sampler_stats(self.sampler_stats)
 
     def replay(self, tokens: Optional[torch.Tensor] = None):
         if tokens is not None:
@@ -320,6 +322,11 @@ class CapturedBatchQuery:
         with torch.cuda.graph(self.graph):
             self.counter += 1
             self.c2w, self.idx, self.val = pipe.query_batch(self.tokens, gen_points, seed, k, seed_offset=self.counter)
+            self.sampler_stats = pipe.last_sampler_stats
+
+    def check(self) -> None:
+        """After a synchronised replay: raise if this instance's last sampler run timed out (see check_sampler_stats)."""
+        check_sampler_stats(self.sampler_stats)
 
     def replay(self, tokens: Optional[torch.Tensor] = None):
         if tokens is not None:

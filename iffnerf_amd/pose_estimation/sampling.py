@@ -37,6 +37,8 @@ def iterative_surface_sampling_process(model, gen_points=8000, n_iteration=4, ma
     seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # tie the device stream to torch.manual_seed
     samples, alpha, stats = model.field_handle().surface_sample(
         int(gen_points), _jitter_scale(model), n_epochs=n_iteration, max_iterations=max_resampling_iterations, seed=seed)
+    from ..pipeline import check_sampler_stats
+    check_sampler_stats(stats)          # one device->host read per call (the reference syncs twice per iteration)
     if return_stats:
         return samples, alpha, stats
     return samples

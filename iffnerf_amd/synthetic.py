@@ -79,13 +79,16 @@ def make_field_ckpt(grid: Sequence[int] = (300, 300, 300),
                     step_ratio: float = 0.5, density_shift: float = -10.0, distance_scale: float = 25.0,
                     contraction_type: str = "aabb", near_far=(2.0, 6.0),
                     blob_sigma: float = 0.42, peak: float = 32.0, mask_radius: float = 0.9,
-                    view_pe: int = 2, fea_pe: int = 2) -> dict:
+                    view_pe: int = 2, fea_pe: int = 2, density_offset: float = 0.0) -> dict:
     """Build a TensorVMSplit-shaped checkpoint dictionary (see module docstring).
 
     ``grid`` is gridSize (x, y, z); plane i is [1,C,G[b],G[a]] with (a,b)=MAT_MODE[i], line i is
     [1,C,G[v],1] with v=VEC_MODE[i] (reference models/tensoRF.py:160-170).
     Density feature ~= peak * exp(-r^2/(2 blob_sigma^2)) * (1+noise) in normalised coordinates, so
     softplus(feature + shift) crosses from ~0 to large around r ~ 0.6-0.65: a closed surface.
+    ``density_offset`` (for configs with ``density_shift = 0``, reference configs/bicycle.txt:28): channel 0 of every
+    density plane becomes the constant ``density_offset / 3`` and channel 0 of every line 1, i.e. the offset is added to
+    the feature by the tables themselves.
     """
     rng = np.random.default_rng(seed)
     G = [int(g) for g in grid]
@@ -100,6 +103,8 @@ def make_field_ckpt(grid: Sequence[int] = (300, 300, 300),
         gv = np.exp(-ax[v] ** 2 / (2 * blob_sigma ** 2))
         plane = amp * gb[None, :, None] * ga[None, None, :] * (1.0 + 0.15 * rng.standard_normal((n_sigma, G[b], G[a])))
         line = amp * gv[None, :] * (1.0 + 0.15 * rng.standard_normal((n_sigma, G[v])))
+        if density_offset != 0.0:
+            plane[0], line[0] = density_offset / 3.0, 1.0
         sd[f"density_plane.{i}"] = torch.from_numpy(plane.astype(np.float32))[None]
         sd[f"density_line.{i}"] = torch.from_numpy(line.astype(np.float32))[None, :, :, None]
     for i in range(3):
@@ -174,3 +179,54 @@ def make_tokens(m: int = 256, fea: int = 384, seed: int = 7) -> torch.Tensor:
     reps = int(math.ceil(m / pe.shape[0]))
     pe = np.tile(pe, (reps, 1))[:m]
     return torch.from_numpy(np.concatenate([feats, pe], axis=-1))
+
+
+# ----------------------------------------------------------------------------- BASELINE.json workloads
+def n_to_reso(n_voxels: int, aabb) -> list:
+    """gridSize for a voxel budget, as reference utils.py:20-24 (N_to_reso) derives it from the scene box."""
+    a = torch.as_tensor(aabb, dtype=torch.float32)
+    size = a[1] - a[0]
+    voxel = (size.prod() / n_voxels).pow(1 / 3)
+    return (size / voxel).long().tolist()
+
+
+# T&T-shaped scene box: the reference reads ``bbox.txt`` of the scene and scales it by 1.2 (dataLoader/tankstemple.py:
+# 113-119); the file is not available offline, so this is a fixed non-cubic box of Truck-like proportions (x 1.2 applied)
+TRUCK_AABB = ((-1.38, -0.90, -1.86), (1.44, 1.08, 1.98))
+
+# name -> what BASELINE.json's ``configs`` describe.  ``field``: make_field_ckpt arguments; ``gen_points`` x 27 = rays;
+# ``queries``: query images per step of bench.py; ``shared_rays``: all queries of a step see ONE emitted ray set (the
+# reference's eval semantics, train_eval_pose_est.py:131-149) instead of one fresh ray set per query.
+WORKLOADS = {
+    # configs[1]: "lego 800x800, 16k candidate rays": configs/lego.txt (300^3, blender box, near_far dataLoader/blender.py:41)
+    "lego16k": dict(
+        field=dict(grid=(300, 300, 300), aabb=((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5)), mask_res=(180, 180, 180), seed=1234,
+                   step_ratio=0.5, peak=20.0, near_far=(2.0, 6.0)),
+        gen_points=593, queries=16, shared_rays=False,
+        describe="lego-shaped TensorVMSplit 300^3 (16/48 comps, 180^3 mask), gen_points=593 -> 16011 rays"),
+    # configs[2]: "truck (Tanks&Temples) 1920x1080, 32k rays": configs/truck.txt (27e6 voxels over a non-cubic box,
+    # near_far dataLoader/tankstemple.py:113)
+    "truck32k": dict(
+        field=dict(grid=tuple(n_to_reso(27_000_000, TRUCK_AABB)), aabb=TRUCK_AABB, mask_res=(176, 124, 240), seed=4321,
+                   step_ratio=0.5, peak=20.0, near_far=(0.01, 6.0)),
+        gen_points=1186, queries=16, shared_rays=False,
+        describe="truck-shaped TensorVMSplit 27e6 voxels over a non-cubic T&T box, gen_points=1186 -> 32022 rays"),
+    # configs[4]: "mip360 bicycle (unbounded scene), 64k rays": configs/bicycle.txt (640^3, density_shift 0), scene box
+    # and near_far of dataLoader/mip360.py:215-219, contraction_type='unisphere' (models/tensorBase.py:389-396)
+    "bicycle64k": dict(
+        field=dict(grid=(640, 640, 640), aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), mask_res=(256, 256, 256), seed=777,
+                   step_ratio=0.5, peak=20.0, near_far=(0.01, 1.4), contraction_type="unisphere", density_shift=0.0,
+                   density_offset=-10.0, blob_sigma=0.30, mask_radius=0.62),
+        gen_points=2371, queries=16, shared_rays=False,
+        describe="bicycle-shaped TensorVMSplit 640^3, unisphere contraction, density_shift 0, gen_points=2371 -> 64017 rays"),
+    # configs[3]: "lego, batch of 64 query images, rays sharded across the GPUs": one emitted ray set per step
+    "lego_b64": dict(
+        field=dict(grid=(300, 300, 300), aabb=((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5)), mask_res=(180, 180, 180), seed=1234,
+                   step_ratio=0.5, peak=20.0, near_far=(2.0, 6.0)),
+        gen_points=593, queries=64, shared_rays=True,
+        describe="lego-shaped TensorVMSplit 300^3, ONE emitted ray set (16011 rays) per step shared by a batch of 64 query images"),
+}
+
+
+def make_workload_ckpt(name: str) -> dict:
+    return make_field_ckpt(**WORKLOADS[name]["field"])

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 1
+#define IFF_ABI_VERSION 2
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -85,6 +85,10 @@ typedef struct iff_field_desc {
     float   near_far[2];
     int32_t softplus;                /* 1: fea2denseAct == "softplus", 0: relu (tensorBase.py:750-754) */
     int32_t unisphere;               /* 1: contraction_type == "unisphere" (tensorBase.py:390-396) */
+    int32_t density_lanes;           /* lanes that share one density lookup (compute_densityfeature, tensoRF.py:216-235) in the
+                                        march and the surface sampler: 0 = choose (one lane per point when a density texel
+                                        is one 64-B line, and for sampler batches < 8 four), 1 or 4 = force that form.  Both
+                                        forms produce the same bits; the knob exists for A/B tests and tuning. */
     /* Ref head, models/ref.py:69-101 (nn.Linear layouts [out,in]) */
     const float* normal_w;  const float* normal_b;    /* [3,app_dim],[3] */
     const float* tint_w;    const float* tint_b;      /* [3,app_dim],[3] */

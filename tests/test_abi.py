@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     # the ctypes table binds exactly the declared surface
     assert sorted(_lib.SIGNATURES) == names
     bound = _lib.lib()
-    assert bound.iff_abi_version() == 1
+    assert bound.iff_abi_version() == _lib.ABI_VERSION
     assert bound.iff_last_error() == b""
 
 

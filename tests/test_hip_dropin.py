@@ -143,25 +143,6 @@ def test_captured_query_replays_like_eager(dev):
     assert torch.equal(cq.c2w, eager[1][0]) and torch.equal(cq2.c2w, eager[3][0])
 
 
-def test_prefetching_captured_query(dev):
-    """Software-pipelined capture: replay r runs on the points the graph's sampler branch drew during replay r - 1, so
-    it equals the eager query with seed offset r - 1; one fresh draw is consumed and one produced per replay."""
-    from iffnerf_amd.pipeline import PosePipeline
-    ck = util.ckpt("small")
-    pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
-    tok = synthetic.make_tokens(256, 384, seed=7).to(dev)
-    eager = {s: [t.clone() for t in pipe.query(tok, 75, seed=500 + s, k=100)] for s in range(0, 5)}
-    cq = pipe.capture_query(tok.shape, 75, seed=500, k=100, prefetch_emission=True)
-    cq.tokens.copy_(tok)
-    torch.cuda.synchronize()
-    for r in range(1, 6):
-        cq.replay()
-        torch.cuda.synchronize()
-        assert int(cq.counter.item()) == r
-        want = eager[r - 1]
-        assert torch.equal(cq.idx, want[1]) and torch.equal(cq.val, want[2]) and torch.equal(cq.c2w, want[0]), r
-
-
 def test_batched_cold_queries_equal_single_queries(dev):
     """query_batch: B cold queries per set of launches (batched sampler, grid.y = query in the encoder/logits launch).
     Query b must equal the single-query path with seed + b * SAMPLER_SEED_STRIDE bit for bit; also as a captured graph."""

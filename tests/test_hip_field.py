@@ -156,57 +156,21 @@ def test_determinism(small, dev):
         assert torch.equal(x, y)
 
 
-_MARCH_DUMP = r"""
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from iffnerf_amd import synthetic
-from iffnerf_amd.pipeline import PosePipeline
-from tests import util
-dev = torch.device("cuda:0")
-pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev)
-out = {}
-for P in (75, 9, 1):
-    ori, dirs, rgb = pipe.emit(P, seed=17)
-    rays = torch.cat((ori, dirs), -1).contiguous()
-    out[f"point{P}"] = [t.cpu() for t in pipe.field.march(rays, 0, 20, want_alpha=True, want_counts=True) if torch.is_tensor(t)]
-    out[f"slab{P}"] = [t.cpu() for t in pipe.field.march(rays[:50], 1, 0, want_alpha=True, want_counts=True) if torch.is_tensor(t)]
-torch.save(out, sys.argv[2])
-"""
-
-
-def test_one_lane_density_gather_is_bit_identical_to_the_four_lane_form(tmp_path):
+def test_one_lane_density_gather_is_bit_identical_to_the_four_lane_form(dev):
     """K4a with one lane per sample (taps computed once for all 16 density channels) against the four-lanes-per-sample form
-    (IFF_K4A_LPS=4): density_full reproduces the butterfly's summation order, so every output must be equal, in the
-    point-centred and in the slab sampler."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for tag, env in (("one", {}), ("four", {"IFF_K4A_LPS": "4"})):
-        path = str(tmp_path / f"{tag}.pt")
-        r = subprocess.run([sys.executable, "-c", _MARCH_DUMP, root, path], capture_output=True, text=True, timeout=600,
-                           env={**os.environ, **env})
-        assert r.returncode == 0, r.stderr[-3000:]
-        outs.append(torch.load(path))
-    one, four = outs
-    for k in one:
-        assert len(one[k]) == len(four[k]) >= 5
-        for x, y in zip(one[k], four[k]):
-            assert torch.equal(x, y), k
-
-
-def test_appearance_gather_lane_groupings_are_bit_identical(tmp_path):
-    """K4b with 12, 6 or 3 lanes per ray (IFF_K4B_Q = 1, 2, 4 texel quarters per lane): the per-channel arithmetic is the
-    same and the basis_mat sum keeps the 12-lane butterfly's pairing, so rgb / depth / acc / alpha are equal bit for bit."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for q in ("1", "2", "4"):
-        path = str(tmp_path / f"q{q}.pt")
-        r = subprocess.run([sys.executable, "-c", _MARCH_DUMP, root, path], capture_output=True, text=True, timeout=600,
-                           env={**os.environ, "IFF_K4B_Q": q})
-        assert r.returncode == 0, r.stderr[-3000:]
-        outs.append(torch.load(path))
-    for other in outs[1:]:
-        for k in outs[0]:
-            for x, y in zip(outs[0][k], other[k]):
-                assert torch.equal(x, y), k
+    (iff_field_desc.density_lanes = 4): density_full reproduces the butterfly's summation order, so every output must be
+    equal, in the point-centred and in the slab sampler."""
+    from iffnerf_amd import synthetic
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    from iffnerf_amd.pipeline import PosePipeline
+    ck = util.ckpt("small")
+    pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev)
+    one, four = field_handle_from_ckpt(ck, dev, density_lanes=1), field_handle_from_ckpt(ck, dev, density_lanes=4)
+    for P in (75, 9, 1):
+        ori, dirs, _ = pipe.emit(P, seed=17)
+        rays = torch.cat((ori, dirs), -1).contiguous()
+        for r, mode, S in ((rays, 0, 20), (rays[:50].contiguous(), 1, 0)):
+            a = one.march(r, mode, S, want_alpha=True, want_counts=True)
+            b = four.march(r, mode, S, want_alpha=True, want_counts=True)
+            for x, y in zip(a[:5], b[:5]):
+                assert torch.equal(x, y), (P, mode)

@@ -101,39 +101,19 @@ def test_small_and_degenerate(small, dev):
         small.surface_sample(0, 0.1)
 
 
-_SAMPLER_DUMP = r"""
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from iffnerf_amd import synthetic
-from iffnerf_amd.pipeline import PosePipeline
-from tests import util
-dev = torch.device("cuda:0")
-pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev)
-out = {}
-for P in (75, 593, 5):
-    s, a, st = pipe.field.surface_sample(P, pipe.rho, 4, 200, seed=11)
-    out[f"one{P}"] = [s.cpu(), a.cpu(), st.cpu()]
-    s, a, st = pipe.field.surface_sample_batched(3, P, pipe.rho, 4, 200, seed=11)
-    out[f"batch{P}"] = [s.cpu(), a.cpu(), st.cpu()]
-torch.save(out, sys.argv[2])
-"""
-
-
-def test_one_lane_candidates_draw_the_same_samples(tmp_path):
+def test_one_lane_candidates_draw_the_same_samples(dev):
     """The sampler with one lane per candidate (a quarter of the workgroups) against the four-lane form
-    (IFF_SAMPLER_LPC=4): same random streams, same alpha bits (density_full), so samples / alpha / statistics are equal."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for tag, env in (("one", {}), ("four", {"IFF_SAMPLER_LPC": "4"})):
-        path = str(tmp_path / f"{tag}.pt")
-        r = subprocess.run([sys.executable, "-c", _SAMPLER_DUMP, root, path], capture_output=True, text=True, timeout=600,
-                           env={**os.environ, **env})
-        assert r.returncode == 0, r.stderr[-3000:]
-        outs.append(torch.load(path))
-    for k in outs[0]:
-        for x, y in zip(outs[0][k], outs[1][k]):
-            assert torch.equal(x, y), k
+    (iff_field_desc.density_lanes = 1 / 4): same random streams, same alpha bits (density_full), so samples / alpha /
+    statistics are equal."""
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    ck = util.ckpt("small")
+    rho = rho_of(ck)
+    one, four = field_handle_from_ckpt(ck, dev, density_lanes=1), field_handle_from_ckpt(ck, dev, density_lanes=4)
+    for P in (75, 593, 5):
+        for a, b in zip(one.surface_sample(P, rho, 4, 200, seed=11), four.surface_sample(P, rho, 4, 200, seed=11)):
+            assert torch.equal(a, b), P
+        for a, b in zip(one.surface_sample_batched(3, P, rho, 4, 200, seed=11), four.surface_sample_batched(3, P, rho, 4, 200, seed=11)):
+            assert torch.equal(a, b), P
 
 
 def test_batched_runs_large_point_counts_and_residency(small, dev):
