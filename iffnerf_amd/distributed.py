@@ -10,7 +10,12 @@ and the path needs exactly two small exchanges per batch of queries:
   2. per-query local top-k (value, global ray index, origin, direction): ``all_gather`` of [Q, k, 8] floats per rank,
      reduced to the global top-k with the single-GPU tie rule (higher value first, lower index on ties).
 
-Both messages are a few KB: latency-bound, no bandwidth tuning needed.  The functions below contain only the exchange
+Batches of COLD queries (every query with its own freshly drawn ray set, ``PosePipeline.query_batch_sharded``) add one
+exchange in front: each rank draws the surface points of its own B queries (the sampler is globally coupled per query) and
+folds its own B token blocks, and one ``all_gather`` of [B*P*3 + B*M*272] floats per rank (4.5 MB at B = 16) hands every
+rank the points and folded queries of all G*B queries, of which it then emits, marches and encodes its block.
+
+The messages are a few KB to a few MB: latency-bound, no bandwidth tuning needed.  The functions below contain only the exchange
 and merge logic on small tensors and are device-agnostic, so the world_size-2 ``gloo`` tests on CPU exercise the very
 code the GPU ranks run; the heavy local work is passed in by the caller (HIP on the GPU, the oracle in those tests).
 """
@@ -39,9 +44,25 @@ def _all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
     rank, ws = world(group)
     if ws == 1:
         return t[None]
-    out = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(out, t.contiguous(), group=group)
-    return torch.stack(out)
+    out = t.new_empty((ws,) + tuple(t.shape))
+    all_gather_into(out, t, group)
+    return out
+
+
+def all_gather_into(out: torch.Tensor, src: torch.Tensor, group=None) -> None:
+    """``out`` [world, *src.shape] <- every rank's ``src``, in rank order.  With the ``nccl`` (= RCCL) backend this is one
+    ``all_gather_into_tensor`` on device memory.  With ``gloo`` and device tensors (rehearsing several ranks on ONE GPU,
+    where RCCL refuses two ranks per device) the message is staged through host memory; without a process group it is a copy."""
+    if not (dist.is_available() and dist.is_initialized()):
+        out.copy_(src[None])
+        return
+    flat = out.view((-1,) + tuple(src.shape[1:])) if src.dim() > 0 else out.view(-1)
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(flat.shape, dtype=flat.dtype)
+        dist.all_gather_into_tensor(host, src.detach().cpu().contiguous(), group=group)
+        flat.copy_(host)
+        return
+    dist.all_gather_into_tensor(flat, src.contiguous(), group=group)
 
 
 def merge_row_stats(row_max: torch.Tensor, row_sumexp: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -14,7 +14,8 @@ import torch
 from . import _lib
 from ._lib import check, dptr, fvec, stream_ptr
 
-GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_LAYERED = 0, 1, 2        # include/iffnerf_hip.h IFF_GEMM_*
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_LAYERED, GEMM_F16X2 = 0, 1, 2, 3        # include/iffnerf_hip.h IFF_GEMM_*
+GEMM_DEFAULT = GEMM_BF16X3
 
 _KEYS = (("l1", "ray_preprocessor.mlp.0"), ("l2", "ray_preprocessor.mlp.2"), ("l3", "ray_preprocessor.mlp2.0"),
          ("l4", "ray_preprocessor.mlp2.2"), ("q", "attention.q_proj"), ("k", "attention.k_proj"))
@@ -32,9 +33,9 @@ def _gpu(t: torch.Tensor, name: str, cols: Optional[int] = None) -> torch.Tensor
 class IdNetHandle:
     """Weights of RayPreprocessor + MultiHeadAttention, transposed/padded once for the MFMA GEMMs."""
 
-    def __init__(self, weights: Dict[str, torch.Tensor], device, gemm_mode: int = GEMM_BF16X3):
+    def __init__(self, weights: Dict[str, torch.Tensor], device, gemm_mode: Optional[int] = None):
         self._h = None
-        self.gemm_mode = int(gemm_mode)
+        self.gemm_mode = int(GEMM_DEFAULT if gemm_mode is None else gemm_mode)
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(f"IdNetHandle needs a GPU device (got {device}); libiffnerf_hip has no CPU path")
@@ -68,6 +69,22 @@ class IdNetHandle:
             self.close()
         except Exception:
             pass
+
+    # ------------------------------------------------------------------ bookkeeping for bench.py's roofline
+    def mfma_products(self) -> int:
+        """MFMA products the matrix-product mode issues per fp32-accurate product (include/iffnerf_hip.h IFF_GEMM_*)."""
+        return {GEMM_F32: 1, GEMM_BF16X3: 6, GEMM_BF16X3_LAYERED: 6, GEMM_F16X2: 3}[self.gemm_mode]
+
+    def gemm_description(self) -> str:
+        return {GEMM_F32: "fp32-input MFMA (k-ordered fmaf chain)",
+                GEMM_BF16X3: "3xBF16 split on the bf16 MFMA (6 products, fp32-accurate), fp32 accumulate",
+                GEMM_BF16X3_LAYERED: "3xBF16 split on the bf16 MFMA, one launch per layer",
+                GEMM_F16X2: "2xFP16 split on the fp16 MFMA (3 products, fp32-accurate), fp32 accumulate",
+                }[self.gemm_mode] + "; march and shading in fp32"
+
+    def trunk_kernel_name(self) -> str:
+        """Name of the fused encoder + logits kernel as rocprofv3 prints it (profiles/*.csv)."""
+        return {GEMM_F16X2: "k5_trunk_h<true>"}.get(self.gemm_mode, "k5_trunk<true, 1>")
 
     # ------------------------------------------------------------------ K5
     def ray_encode(self, o, d, rgb, want_features: bool = True, want_k: bool = False):

@@ -47,8 +47,8 @@ class PosePipeline:
 
     @classmethod
     def from_checkpoints(cls, field_ckpt: dict, id_weights: Dict[str, torch.Tensor], device, model_up=(0.0, 0.0, 1.0),
-                         fold_heads: bool = True):
-        return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device),
+                         fold_heads: bool = True, gemm_mode: Optional[int] = None):
+        return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device, gemm_mode),
                    jitter_scale_from_kwargs(field_ckpt["kwargs"], "alphaMask.aabb" in field_ckpt), model_up, fold_heads)
 
     def logits(self, tokens, ori, dirs, rgb):
@@ -194,6 +194,74 @@ class PosePipeline:
     def capture_query_sharded(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100, group=None) -> "CapturedShardedQuery":
         return CapturedShardedQuery(self, tokens_shape, gen_points, seed, k, group)
 
+    # ------------------------------------------------------------------ ray-sharded batches of COLD queries (multi-GPU)
+    # Every rank owns B query images per step; EVERY query's freshly drawn ray set is sharded over all G ranks (contiguous
+    # blocks of its surface points), so a step serves G*B cold queries and per-rank work does not depend on G.  Four local
+    # segments with three small all_gathers between them.  Global query g = rank * B + b draws with
+    # seed + g * SAMPLER_SEED_STRIDE: the G*B queries are exactly those of ``query_batch`` with G*B token blocks on one GPU.
+    def batch_shard_draw(self, tokens_local, gen_points: int, seed: int, rank: int, seed_offset=None):
+        """Segment 1: this rank's B surface-sampler runs (the sampler is globally coupled per query -- quantile,
+        candidate budget -- so one rank draws all P points of a query) and its B folded query blocks, packed as ONE
+        message [B*P*3 + B*M*qw] for the first all_gather."""
+        from .hip_field import SAMPLER_SEED_STRIDE
+        B, M, C = tokens_local.shape
+        s = (int(seed) + rank * B * SAMPLER_SEED_STRIDE) % (1 << 64)
+        samples, _, stats = self.field.surface_sample_batched(B, gen_points, self.rho, n_epochs=4, max_iterations=200, seed=s,
+                                                              seed_offset=seed_offset)
+        self.last_sampler_stats = stats
+        qf = self.idnet.q_fold(tokens_local.reshape(B * M, C))
+        return torch.cat((samples.reshape(-1), qf.reshape(-1)))
+
+    def batch_shard_local_logits(self, msg_all, B: int, M: int, gen_points: int, rank: int, ws: int):
+        """Segment 2: ``msg_all`` [G, L] (every rank's segment-1 message) -> this rank's block of EVERY query's ray set and
+        its logits columns: (ori, dirs [G*B*n_local, 3] query-major, logits [G*B*M, n_local], stats [G*B*M, 2])."""
+        from . import distributed as D
+        G, P = msg_all.shape[0], gen_points
+        ns = B * P * 3
+        samples = msg_all[:, :ns].reshape(G * B, P, 3)
+        qf = msg_all[:, ns:].reshape(G * B * M, -1).contiguous()
+        lo, hi = D.shard_points(P, rank, ws)
+        ori, dirs, rgb = self.emit_from_samples(samples[:, lo:hi].reshape(-1, 3).contiguous())
+        logits, rmax, rsum = self.idnet.ray_logits_folded_batched(qf, ori, dirs, rgb, G * B)
+        return ori, dirs, logits, torch.stack((rmax, rsum), dim=-1)
+
+    def batch_shard_local_candidates(self, logits, stats_all, ori, dirs, QT: int, k: int, first_ray: int):
+        """Segment 3: global statistics -> this rank's score columns -> its top-k candidates of every query [QT, k, 8]
+        (as ``shard_local_candidates``, with one ray set per query)."""
+        from . import distributed as D
+        gmax, gsum = D.merge_row_stats_gathered(stats_all)
+        score = H.attn_colsum_batched(logits, gmax.contiguous(), gsum.contiguous(), QT, write_attention=False)
+        n_local = score.shape[1]
+        kl = min(k, n_local)
+        i, v = H.topk_batched(score, kl)
+        gi = i[..., None].expand(-1, -1, 3)
+        lval = ori.new_full((QT, k), float("-inf"))
+        lidx = torch.full((QT, k), 2 ** 31 - 1, dtype=torch.int64, device=ori.device)
+        pay = ori.new_zeros(QT, k, 6)
+        lval[:, :kl], lidx[:, :kl] = v, i + first_ray
+        pay[:, :kl, :3] = torch.gather(ori.view(QT, n_local, 3), 1, gi)
+        pay[:, :kl, 3:] = torch.gather(dirs.view(QT, n_local, 3), 1, gi)
+        return D.pack_candidates(lval, lidx, pay)
+
+    def batch_shard_global_poses(self, cand_all, k: int, rank: int, B: int):
+        """Segment 4: every rank's candidates [G, G*B, k, 8] -> the poses of THIS rank's B queries (poses [B,4,4], val, idx)."""
+        return self.shard_global_poses(cand_all[:, rank * B:(rank + 1) * B].contiguous(), k)
+
+    def query_batch_sharded(self, tokens_local, gen_points: int, seed: int, k: int = 100, group=None, seed_offset=None):
+        """``tokens_local`` [B,M,C]: this rank's B cold queries.  Every rank returns the poses / top-k of its own queries;
+        with one rank this is ``query_batch``."""
+        from . import distributed as D
+        rank, ws = D.world(group)
+        B, M, _ = tokens_local.shape
+        lo, _ = D.shard_points(gen_points, rank, ws)
+        msg = self.batch_shard_draw(tokens_local, gen_points, seed, rank, seed_offset)
+        ori, dirs, logits, stats = self.batch_shard_local_logits(D._all_gather_stack(msg, group), B, M, gen_points, rank, ws)
+        cand = self.batch_shard_local_candidates(logits, D._all_gather_stack(stats, group), ori, dirs, ws * B, k, lo * 27)
+        return self.batch_shard_global_poses(D._all_gather_stack(cand, group), k, rank, B)
+
+    def capture_query_batch_sharded(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100, group=None) -> "CapturedShardedBatch":
+        return CapturedShardedBatch(self, tokens_shape, gen_points, seed, k, group)
+
 
 class CapturedQuery:
     """The cold query captured once as a hipGraph (torch.cuda.CUDAGraph) and replayed per query.
@@ -279,12 +347,8 @@ class CapturedShardedQuery:
             self.poses, self.val, self.idx = pipe.shard_global_poses(self.cand_all, k)
 
     def _gather(self, out, src):
-        import torch.distributed as dist
-        if self.collective:
-            # `out` is [world, *src.shape]; pass it as the concatenation along dim 0, the form every backend accepts
-            dist.all_gather_into_tensor(out.view((-1,) + tuple(src.shape[1:])), src, group=self.group)
-        else:
-            out.copy_(src[None])
+        from . import distributed as D
+        D.all_gather_into(out, src, self.group)
 
     def check(self) -> None:
         """After a synchronised replay: raise if this instance's last sampler run timed out (see check_sampler_stats)."""
@@ -333,3 +397,59 @@ class CapturedBatchQuery:
             self.tokens.copy_(tokens, non_blocking=True)
         self.graph.replay()
         return self.c2w
+
+
+class CapturedShardedBatch:
+    """``PosePipeline.query_batch_sharded`` as four captured hipGraph segments with the three RCCL all_gathers issued eagerly
+    between them (samples + folded queries | softmax statistics | top-k candidates).  Static buffers: ``tokens`` [B,M,C] in
+    (this rank's queries); ``poses`` [B,4,4], ``val`` / ``idx`` [B,k] out."""
+
+    def __init__(self, pipe: PosePipeline, tokens_shape, gen_points: int, seed: int = 0, k: int = 100, group=None):
+        from . import distributed as D
+        dev = pipe.device
+        self.pipe, self.group = pipe, group
+        self.rank, self.ws = D.world(group)
+        B, M = int(tokens_shape[0]), int(tokens_shape[1])
+        lo, _ = D.shard_points(gen_points, self.rank, self.ws)
+        self.tokens = torch.zeros(tokens_shape, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                 # warm-up outside capture (lazy initialisations, allocator, RCCL)
+            for _ in range(2):
+                pipe.query_batch_sharded(self.tokens, gen_points, seed, k, group, seed_offset=self.counter)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        opts = dict(capture_error_mode="thread_local")     # the RCCL watchdog thread must not invalidate a capture
+        self.g1, self.g2, self.g3, self.g4 = (torch.cuda.CUDAGraph() for _ in range(4))
+        with torch.cuda.graph(self.g1, **opts):
+            self.counter += 1
+            self.msg = pipe.batch_shard_draw(self.tokens, gen_points, seed, self.rank, seed_offset=self.counter)
+            self.sampler_stats = pipe.last_sampler_stats
+        self.msg_all = self.msg.new_zeros((self.ws,) + tuple(self.msg.shape))
+        with torch.cuda.graph(self.g2, **opts):
+            ori, dirs, logits, self.stats = pipe.batch_shard_local_logits(self.msg_all, B, M, gen_points, self.rank, self.ws)
+        self._seg2 = (ori, dirs, logits)              # g3 reads these blocks of g2's private pool: keep them allocated
+        self.stats_all = self.stats.new_zeros((self.ws,) + tuple(self.stats.shape))
+        with torch.cuda.graph(self.g3, **opts):
+            self.cand = pipe.batch_shard_local_candidates(logits, self.stats_all, ori, dirs, self.ws * B, k, lo * 27)
+        self.cand_all = self.cand.new_zeros((self.ws,) + tuple(self.cand.shape))
+        with torch.cuda.graph(self.g4, **opts):
+            self.poses, self.val, self.idx = pipe.batch_shard_global_poses(self.cand_all, k, self.rank, B)
+        self.c2w = self.poses
+
+    def check(self) -> None:
+        check_sampler_stats(self.sampler_stats)
+
+    def replay(self, tokens: Optional[torch.Tensor] = None):
+        from . import distributed as D
+        if tokens is not None:
+            self.tokens.copy_(tokens, non_blocking=True)
+        self.g1.replay()
+        D.all_gather_into(self.msg_all, self.msg, self.group)
+        self.g2.replay()
+        D.all_gather_into(self.stats_all, self.stats, self.group)
+        self.g3.replay()
+        D.all_gather_into(self.cand_all, self.cand, self.group)
+        self.g4.replay()
+        return self.poses

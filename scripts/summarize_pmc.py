@@ -1,13 +1,26 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc passes into profiles/: per-kernel means of FETCH_SIZE / WRITE_SIZE (KiB per dispatch) and the
-HBM-side bytes per launch with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports by 2x):
+"""Summarise rocprofv3 --pmc passes (one directory per pass, `--output-format csv`) into profiles/.
 
-    hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+    summarize_pmc.py <out_prefix> <config> <pass_dir> [<pass_dir> ...]
 
-usage: summarize_pmc.py <fetch_dir> <write_dir> <out_prefix>      e.g.  gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 profiles/r01v3
+Writes
+  <out_prefix>_pmc_counters.csv   per kernel: dispatches and the mean of every collected counter (one column per counter)
+  <out_prefix>_hbm_traffic.json   {"source_sha16", "config", "kernels": {name: {fetch_KiB_raw, write_KiB,
+                                  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, ...derived ratios}}}
+The x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (section HBM): FETCH_SIZE reports half the bytes of a
+wide coalesced read; for 64-B gathers it is uncalibrated, so read the figure as an upper bound of 2x the raw count.
+Derived per kernel where the counters exist (SQ_* cycle counters are in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES and
+SQ_BUSY_CYCLES; ratios of like units only):
+  valu_active_share   = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES        share of wave lifetime with a VALU instruction executing
+  wait_share          = SQ_WAIT_ANY / SQ_WAVE_CYCLES                 ... parked at s_waitcnt / barrier
+  issue_stall_share   = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES            ... stalled at issue
+  mfma_busy_share     = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMDs per CU ...)  reported raw, see profiles/README.md
+  l2_hit_rate         = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
 """
-import csv, glob, json, re, sys
+import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
@@ -15,34 +28,55 @@ def short(name):
     return name.split("(")[0][:120]
 
 
-def means(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-    acc = defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter:
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: (len(v), sum(v) / len(v), min(v), max(v)) for k, v in acc.items()}
+def source_fingerprint():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "iffnerf_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
-    fd, wd, out = sys.argv[1:4]
-    fe, wr = means(fd, "FETCH_SIZE"), means(wd, "WRITE_SIZE")
-    for tag, m in (("FETCH_SIZE", fe), ("WRITE_SIZE", wr)):
-        with open(f"{out}_pmc_{tag}.csv", "w", newline="") as fh:
-            w = csv.writer(fh)
-            w.writerow(["Kernel_Name", "Counter", "Dispatches", "Mean_KB", "Min_KB", "Max_KB"])
-            for k in sorted(m):
-                n, mean, lo, hi = m[k]
-                w.writerow([k, tag, n, round(mean, 1), lo, hi])
-    js = {}
-    for k in sorted(set(fe) | set(wr)):
-        f = fe.get(k, (0, 0.0, 0, 0))[1]
-        w = wr.get(k, (0, 0.0, 0, 0))[1]
-        js[k] = {"fetch_KiB_raw": round(f, 1), "write_KiB": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    out, config, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    acc = defaultdict(lambda: defaultdict(list))          # kernel -> counter -> values
+    for d in dirs:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = sorted({c for k in acc for c in acc[k]})
+    mean = {k: {c: sum(v) / len(v) for c, v in acc[k].items()} for k in acc}
+    with open(f"{out}_pmc_counters.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Kernel_Name", "Dispatches"] + counters)
+        for k in sorted(acc):
+            n = max(len(v) for v in acc[k].values())
+            w.writerow([k, n] + [("%.6g" % mean[k][c]) if c in mean[k] else "" for c in counters])
+    js = {"source_sha16": source_fingerprint(), "config": config, "kernels": {}}
+    for k in sorted(acc):
+        m = mean[k]
+        e = {}
+        if "FETCH_SIZE" in m or "WRITE_SIZE" in m:
+            f, wv = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
+            e.update(fetch_KiB_raw=round(f, 1), write_KiB=round(wv, 1), hbm_bytes_per_launch=int((2 * f + wv) * 1024))
+        wc = m.get("SQ_WAVE_CYCLES")
+        if wc:
+            for name, c in (("valu_active_share", "SQ_ACTIVE_INST_VALU"), ("wait_share", "SQ_WAIT_ANY"),
+                            ("issue_stall_share", "SQ_WAIT_INST_ANY"), ("any_inst_active_share", "SQ_ACTIVE_INST_ANY"),
+                            ("lds_active_share", "SQ_ACTIVE_INST_LDS"), ("vmem_active_share", "SQ_ACTIVE_INST_VMEM")):
+                if c in m:
+                    e[name] = round(m[c] / wc, 4)
+        if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"] > 0:
+            e["mfma_busy_cycles_over_sq_busy_cycles"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"], 4)
+        if e:
+            js["kernels"][k] = e
     json.dump(js, open(f"{out}_hbm_traffic.json", "w"), indent=1, sort_keys=True)
-    for k in ("k4b_appearance<27, true, 1>", "k4b_appearance<27, true>", "k4b_appearance<27>", "k4a_density_composite<1>", "k4a_density_composite", "k_ref_shade<27, true>", "k5_trunk<true, 1>", "k5_trunk<true>", "k6_colsum", "k_surface_sample"):
-        if k in js:
-            print(k, js[k])
+    for k in js["kernels"]:
+        if any(t in k for t in ("k4b", "k4a", "k5_trunk", "k_ref_shade", "k6_", "k_surface", "k_score")):
+            print(k, js["kernels"][k])
 
 
 if __name__ == "__main__":

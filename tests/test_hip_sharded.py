@@ -163,3 +163,97 @@ def test_large_ray_sets_keep_the_invariants(dev):
         poses, val3, idx3 = pipe.shard_global_poses(cands, 100)
         assert torch.equal(idx3, want_idx)
         torch.testing.assert_close(poses, want_pose, atol=1e-5, rtol=0)
+
+
+def test_batched_cold_queries_sharded_over_emulated_ranks_equal_one_gpu(pipe, dev):
+    """query_batch_sharded's four segments with G = 2 and 3 ranks emulated on one GPU (the three all_gathers replaced by
+    stacking the per-rank messages): the G*B cold queries are those of query_batch on one GPU -- same random streams, same
+    rays, hence the same top-100 lists and poses."""
+    from iffnerf_amd import distributed as D
+    P, k, M, B = 75, 100, 64, 2
+    for G in (2, 3):
+        tok = torch.stack([synthetic.make_tokens(M, 384, seed=40 + q) for q in range(G * B)]).to(dev)
+        want_c2w, want_idx, want_val = pipe.query_batch(tok, P, seed=1234, k=k)
+        msgs = torch.stack([pipe.batch_shard_draw(tok[r * B:(r + 1) * B].contiguous(), P, 1234, r) for r in range(G)])
+        seg2 = [pipe.batch_shard_local_logits(msgs, B, M, P, r, G) for r in range(G)]
+        assert sum(s[0].shape[0] for s in seg2) == G * B * P * 27
+        stats_all = torch.stack([s[3] for s in seg2])
+        cand_all = torch.stack([pipe.batch_shard_local_candidates(s[2], stats_all, s[0], s[1], G * B, k, D.shard_points(P, r, G)[0] * 27)
+                                for r, s in enumerate(seg2)])
+        for r in range(G):
+            poses, val, idx = pipe.batch_shard_global_poses(cand_all, k, r, B)
+            assert torch.equal(idx, want_idx[r * B:(r + 1) * B]), (G, r)
+            torch.testing.assert_close(val, want_val[r * B:(r + 1) * B], atol=0, rtol=1e-5)
+            torch.testing.assert_close(poses, want_c2w[r * B:(r + 1) * B], atol=1e-5, rtol=0)
+    # one rank, no process group: the sharded path IS the batch path
+    tok = torch.stack([synthetic.make_tokens(M, 384, seed=40 + q) for q in range(3)]).to(dev)
+    a = pipe.query_batch_sharded(tok, P, seed=77, k=k)
+    b = pipe.query_batch(tok, P, seed=77, k=k)
+    assert torch.equal(a[2], b[1]) and torch.equal(a[0], b[0])
+
+
+_GLOO_2RANKS = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank = int(sys.argv[3])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE="2")
+from iffnerf_amd import synthetic
+from iffnerf_amd.pipeline import PosePipeline
+from tests import util
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")          # two ranks on ONE GPU: RCCL refuses that, gloo stages the messages through the host
+pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
+B, M, P, k = 2, 64, 75, 100
+tok_all = torch.stack([synthetic.make_tokens(M, 384, seed=40 + q) for q in range(2 * B)]).to(dev)
+mine = tok_all[rank * B:(rank + 1) * B].contiguous()
+out = {}
+out["eager"] = [t.cpu() for t in pipe.query_batch_sharded(mine, P, seed=1234, k=k)]
+cq = pipe.capture_query_batch_sharded(mine.shape, P, seed=1234, k=k)
+cq.tokens.copy_(mine)
+for rep in (1, 2):
+    cq.replay(); torch.cuda.synchronize(); cq.check()
+    out[f"replay{rep}"] = [cq.poses.cpu().clone(), cq.val.cpu().clone(), cq.idx.cpu().clone()]
+# the shared-ray-set form (BASELINE configs[3]) through the same transport
+out["shared"] = [t.cpu() for t in pipe.query_sharded(tok_all, P, seed=55, k=k)]
+if rank == 0:
+    want = {"eager": pipe.query_batch(tok_all, P, seed=1234, k=k)}
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    for rep in (1, 2):
+        ctr += 1
+        want[f"replay{rep}"] = pipe.query_batch(tok_all, P, seed=1234, k=k, seed_offset=ctr)
+    out["want"] = {key: [t.cpu() for t in v] for key, v in want.items()}
+    out["want_shared"] = [torch.stack([pipe.query(tok_all[q], P, seed=55, k=k)[j] for q in range(2 * B)]).cpu() for j in range(3)]
+torch.save(out, sys.argv[4])
+dist.barrier()
+dist.destroy_process_group()
+print("GLOO_2RANKS_OK")
+"""
+
+
+@pytest.mark.timeout(900)
+def test_two_real_ranks_on_one_gpu_over_gloo(tmp_path):
+    """Two PROCESSES (ranks 0 and 1 of a gloo group, both on the one GPU of the box) run the sharded paths end to end -- eager,
+    and as captured segments with the collectives between them: every rank's poses / top-100 are those of the one-GPU
+    batch path.  Only the transport differs from the 8-GPU run (gloo through host memory instead of RCCL over xGMI)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, "-c", _GLOO_2RANKS, ROOT, str(port), str(r), str(tmp_path / f"r{r}.pt")],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=800) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "GLOO_2RANKS_OK" in so, so[-2000:] + se[-4000:]
+    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(2)]
+    B = 2
+    for key in ("eager", "replay1", "replay2"):
+        c2w, idx, val = r[0]["want"][key]
+        for rank in range(2):
+            poses, v, i = r[rank][key]
+            assert torch.equal(i, idx[rank * B:(rank + 1) * B]), (key, rank)
+            torch.testing.assert_close(v, val[rank * B:(rank + 1) * B], atol=0, rtol=1e-5)
+            torch.testing.assert_close(poses, c2w[rank * B:(rank + 1) * B], atol=1e-5, rtol=0)
+    w_c2w, w_idx, w_val = r[0]["want_shared"]
+    for rank in range(2):
+        poses, v, i = r[rank]["shared"]
+        assert torch.equal(i, w_idx) and torch.equal(poses, r[0]["shared"][0])
+        torch.testing.assert_close(poses, w_c2w, atol=1e-5, rtol=0)

@@ -52,3 +52,21 @@ def ckpt(which: str, **over):
 def check_digest(golden_arr, sd):
     want = bytes(np.asarray(golden_arr, dtype=np.uint8)).hex()
     assert digest(sd) == want, "seeded synthetic weights drifted from the ones the golden vectors were made with"
+
+
+def assert_topk_matches(idx_got: torch.Tensor, score_ref: torch.Tensor, k: int, rel_tie: float = 2e-5) -> int:
+    """``idx_got`` [k] must be the oracle's top-k list (value descending, lower index first on ties).  Returns the number of
+    positions at which the two lists differ; a difference is tolerated (counted, not failed) only when the oracle's own
+    scores of the rays involved lie within ``rel_tie`` of each other, i.e. when the order is decided by fp32 rounding --
+    anything else fails here.  Callers that need the bit-exact list assert that the return value is 0."""
+    s = score_ref.double()
+    want = torch.argsort(score_ref, descending=True, stable=True)[:k].tolist()
+    got = idx_got.tolist()
+    if got == want:
+        return 0
+    kth = float(s[want[-1]])
+    for i in set(got) ^ set(want):
+        assert abs(float(s[i]) - kth) <= rel_tie * abs(kth), f"ray {i} is in one top-{k} set only and is not a near-tie of the k-th score"
+    sg = s[got]
+    assert bool(((sg[1:] - sg[:-1]) <= rel_tie * sg[:-1].abs()).all()), "returned order is not the oracle's score order"
+    return sum(int(a != b) for a, b in zip(got, want))
