@@ -48,13 +48,6 @@ M_TOKENS = 256
 TOPK = 100
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16
-# SURVEY.md section 8(d), per ray and query: ray MLP 603 136 + k_proj 294 912 + QK^T 2*384*M + softmax/column-sum 4*M
-def algorithmic_flops_per_ray(m_tokens):
-    return 603136.0 + 294912.0 + 2.0 * 384.0 * m_tokens + 4.0 * m_tokens
-# what the fused kernel ISSUES on the matrix cores per ray: `products` MFMA products per fp32-accurate product x 2 x 256
-# outputs x (144 + 144 + 256 + 256 encoder k + 256 logits k per 256-token block)  (folded heads: DESIGN.md section 3)
-def issued_mfma_flops_per_ray(m_tokens, products):
-    return products * 2.0 * 256.0 * (144 + 144 + 256 + 256 + 256 * ((m_tokens + 255) // 256))
 # march: algorithmic bytes per sample = valid*1184 (8 mask corners x 4 B + density taps) + shaded*3456 (appearance taps)
 B_VALID, B_APP = 32 + 1152, 3456
 
@@ -70,6 +63,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="queries per step and rank (default: the workload's: 16, lego_b64: 64)")
     ap.add_argument("--gemm", default="auto", choices=("auto", "bf16x3", "f16x2"),
                     help="matrix-product arithmetic of the encoder / logits (both fp32-accurate; DESIGN.md section 4)")
+    ap.add_argument("--trunk-variant", type=int, default=0, help="work split of the fused F16X2 launch (0 = default; tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true", help="skip the per-stage / roofline measurements after the timed loop")
     ap.add_argument("--force-sharded", action="store_true",
@@ -179,7 +173,8 @@ def main():
     idw = synthetic.make_id_weights(seed=99)
     from iffnerf_amd import hip_identify as H
     gemm_mode = {"auto": H.GEMM_DEFAULT, "bf16x3": H.GEMM_BF16X3, "f16x2": H.GEMM_F16X2}[args.gemm]
-    pipe = PosePipeline.from_checkpoints(ck, idw, device, model_up=(0.0, 0.0, 1.0), gemm_mode=gemm_mode)
+    pipe = PosePipeline.from_checkpoints(ck, idw, device, model_up=(0.0, 0.0, 1.0), gemm_mode=gemm_mode,
+                                         trunk_variant=args.trunk_variant)
     # cold configs: rank r owns global queries r*B .. r*B+B-1; lego_b64: every rank sees the same B queries (shared rays)
     q0 = 0 if shared else rank * B
     tokens = torch.stack([synthetic.make_tokens(M_TOKENS, 384, seed=7 + q0 + q) for q in range(B)]).to(device)

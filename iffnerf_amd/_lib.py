@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
 _lib = None
-ABI_VERSION = 2          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 3          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -39,7 +39,8 @@ class FieldDesc(C.Structure):
 
 
 class IdNetDesc(C.Structure):
-    _fields_ = [("feature_c", C.c_int32), ("fea", C.c_int32), ("img_fea", C.c_int32), ("gemm_mode", C.c_int32)] + [
+    _fields_ = [("feature_c", C.c_int32), ("fea", C.c_int32), ("img_fea", C.c_int32), ("gemm_mode", C.c_int32),
+                ("trunk_variant", C.c_int32)] + [
         (n, C.c_void_p) for n in ("l1_w", "l1_b", "l2_w", "l2_b", "l3_w", "l3_b", "l4_w", "l4_b", "q_w", "q_b", "k_w", "k_b")]
 
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "iff_surface_sample_batched": (C.c_int, [_VP, _I32, _I64, _I32, _I32, _U64, _VP, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_idnet_create": (C.c_int, [C.POINTER(IdNetDesc), _VP, C.POINTER(_VP)]),
     "iff_idnet_destroy": (None, [_VP]),
+    "iff_idnet_gemm_mode": (_I32, [_VP]),
     "iff_ray_encode_workspace": (_SZ, [_VP, _I64]),
     "iff_ray_encode": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ, _VP]),
     "iff_k_proj": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),

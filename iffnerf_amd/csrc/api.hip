@@ -4,6 +4,7 @@
 #include "iff_device.h"
 #include "iff_launch.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -366,6 +367,61 @@ static void fold_heads(const float* W4, const float* b4, const float* Wk, const 
     for (int c = 0; c < ld; ++c) bqf[c] = (float)hb[c];
 }
 
+// IFF_GEMM_F16X2: powers of two for the fp16 hi/lo planes of the fused encoder kernel (trunk_f16_kernels.hip).  fp16 tops out
+// at 65504, so every operand is scaled such that a worst-case bound of its magnitude stays <= 2^15.  Bounds: the encoder
+// input x has raw ray origins in columns 0..2 (|o| <= F16_ORIGIN_BOUND, scene units), directions / colours (|.| <= 2) and
+// sines / cosines (<= 1) elsewhere; a layer's output is bounded by max_row(sum_j |W[r][j]| bound_j + |b[r]|).  The bounds
+// are loose (L1 norms), typical activations sit a few powers of two below them, which is exactly the headroom the lo term
+// needs to stay a normal fp16.  Returns false (the handle then keeps the 3xBF16 kernel) when a scale would have to drop below
+// 2^-3, i.e. when fp16's range cannot hold the network's worst case with useful precision.
+static const float F16_ORIGIN_BOUND = 64.0f;
+static int exp_below(double bound, double top = 32768.0) {      // largest e with bound * 2^e <= top
+    if (!(bound > 0.0)) return 15;
+    int e = (int)std::floor(std::log2(top / bound));
+    return e > 20 ? 20 : e;
+}
+static bool plan_f16_scales(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, int C,
+                            IdNetDev& v) {
+    const int IN = IFF_RAY_INPUT;
+    std::vector<double> xb(IN, 1.0);
+    for (int j = 0; j < 3; ++j) xb[j] = F16_ORIGIN_BOUND;
+    for (int j = 3; j < 9; ++j) xb[j] = 2.0;
+    auto maxabs = [](const float* w, size_t n) { double m = 0; for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs((double)w[i])); return m; };
+    double H1 = 0, H2 = 0, H3 = 0, w3h_max = 0, w3x_max = 0;
+    for (int r = 0; r < C; ++r) {
+        double s = std::fabs((double)b1[r]);
+        for (int j = 0; j < IN; ++j) s += std::fabs((double)W1[(size_t)r * IN + j]) * xb[j];
+        H1 = std::fmax(H1, s);
+    }
+    for (int r = 0; r < C; ++r) {
+        double s = 0;
+        for (int j = 0; j < C; ++j) s += std::fabs((double)W2[(size_t)r * C + j]);
+        H2 = std::fmax(H2, s * H1 + std::fabs((double)b2[r]));
+    }
+    for (int r = 0; r < C; ++r) {
+        const float* row = W3 + (size_t)r * (C + IN);
+        double sh = 0, sx = 0;
+        for (int j = 0; j < C; ++j) { sh += std::fabs((double)row[j]); w3h_max = std::fmax(w3h_max, std::fabs((double)row[j])); }
+        for (int j = 0; j < IN; ++j) { sx += std::fabs((double)row[C + j]) * xb[j]; w3x_max = std::fmax(w3x_max, std::fabs((double)row[C + j])); }
+        H3 = std::fmax(H3, sh * H2 + sx + std::fabs((double)b3[r]));
+    }
+    v.e_x = exp_below(F16_ORIGIN_BOUND);
+    v.e_h1 = exp_below(H1); v.e_h2 = exp_below(H2); v.e_h3 = exp_below(H3);
+    v.e_w1 = exp_below(maxabs(W1, (size_t)C * IN));
+    v.e_w2 = exp_below(maxabs(W2, (size_t)C * C));
+    // layer 3 accumulates its h-part and its x-part together: e_w3h + e_h2 == e_w3x + e_x
+    int e3h = exp_below(w3h_max), e3x = exp_below(w3x_max);
+    if (e3h + v.e_h2 - v.e_x > e3x) e3h = e3x - v.e_h2 + v.e_x;
+    v.e_w3h = e3h; v.e_w3x = e3h + v.e_h2 - v.e_x;
+    return std::isfinite(H3) && v.e_h1 >= -3 && v.e_h2 >= -3 && v.e_h3 >= -3 && v.e_w3x >= -8 && v.e_w3h >= -8;
+}
+
+extern "C" int32_t iff_idnet_gemm_mode(const iff_idnet* n) {
+    if (!n) return -1;
+    if (n->dev.trunk_f16) return IFF_GEMM_F16X2;
+    return n->dev.gemm_mode == 0 ? IFF_GEMM_F32 : (n->dev.fused_trunk ? IFF_GEMM_BF16X3 : IFF_GEMM_BF16X3_LAYERED);
+}
+
 extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet** out) {
     IFF_REQUIRE(d && out, "iff_idnet_create: null argument");
     *out = nullptr;
@@ -375,7 +431,8 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     const int C = d->feature_c, Fe = d->fea, IF = d->img_fea;
     IFF_REQUIRE(C >= 16 && C % 16 == 0 && Fe >= 16 && Fe % 16 == 0 && IF >= 1, "iff_idnet_create: widths %d/%d/%d unsupported", C, Fe, IF);
     IFF_REQUIRE(C % 32 == 0 && Fe % 32 == 0, "iff_idnet_create: widths must be multiples of 32 (got %d, %d)", C, Fe);
-    IFF_REQUIRE(d->gemm_mode >= 0 && d->gemm_mode <= 2, "iff_idnet_create: gemm_mode must be 0 (fp32 MFMA), 1 (3xBF16) or 2 (3xBF16, one launch per layer)");
+    IFF_REQUIRE(d->gemm_mode >= 0 && d->gemm_mode <= 3, "iff_idnet_create: gemm_mode must be one of IFF_GEMM_* (0..3)");
+    IFF_REQUIRE(d->trunk_variant >= 0 && d->trunk_variant <= 3, "iff_idnet_create: trunk_variant must be 0 (choose) or 1..3");
     const int KQ = (IF + 15) / 16 * 16;
     const int XW = 160;                  // encoder input 141 padded to a multiple of 32 (identify_kernels.hip)
     iff_idnet* n = new iff_idnet();
@@ -392,6 +449,11 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     size_t o_wqf = take((size_t)KQ * QLD), o_bqf = take(QLD);
     const bool fused = (C == 256);
     size_t o_f1 = fused ? take_planes(C, XW) : 0, o_f2 = fused ? take_planes(C, C) : 0, o_f3 = fused ? take_planes(C, C + XW) : 0;
+    // fp16 hi/lo planes in fragment order (IFF_GEMM_F16X2): [k-steps][2][256][16] halves = k-steps * 4096 floats
+    const bool want_f16 = fused && d->gemm_mode == IFF_GEMM_F16X2;
+    const int KXS = (IFF_RAY_INPUT + 15) / 16;
+    size_t o_h1 = want_f16 ? take((size_t)KXS * 4096) : 0, o_h2 = want_f16 ? take((size_t)(C / 16) * 4096) : 0,
+           o_h3h = want_f16 ? take((size_t)(C / 16) * 4096) : 0, o_h3x = want_f16 ? take((size_t)KXS * 4096) : 0;
     n->slab_bytes = off;
     hipError_t e = hipMalloc(&n->slab, off);
     if (e != hipSuccess) { delete n; return hip_fail(e, "hipMalloc(idnet weights)"); }
@@ -423,6 +485,9 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     v.wk = (const float*)(b + o_wk); v.bk = (const float*)(b + o_bk); v.wq = (const float*)(b + o_wq); v.bq = (const float*)(b + o_bq);
     v.p1 = b + o_p1; v.p2 = b + o_p2; v.p3 = b + o_p3; v.p4 = b + o_p4; v.pk = b + o_pk;
     v.gemm_mode = d->gemm_mode == 0 ? 0 : 1;
+    v.h1 = v.h2 = v.h3h = v.h3x = nullptr;
+    v.trunk_f16 = 0; v.trunk_variant = 0;
+    v.e_x = v.e_h1 = v.e_h2 = v.e_h3 = v.e_w1 = v.e_w2 = v.e_w3h = v.e_w3x = 0;
     v.feature_c = C; v.fea = Fe; v.img_fea = IF;
     v.f1 = v.f2 = v.f3 = nullptr;
     v.fused_trunk = 0;
@@ -431,7 +496,23 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
         IFF_NET_HIP(launch_frag_order(b + o_p2, b + o_f2, C, s));
         IFF_NET_HIP(launch_frag_order(b + o_p3, b + o_f3, C + XW, s));
         v.f1 = b + o_f1; v.f2 = b + o_f2; v.f3 = b + o_f3;
-        v.fused_trunk = d->gemm_mode == 1 ? 1 : 0;
+        v.fused_trunk = (d->gemm_mode == IFF_GEMM_BF16X3 || d->gemm_mode == IFF_GEMM_F16X2) ? 1 : 0;
+    }
+    if (want_f16) {
+        std::vector<float> W1((size_t)C * IFF_RAY_INPUT), b1(C), W2((size_t)C * C), b2(C), W3((size_t)C * (C + IFF_RAY_INPUT)), b3(C);
+        struct { std::vector<float>* dst; const float* src; } dl[] = {{&W1, d->l1_w}, {&b1, d->l1_b}, {&W2, d->l2_w},
+                                                                      {&b2, d->l2_b}, {&W3, d->l3_w}, {&b3, d->l3_b}};
+        IFF_NET_HIP(hipStreamSynchronize(s));
+        for (auto& p : dl) IFF_NET_HIP(hipMemcpy(p.dst->data(), p.src, p.dst->size() * 4, hipMemcpyDeviceToHost));
+        if (plan_f16_scales(W1.data(), b1.data(), W2.data(), b2.data(), W3.data(), b3.data(), C, v)) {
+            IFF_NET_HIP(launch_frag_order_h(d->l1_w, IFF_RAY_INPUT, 0, IFF_RAY_INPUT, KXS, ldexpf(1.0f, v.e_w1), b + o_h1, s));
+            IFF_NET_HIP(launch_frag_order_h(d->l2_w, C, 0, C, C / 16, ldexpf(1.0f, v.e_w2), b + o_h2, s));
+            IFF_NET_HIP(launch_frag_order_h(d->l3_w, C + IFF_RAY_INPUT, 0, C, C / 16, ldexpf(1.0f, v.e_w3h), b + o_h3h, s));
+            IFF_NET_HIP(launch_frag_order_h(d->l3_w, C + IFF_RAY_INPUT, C, IFF_RAY_INPUT, KXS, ldexpf(1.0f, v.e_w3x), b + o_h3x, s));
+            v.h1 = b + o_h1; v.h2 = b + o_h2; v.h3h = b + o_h3h; v.h3x = b + o_h3x;
+            v.trunk_f16 = 1;
+            v.trunk_variant = d->trunk_variant > 0 ? d->trunk_variant - 1 : 0;
+        }
     }
     IFF_NET_HIP(hipStreamSynchronize(s));
     {

@@ -824,6 +824,7 @@ static hipError_t trunk(const IdNetDev& n, const float* o, const float* d, const
     const int C = n.feature_c;
     int64_t tot = N * XW;
     int grid = (int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256);
+    if (n.trunk_f16) return launch_trunk_h_features(n, o, d, rgb, N, 1, h3, s);
     if (n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk) {
         hipLaunchKernelGGL((k5_trunk<false, TRUNK_FG>), dim3((unsigned)((N + TR - 1) / TR)), dim3(64 * 8 / TRUNK_FG), 0, s, o, d, rgb, N, (const uint4*)n.f1,
                            (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, h3, (const uint4*)nullptr,
@@ -1024,7 +1025,8 @@ hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, 
 static inline size_t up256z(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t ray_logits_workspace_bytes(const IdNetDev& n, int64_t N, int M, int B) {
     const size_t n_tb = (size_t)(M + 255) / 256, n_blk = (size_t)(N + TR - 1) / TR;
-    size_t fused = up256z((size_t)B * n_tb * (TC / 16) * 3 * 8 * 64 * 16) + up256z((size_t)B * n_blk * n_tb * 256 * 8);
+    size_t fused = up256z((size_t)B * n_tb * (TC / 16) * 3 * 8 * 64 * 16) + up256z((size_t)B * n_blk * n_tb * 256 * 8) +
+                   up256z((size_t)B * n_tb * 256 * 4);          // query planes | softmax partials | per-token scales (F16X2)
     size_t layered = up256z(ray_trunk_workspace_bytes(n, N)) + (size_t)N * n.feature_c * sizeof(float);
     return (fused > layered ? fused : layered) + 256;
 }
@@ -1037,7 +1039,7 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
     if (N == 0 || M == 0 || B == 0) return hipSuccess;
     if (ws_bytes < ray_logits_workspace_bytes(n, N, M, B)) return hipErrorInvalidValue;
     const int C = n.feature_c;
-    if (!(n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk)) {
+    if (!n.trunk_f16 && !(n.gemm_mode == 1 && C == TC && n.f1 && n.fused_trunk)) {
         if (trunk_ms_host) *trunk_ms_host = -1.0f;        // no fused launch to time in this configuration
         float* h3 = (float*)((char*)ws + up256z(ray_trunk_workspace_bytes(n, N)));
         for (int q = 0; q < B; ++q) {
@@ -1051,24 +1053,35 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
         return hipSuccess;
     }
     const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
-    const int64_t n_blk = (N + TR - 1) / TR;
+    const int rays_per_wg = n.trunk_f16 ? trunk_h_rays_per_wg(n.trunk_variant) : TR;
+    const int64_t n_blk = (N + rays_per_wg - 1) / rays_per_wg;
     if (B > 65535) return hipErrorInvalidValue;
     char* base = (char*)ws;
     __bf16* Qf = (__bf16*)base;
     float2* part = (float2*)((char*)Qf + up256z((size_t)B * n_tb * (TC / 16) * 3 * 8 * 64 * 16));
+    float* qscale = (float*)((char*)part + up256z((size_t)B * ((N + TR - 1) / TR) * n_tb * 256 * 8));
     hipError_t e;
-    const int64_t nq = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;
-    hipLaunchKernelGGL(k_qf_frag, dim3((unsigned)((nq + 255) / 256), (unsigned)B), dim3(256), 0, s, qf, n.qf_ld, M, Qf, n_tb);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    if (trunk_ms_host) {
-        for (auto& x : ev) if ((e = hipEventCreate(&x)) != hipSuccess) return e;
-        (void)hipEventRecord(ev[0], s);
+    if (n.trunk_f16) {
+        // the token-side split (k_qf_frag_h) is part of launch_trunk_h_logits: the timed span covers it too (a few us)
+        if (trunk_ms_host) {
+            for (auto& x : ev) if ((e = hipEventCreate(&x)) != hipSuccess) return e;
+            (void)hipEventRecord(ev[0], s);
+        }
+        e = launch_trunk_h_logits(n, o, d, rgb, N, qf, M, B, divisor, logits, (void*)Qf, qscale, part, s);
+    } else {
+        const int64_t nq = (int64_t)n_tb * (TC / 16) * 8 * 64 * 8;
+        hipLaunchKernelGGL(k_qf_frag, dim3((unsigned)((nq + 255) / 256), (unsigned)B), dim3(256), 0, s, qf, n.qf_ld, M, Qf, n_tb);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (trunk_ms_host) {
+            for (auto& x : ev) if ((e = hipEventCreate(&x)) != hipSuccess) return e;
+            (void)hipEventRecord(ev[0], s);
+        }
+        hipLaunchKernelGGL((k5_trunk<true, TRUNK_FG>), dim3((unsigned)n_blk, (unsigned)B), dim3(64 * 8 / TRUNK_FG), 0, s, o, d, rgb, N, (const uint4*)n.f1,
+                           (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M,
+                           divisor, logits, part, Mpad);
+        e = hipGetLastError();
     }
-    hipLaunchKernelGGL((k5_trunk<true, TRUNK_FG>), dim3((unsigned)n_blk, (unsigned)B), dim3(64 * 8 / TRUNK_FG), 0, s, o, d, rgb, N, (const uint4*)n.f1,
-                       (const uint4*)n.f2, (const uint4*)n.f3, n.b1, n.b2, n.b3, (float*)nullptr, (const uint4*)Qf, qf + C, n.qf_ld, M,
-                       divisor, logits, part, Mpad);
-    e = hipGetLastError();
     if (trunk_ms_host) {
         (void)hipEventRecord(ev[1], s);
         hipError_t es = hipEventSynchronize(ev[1]);

@@ -53,6 +53,13 @@ struct IdNetDev {
     // layers 1-3 in the fragment order of the fused trunk kernel (k5_trunk; only when feature_c == 256), else null
     const void* f1; const void* f2; const void* f3;
     int fused_trunk;                    // 1: one launch for the three ReLU layers; 0: one 3xBF16 GEMM launch per layer
+    // IFF_GEMM_F16X2 (trunk_f16_kernels.hip): layers 1-3 as fp16 hi/lo planes in fragment order, each times a power of
+    // two (exponents below, planned at create time: api.hip plan_f16_scales); null / 0 when that mode is not in use
+    const void* h1; const void* h2; const void* h3h; const void* h3x;
+    int trunk_f16;                      // 1: the fused launch is k5_trunk_h
+    int trunk_variant;                  // k5_trunk_h work split: 0 = 8 waves x 64 rays, 1 = 4 waves x 64 rays, 2 = 8 waves x 128 rays
+    int e_x, e_h1, e_h2, e_h3;          // activations are stored times 2^e
+    int e_w1, e_w2, e_w3h, e_w3x;       // weights are stored times 2^e  (e_w3h + e_h2 == e_w3x + e_x)
     int gemm_mode;                      // 0: fp32-input MFMA (k-ordered fmaf chain), 1: 3xBF16 split on the bf16 MFMA
     int feature_c, fea, img_fea;
 };
@@ -76,6 +83,13 @@ hipError_t launch_transpose_pad(const float* w_out_in, float* dst_in_out, int ou
 hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, int D, float divisor, float* logits,
                               float* row_max, float* row_sumexp, int gemm_mode, hipStream_t s);
 hipError_t launch_frag_order(const void* Wp, void* Wf, int Kp, hipStream_t s);
+// trunk_f16_kernels.hip
+hipError_t launch_frag_order_h(const float* W, int ld, int col0, int ncols, int nks, float scale, void* Wf, hipStream_t s);
+int trunk_h_rays_per_wg(int variant);
+hipError_t launch_trunk_h_features(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, int B, float* h3,
+                                   hipStream_t s);
+hipError_t launch_trunk_h_logits(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf, int M,
+                                 int B, float divisor, float* logits, void* Qf, float* qscale, float2* part, hipStream_t s);
 hipError_t launch_split_rows(const float* w, void* planes, int out_f, int in_f, int in_pad, hipStream_t s);
 hipError_t launch_attn_colsum(float* logits, int Q, int M, int64_t N, const float* row_max, const float* row_sumexp,
                               int write_attention, float* score, hipStream_t s);

@@ -1,0 +1,476 @@
+// trunk_f16_kernels.hip -- the fused ray encoder + attention logits (k5_trunk_h) on the fp16 matrix cores with a TWO-term
+// split of every fp32 operand: IFF_GEMM_F16X2.
+//
+// Reference: pose_estimation/ray_preprocessor.py:29-39 (three ReLU layers), multihead_attention.py:4-12,60-61 (folded
+// into one token-side Linear, api.hip fold_heads).  Same work split as k5_trunk (identify_kernels.hip): a workgroup owns
+// TR = 32 RG rays, a wave 32 FG output features of every layer; activations stay in LDS between the layers and are the
+// MFMA's B operand, weights stream from L2 in fragment order as the A operand; the logits are "layer 4" with swapped
+// operands so that the softmax statistics run down a lane's registers.
+//
+// Arithmetic.  fp16 carries 11 significant bits, so a = hi + lo with hi = fp16(a), lo = fp16(a - hi) represents a to
+// 2^-22 relative (as long as lo stays a normal or subnormal fp16: the MFMA keeps fp16 subnormals in the default float mode),
+// and a*b ~= hi_a hi_b + hi_a lo_b + lo_a hi_b drops only lo_a lo_b <= 2^-22 |a b|: three v_mfma_f32_32x32x16_f16 per
+// product block where the bf16 split needs six for the same fp32-class accuracy (measured against an fp64 evaluation of the
+// chain: rms logit error 4.0e-6 vs 4.0e-6 for a plain fp32 matmul chain, max 3.9e-5 vs 5.1e-5 for the reference's own fp32
+// CPU run -- tests/test_hip_identify.py).  fp16 has a 5-bit exponent, so every operand is first multiplied by a power of
+// two chosen at iff_idnet_create (api.hip plan_f16_scales) from worst-case bounds on the activations (row L1 norms of the
+// weights x the previous layer's bound), so that nothing can overflow 65504 and the lo terms of typical values stay normal;
+// the fp32 accumulator is multiplied back by the exact inverse power of two.  The token side (folded queries) is scaled
+// per token row at run time (k_qf_frag_h).  If the bounds leave fewer than ~3 bits of headroom the handle falls back to
+// the 3xBF16 kernel (iff_idnet_gemm_mode reports what runs).
+#include "iff_device.h"
+#include "iff_launch.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HSLD = 264;          // halves per LDS row: 256 + 8 -> 528 B, an odd multiple of 16 B (conflict-free 16-B reads)
+constexpr int HC = 256;            // feature_c this kernel is built for
+constexpr float H_MAX = 65504.0f;
+
+__device__ inline void split_h(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// ------------------------------------------------------------------------------------------------ weight prep
+// nn.Linear weight W [256][ld] (columns col0 .. col0+ncols-1), times `scale` (a power of two) -> fragment order
+// Wf[ks][plane][nb][lane][8] halves, plane 0 = hi, 1 = lo: lane l of the (nb, ks) fragment holds
+// W[32 nb + (l & 31)][col0 + 16 ks + 8 (l >> 5) + 0..7], the 32x32x16 A-operand map; columns beyond ncols are zero
+__global__ void k_frag_order_h(const float* __restrict__ W, int ld, int col0, int ncols, int nks, float scale,
+                               _Float16* __restrict__ Wf) {
+    const int64_t n = (int64_t)nks * 8 * 64 * 8;            // elements per plane... per (ks): 2 planes x 8 nb x 64 lanes x 8
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t & 7), lane = (int)((t >> 3) & 63), nb = (int)((t >> 9) & 7), ks = (int)(t >> 12);
+        const int row = nb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + i;
+        const float v = (k < ncols) ? W[(size_t)row * ld + col0 + k] * scale : 0.0f;
+        _Float16 hi, lo;
+        split_h(v, hi, lo);
+        const size_t base = (((size_t)ks * 2) * 8 + nb) * 512 + lane * 8 + i;
+        Wf[base] = hi;
+        Wf[base + 8 * 512] = lo;
+    }
+}
+hipError_t launch_frag_order_h(const float* W, int ld, int col0, int ncols, int nks, float scale, void* Wf, hipStream_t s) {
+    const int64_t n = (int64_t)nks * 8 * 64 * 8;
+    hipLaunchKernelGGL(k_frag_order_h, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ld, col0, ncols, nks, scale, (_Float16*)Wf);
+    return hipGetLastError();
+}
+
+// folded query rows qf [M][ld] (iff_q_fold; columns 0..255) -> per-token power-of-two scale, hi/lo planes in fragment
+// order, one 256-token block after the other: Qf[tb][ks][plane][nb][lane][8], token = 256 tb + 32 nb + (lane & 31),
+// feature = 16 ks + 8 (lane >> 5) + i; tokens beyond M are zero.  qscale[token] = 2^-(e + e3): what the logits epilogue
+// multiplies the accumulator with (e: this token's exponent, e3: the exponent the h3 planes were scaled by).
+// One workgroup per 32 tokens: thread = (token, 8-feature chunk group), 8 threads per token.
+__global__ void __launch_bounds__(256) k_qf_frag_h(const float* __restrict__ qf, int ld, int M, int n_tb, int e3,
+                                                   _Float16* __restrict__ Qf, float* __restrict__ qscale) {
+    const int tid = threadIdx.x, tl = tid >> 3, sub = tid & 7;
+    const int tok = blockIdx.x * 32 + tl;                      // token of this query
+    const int tb = tok >> 8, nb = (tok >> 5) & 7;
+    const size_t plane_elems = (size_t)n_tb * (HC / 16) * 2 * 8 * 64 * 8;   // elements of one query's Qf (both planes)
+    qf += (size_t)blockIdx.y * M * ld;
+    Qf += (size_t)blockIdx.y * plane_elems;
+    qscale += (size_t)blockIdx.y * n_tb * 256;
+    const bool ok = tok < M;
+    float v[4][8];
+    float amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = sub + 8 * j;                              // 8-feature chunk: features 8c .. 8c+7
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[j][i] = ok ? qf[(size_t)tok * ld + 8 * c + i] : 0.0f;
+            amax = fmaxf(amax, fabsf(v[j][i]));
+        }
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    // amax = m 2^ex with m in [0.5, 1): scaling by 2^(15 - ex) puts the row's largest magnitude in [16384, 32768)
+    int ex = 0;
+    if (amax > 0.0f && amax < INFINITY) (void)frexpf(amax, &ex);
+    int e = 15 - ex;
+    e = e > 40 ? 40 : (e < -40 ? -40 : e);
+    const float sc = ldexpf(1.0f, e);
+    if (sub == 0) qscale[tok] = ldexpf(1.0f, -(e + e3));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = sub + 8 * j, ks = c >> 1, h = c & 1;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            _Float16 a, b;
+            split_h(fminf(fmaxf(v[j][i] * sc, -H_MAX), H_MAX), a, b);
+            hi[i] = a; lo[i] = b;
+        }
+        const size_t base = ((((size_t)tb * (HC / 16) + ks) * 2) * 8 + nb) * 512 + ((tok & 31) + 32 * h) * 8;
+        *reinterpret_cast<f16x8*>(Qf + base) = hi;
+        *reinterpret_cast<f16x8*>(Qf + base + 8 * 512) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the fused kernel
+struct TrunkHArgs {
+    const float* ray_o; const float* ray_d; const float* ray_c; int64_t N;
+    const uint4* W1; const uint4* W2; const uint4* W3h; const uint4* W3x;      // fragment-ordered fp16 hi/lo planes
+    const float* b1; const float* b2; const float* b3;
+    float sx;                 // x is multiplied by sx before the split
+    float inv1, s1;           // h1 = relu(acc inv1 + b1); its planes hold h1 s1
+    float inv2, s2;
+    float inv3, s3;           // layer 3: the h-part and the x-part accumulate at one common scale
+    float* h3;                // LOGITS = false: [N][256] fp32 out
+    const uint4* Qf; const float* qscale; const float* rowc; int rowc_ld; int M; float divisor;
+    float* logits; float2* part; int Mpad;
+};
+
+template <int FG> struct WFragH { f16x8 p[FG][2]; };      // [feature group][hi, lo]
+
+template <int FG>
+__device__ inline void trunk_load_w_h(WFragH<FG>& w, const uint4* __restrict__ Wf, int ks, int wave, int lane) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int fg = 0; fg < FG; ++fg) {
+            uint4 v = Wf[(((size_t)ks * 2 + pl) * 8 + FG * wave + fg) * 64 + lane];
+            w.p[fg][pl] = *reinterpret_cast<f16x8*>(&v);
+        }
+}
+
+// acc[fg][rg] += W(fg) * act(rg) over one 16-wide k-step: lo*hi, hi*lo, hi*hi (smallest contributions first)
+template <int FG, int RG>
+__device__ inline void trunk_mfma_h(f32x16 (&acc)[FG][RG], const WFragH<FG>& w, const f16x8 (&a)[RG][2]) {
+#pragma unroll
+    for (int fg = 0; fg < FG; ++fg)
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][1], a[rg][0], acc[fg][rg], 0, 0, 0);
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][0], a[rg][1], acc[fg][rg], 0, 0, 0);
+            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][0], a[rg][0], acc[fg][rg], 0, 0, 0);
+        }
+}
+// the logits tile: rows = rays, columns = tokens (operands swapped)
+template <int FG, int RG>
+__device__ inline void trunk_mfma_ht(f32x16 (&acc)[FG][RG], const WFragH<FG>& w, const f16x8 (&a)[RG][2]) {
+#pragma unroll
+    for (int tg = 0; tg < FG; ++tg)
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][0], w.p[tg][1], acc[tg][rg], 0, 0, 0);
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][1], w.p[tg][0], acc[tg][rg], 0, 0, 0);
+            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][0], w.p[tg][0], acc[tg][rg], 0, 0, 0);
+        }
+}
+
+struct __attribute__((packed, aligned(4))) f4uh { float x, y, z, w; };     // 16-byte store at 4-byte alignment
+
+// FG = 32-feature groups per wave (8 / FG waves per workgroup), RG = 32-ray groups per workgroup (TR = 32 RG rays).
+template <bool LOGITS, int FG, int RG>
+__global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_trunk_h(TrunkHArgs a) {
+    constexpr int TR = 32 * RG, NT = 64 * 8 / FG, NWAVE = 8 / FG;
+    __shared__ __attribute__((aligned(16))) _Float16 S[2][TR][HSLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * TR;
+    const int64_t N = a.N;
+    {   // blockIdx.y = query of a batch: its own rays [N,3], folded query planes, logits [M,N] and partials
+        const size_t qb = blockIdx.y;
+        a.ray_o += qb * N * 3; a.ray_d += qb * N * 3; a.ray_c += qb * N * 3;
+        if (LOGITS) {
+            a.Qf += qb * (size_t)(a.Mpad / 256) * (HC / 16) * 2 * 8 * 64;
+            a.qscale += qb * (size_t)a.Mpad;
+            a.rowc += qb * (size_t)a.M * a.rowc_ld;
+            a.logits += qb * (size_t)a.M * N;
+            a.part += qb * (size_t)gridDim.x * a.Mpad;
+        } else {
+            a.h3 += qb * N * HC;
+        }
+    }
+
+    // encoder input x (ray_preprocessor.py:30-37, tensorBase.py:14-20) straight into LDS as hi/lo planes:
+    // x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141 columns, zero-padded to 160; rows beyond N are zero).
+    // Work items per ray: 66 (source component, frequency) pairs -- one sincosf serves the sin and the cos column --
+    // plus the 9 raw values and the 19 pad columns: 94 items x TR rays over NT threads.
+    {
+        const float sx = a.sx;
+        auto put = [&](int ray, int col, float v) {
+            _Float16 hi, lo;
+            split_h(fminf(fmaxf(v * sx, -H_MAX), H_MAX), hi, lo);
+            S[0][ray][col] = hi; S[1][ray][col] = lo;
+        };
+        const int ray = tid % TR;
+        const int64_t gr = row0 + ray;
+        const bool ok = gr < N;
+        float src[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            src[c] = ok ? a.ray_o[3 * gr + c] : 0.0f;
+            src[3 + c] = ok ? a.ray_d[3 * gr + c] : 0.0f;
+            src[6 + c] = ok ? a.ray_c[3 * gr + c] : 0.0f;
+        }
+        for (int item = tid / TR; item < 94; item += NT / TR) {       // wave-uniform item -> no divergence
+            if (item < 66) {
+                // blocks: PE(o) at column 9, PE(d) at 57, PE(rgb) at 105; each [sin (F*3) | cos (F*3)], component-major
+                int blk = item < 24 ? 0 : (item < 48 ? 1 : 2);
+                int b = item - 24 * blk;
+                int F = blk == 2 ? 6 : 8;
+                int j = b / F, k = b - j * F;
+                // select instead of src[3 * blk + j]: a dynamically indexed local array would live in scratch memory
+                const float c0 = blk == 0 ? src[0] : (blk == 1 ? src[3] : src[6]);
+                const float c1 = blk == 0 ? src[1] : (blk == 1 ? src[4] : src[7]);
+                const float c2 = blk == 0 ? src[2] : (blk == 1 ? src[5] : src[8]);
+                float arg = (j == 0 ? c0 : (j == 1 ? c1 : c2)) * (float)(1 << k);
+                float sv, cv;
+                sincosf(arg, &sv, &cv);               // one argument reduction for both columns
+                int col = 9 + 48 * blk + b;
+                put(ray, col, sv);
+                put(ray, col + 3 * F, cv);
+            } else if (item < 75) {
+                const int ci = item - 66;
+                float rv = src[0];
+#pragma unroll
+                for (int u = 1; u < 9; ++u) rv = (ci == u) ? src[u] : rv;
+                put(ray, ci, rv);
+            } else {
+                put(ray, 141 + (item - 75), 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+
+    auto load_act = [&](f16x8 (&v)[RG][2], int ks) {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) v[rg][pl] = *reinterpret_cast<const f16x8*>(&S[pl][32 * rg + lr][16 * ks + 8 * lh]);
+    };
+    // relu(acc inv + bias) s -> hi/lo planes of this wave's 32 FG features for all TR rays
+    auto write_planes = [&](const f32x16 (&acc)[FG][RG], const float* __restrict__ bias, float inv, float s) {
+#pragma unroll
+        for (int fg = 0; fg < FG; ++fg)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 32 * FG * wave + 32 * fg + 8 * q + 4 * lh;     // features f0..f0+3 <- registers 4q..4q+3
+                const float4 bv = *reinterpret_cast<const float4*>(bias + f0);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    f16x4 p0, p1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = fmaxf(fmaf(acc[fg][rg][4 * q + i], inv, bb[i]), 0.0f);
+                        _Float16 hi, lo;
+                        split_h(fminf(v * s, H_MAX), hi, lo);
+                        p0[i] = hi; p1[i] = lo;
+                    }
+                    *reinterpret_cast<f16x4*>(&S[0][32 * rg + lr][f0]) = p0;
+                    *reinterpret_cast<f16x4*>(&S[1][32 * rg + lr][f0]) = p1;
+                }
+            }
+    };
+    auto zero = [](f32x16 (&acc)[FG][RG]) {
+#pragma unroll
+        for (int x = 0; x < FG; ++x)
+#pragma unroll
+            for (int y = 0; y < RG; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+    };
+
+    f32x16 acc[FG][RG], acc3[FG][RG];
+    zero(acc); zero(acc3);
+    constexpr int KX = (141 + 15) / 16, KH = HC / 16;
+
+    // One k loop, software-pipelined in registers: the weight fragments of k-step ks + DEPTH - 1 are requested before
+    // k-step ks is multiplied.  DUAL: two weight streams over the same activations (layer 1 and the x-part of layer 3).
+    constexpr int AB = (FG == 1 && RG == 2) ? 1 : 2;
+    auto phase = [&](auto nk_c, auto depth_c, auto dual_c, auto swap_c, f32x16 (&accA)[FG][RG], const uint4* __restrict__ WA,
+                     f32x16 (&accB)[FG][RG], const uint4* __restrict__ WB) {
+        constexpr int NK = decltype(nk_c)::value, DEPTH = decltype(depth_c)::value;
+        constexpr bool DUAL = decltype(dual_c)::value, SWAP = decltype(swap_c)::value;
+        WFragH<FG> wa[DEPTH], wb[DUAL ? DEPTH : 1];
+        f16x8 act[AB][RG][2];                  // AB = 2: activations one k-step ahead as well (LDS latency)
+        load_act(act[0], 0);
+#pragma unroll
+        for (int i = 0; i < DEPTH - 1; ++i) {
+            if (i < NK) {
+                trunk_load_w_h(wa[i], WA, i, wave, lane);
+                if (DUAL) trunk_load_w_h(wb[i], WB, i, wave, lane);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            if (ks + DEPTH - 1 < NK) {
+                trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wave, lane);
+                if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wave, lane);
+            }
+            if (AB == 2 && ks + 1 < NK) load_act(act[(ks + 1) & 1], ks + 1);
+            __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them)
+            if (SWAP) trunk_mfma_ht<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
+            else trunk_mfma_h<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
+            if (DUAL) trunk_mfma_h<FG, RG>(accB, wb[ks % DEPTH], act[ks & (AB - 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (AB == 1 && ks + 1 < NK) load_act(act[0], ks + 1);
+        }
+    };
+    using std::integral_constant;
+    using no_t = integral_constant<bool, false>;
+    using yes_t = integral_constant<bool, true>;
+    // the 8-wave x 64-ray form is built for two workgroups per CU (4 waves per SIMD, 128 registers): shallower register
+    // prefetch, the other waves of the SIMD cover the latency instead
+    constexpr bool LEAN = (FG == 1 && RG == 2);
+    constexpr int DEPTH_DUAL = LEAN ? 2 : 3, DEPTH_ONE = LEAN ? 3 : 4;
+
+    // layer 1 and the x-part of layer 3, one pass over x
+    phase(integral_constant<int, KX>{}, integral_constant<int, DEPTH_DUAL>{}, yes_t{}, no_t{}, acc, a.W1, acc3, a.W3x);
+    __syncthreads();                      // every wave has finished reading x
+    write_planes(acc, a.b1, a.inv1, a.s1);
+    __syncthreads();
+
+    // layer 2
+    zero(acc);
+    phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc, a.W2, acc, a.W2);
+    __syncthreads();
+    write_planes(acc, a.b2, a.inv2, a.s2);
+    __syncthreads();
+
+    // layer 3, h-part, on top of the x-part
+    phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc3, a.W3h, acc3, a.W3h);
+    __syncthreads();                      // every wave has finished reading h2
+    if (LOGITS) {
+        write_planes(acc3, a.b3, a.inv3, a.s3);           // h3 planes
+        __syncthreads();
+        const int n_tb = a.Mpad / 256;
+        const float divisor = a.divisor, inv_div = 1.0f / divisor;
+        for (int tb = 0; tb < n_tb; ++tb) {
+            zero(acc);
+            phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, yes_t{}, acc,
+                  a.Qf + (size_t)tb * (KH * 2 * 8 * 64), acc, a.Qf);
+            // tile: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 32 FG wave + 32 tg + lr
+#pragma unroll
+            for (int tg = 0; tg < FG; ++tg) {
+                const int tok = tb * 256 + 32 * FG * wave + 32 * tg + lr;
+                const bool tok_ok = tok < a.M;
+                const float rc = tok_ok ? a.rowc[(size_t)tok * a.rowc_ld] : 0.0f;
+                const float qs = a.qscale[tok];
+                float vmax = -INFINITY;
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t ray = row0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        // (acc qs + rc) / divisor, correctly rounded (qs is a power of two: acc qs is exact): quotient
+                        // estimate by the reciprocal, exact remainder, one correction
+                        const float num = fmaf(acc[tg][rg][r], qs, rc);
+                        const float q1 = num * inv_div;
+                        const float v = fmaf(fmaf(-q1, divisor, num), inv_div, q1);
+                        acc[tg][rg][r] = v;
+                        vmax = fmaxf(vmax, ray < N ? v : -INFINITY);
+                    }
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+                float ssum = 0.0f;
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t ray0 = row0 + 32 * rg + 8 * q + 4 * lh;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ray0 + i < N) ssum += __expf(acc[tg][rg][4 * q + i] - vmax);   // denominator only: <= 4e-6 relative, common to the whole token row
+                        if (tok_ok) {
+                            float* dst = a.logits + (size_t)tok * N + ray0;
+                            if (ray0 + 3 < N) {
+                                f4uh o4 = {acc[tg][rg][4 * q], acc[tg][rg][4 * q + 1], acc[tg][rg][4 * q + 2], acc[tg][rg][4 * q + 3]};
+                                *reinterpret_cast<f4uh*>(dst) = o4;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (ray0 + i < N) dst[i] = acc[tg][rg][4 * q + i];
+                            }
+                        }
+                    }
+                ssum += __shfl_xor(ssum, 32, 64);
+                if (lh == 0) a.part[(size_t)blockIdx.x * a.Mpad + tok] = make_float2(vmax, ssum);
+            }
+        }
+        return;
+    }
+    // h3 = relu(acc3 inv3 + b3).  A lane holds 4 consecutive features of one ray per register quad; the tile is transposed
+    // through LDS (fp32 [ray][260]) so that every global store instruction writes one whole 1-KiB row of h3.
+    constexpr int OLD = HC + 4;           // 1040-B rows: an odd multiple of 16 B
+    float* O = reinterpret_cast<float*>(&S[0][0][0]);
+    static_assert(TR * OLD * 4 <= 2 * TR * HSLD * 2, "output tile must fit in the activation planes");
+#pragma unroll
+    for (int fg = 0; fg < FG; ++fg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * FG * wave + 32 * fg + 8 * q + 4 * lh;
+            const float4 bv = *reinterpret_cast<const float4*>(a.b3 + f0);
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                float4 o4;
+                o4.x = fmaxf(fmaf(acc3[fg][rg][4 * q + 0], a.inv3, bv.x), 0.0f);
+                o4.y = fmaxf(fmaf(acc3[fg][rg][4 * q + 1], a.inv3, bv.y), 0.0f);
+                o4.z = fmaxf(fmaf(acc3[fg][rg][4 * q + 2], a.inv3, bv.z), 0.0f);
+                o4.w = fmaxf(fmaf(acc3[fg][rg][4 * q + 3], a.inv3, bv.w), 0.0f);
+                *reinterpret_cast<float4*>(&O[(32 * rg + lr) * OLD + f0]) = o4;
+            }
+        }
+    __syncthreads();
+    for (int ray = wave; ray < TR; ray += NWAVE) {
+        const int64_t gr = row0 + ray;
+        if (gr < N) *reinterpret_cast<float4*>(a.h3 + gr * HC + 4 * lane) = *reinterpret_cast<const float4*>(&O[ray * OLD + 4 * lane]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+// variant: 0 -> 8 waves x 32 features, 64 rays;  1 -> 4 waves x 64 features, 64 rays (two workgroups per CU);
+//          2 -> 8 waves x 32 features, 128 rays (half the weight stream per ray)
+int trunk_h_rays_per_wg(int variant) { return variant == 2 ? 128 : 64; }
+
+static TrunkHArgs base_args(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N) {
+    TrunkHArgs a;
+    a.ray_o = o; a.ray_d = d; a.ray_c = rgb; a.N = N;
+    a.W1 = (const uint4*)n.h1; a.W2 = (const uint4*)n.h2; a.W3h = (const uint4*)n.h3h; a.W3x = (const uint4*)n.h3x;
+    a.b1 = n.b1; a.b2 = n.b2; a.b3 = n.b3;
+    a.sx = ldexpf(1.0f, n.e_x);
+    a.inv1 = ldexpf(1.0f, -(n.e_w1 + n.e_x)); a.s1 = ldexpf(1.0f, n.e_h1);
+    a.inv2 = ldexpf(1.0f, -(n.e_w2 + n.e_h1)); a.s2 = ldexpf(1.0f, n.e_h2);
+    a.inv3 = ldexpf(1.0f, -(n.e_w3h + n.e_h2)); a.s3 = ldexpf(1.0f, n.e_h3);
+    a.h3 = nullptr; a.Qf = nullptr; a.qscale = nullptr; a.rowc = nullptr; a.rowc_ld = 0; a.M = 0; a.divisor = 1.0f;
+    a.logits = nullptr; a.part = nullptr; a.Mpad = 0;
+    return a;
+}
+
+template <bool LOGITS>
+static hipError_t launch_variant(int variant, dim3 grid, const TrunkHArgs& a, hipStream_t s) {
+    if (variant == 1) hipLaunchKernelGGL((k5_trunk_h<LOGITS, 2, 2>), grid, dim3(256), 0, s, a);
+    else if (variant == 2) hipLaunchKernelGGL((k5_trunk_h<LOGITS, 1, 4>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k5_trunk_h<LOGITS, 1, 2>), grid, dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_trunk_h_features(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, int B, float* h3,
+                                   hipStream_t s) {
+    TrunkHArgs a = base_args(n, o, d, rgb, N);
+    a.h3 = h3;
+    const int TR = trunk_h_rays_per_wg(n.trunk_variant);
+    return launch_variant<false>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
+}
+
+// qf [B*M][qf_ld] -> Qf planes + qscale in `ws` (layout: Qf | qscale | part), then the fused launch; `part_out` / `n_blk_out`
+// tell the caller where the per-workgroup softmax partials are for k6_merge_stats
+hipError_t launch_trunk_h_logits(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf, int M,
+                                 int B, float divisor, float* logits, void* Qf, float* qscale, float2* part, hipStream_t s) {
+    const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
+    hipLaunchKernelGGL(k_qf_frag_h, dim3((unsigned)(Mpad / 32), (unsigned)B), dim3(256), 0, s, qf, n.qf_ld, M, n_tb, n.e_h3,
+                       (_Float16*)Qf, qscale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    TrunkHArgs a = base_args(n, o, d, rgb, N);
+    a.Qf = (const uint4*)Qf; a.qscale = qscale; a.rowc = qf + HC; a.rowc_ld = n.qf_ld; a.M = M; a.divisor = divisor;
+    a.logits = logits; a.part = part; a.Mpad = Mpad;
+    const int TR = trunk_h_rays_per_wg(n.trunk_variant);
+    return launch_variant<true>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
+}

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import check, dptr, fvec, stream_ptr
 
 GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_LAYERED, GEMM_F16X2 = 0, 1, 2, 3        # include/iffnerf_hip.h IFF_GEMM_*
-GEMM_DEFAULT = GEMM_BF16X3
+GEMM_DEFAULT = GEMM_F16X2        # falls back to BF16X3 by itself when a network does not fit fp16's range
 
 _KEYS = (("l1", "ray_preprocessor.mlp.0"), ("l2", "ray_preprocessor.mlp.2"), ("l3", "ray_preprocessor.mlp2.0"),
          ("l4", "ray_preprocessor.mlp2.2"), ("q", "attention.q_proj"), ("k", "attention.k_proj"))
@@ -33,7 +33,7 @@ def _gpu(t: torch.Tensor, name: str, cols: Optional[int] = None) -> torch.Tensor
 class IdNetHandle:
     """Weights of RayPreprocessor + MultiHeadAttention, transposed/padded once for the MFMA GEMMs."""
 
-    def __init__(self, weights: Dict[str, torch.Tensor], device, gemm_mode: Optional[int] = None):
+    def __init__(self, weights: Dict[str, torch.Tensor], device, gemm_mode: Optional[int] = None, trunk_variant: int = 0):
         self._h = None
         self.gemm_mode = int(GEMM_DEFAULT if gemm_mode is None else gemm_mode)
         device = torch.device(device)
@@ -54,10 +54,13 @@ class IdNetHandle:
             raise RuntimeError("ray encoder input width must be 141 (pospe=8, viewpe=8, rgbpe=6)")
         d.feature_c, d.fea, d.img_fea = self.feature_c, self.fea, self.img_fea
         d.gemm_mode = self.gemm_mode
+        d.trunk_variant = int(trunk_variant)
         out = C.c_void_p()
         with torch.cuda.device(device):
             check(_lib.lib().iff_idnet_create(C.byref(d), stream_ptr(device), C.byref(out)), "iff_idnet_create")
         self._h = out
+        self.requested_gemm_mode = self.gemm_mode
+        self.gemm_mode = int(_lib.lib().iff_idnet_gemm_mode(out))       # F16X2 falls back to BF16X3 when fp16's range is too small
 
     def close(self):
         if getattr(self, "_h", None):

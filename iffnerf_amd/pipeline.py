@@ -47,8 +47,8 @@ class PosePipeline:
 
     @classmethod
     def from_checkpoints(cls, field_ckpt: dict, id_weights: Dict[str, torch.Tensor], device, model_up=(0.0, 0.0, 1.0),
-                         fold_heads: bool = True, gemm_mode: Optional[int] = None):
-        return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device, gemm_mode),
+                         fold_heads: bool = True, gemm_mode: Optional[int] = None, trunk_variant: int = 0):
+        return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device, gemm_mode, trunk_variant),
                    jitter_scale_from_kwargs(field_ckpt["kwargs"], "alphaMask.aabb" in field_ckpt), model_up, fold_heads)
 
     def logits(self, tokens, ori, dirs, rgb):
@@ -56,7 +56,7 @@ class PosePipeline:
         if self.fold_heads:
             return self.idnet.ray_logits_folded(self.idnet.q_fold(tokens), ori, dirs, rgb)
         _, k = self.idnet.ray_encode(ori, dirs, rgb, want_features=False, want_k=True)
-        return H.attn_logits(self.idnet.q_proj(tokens), k, gemm_mode=self.idnet.gemm_mode)
+        return H.attn_logits(self.idnet.q_proj(tokens), k, gemm_mode=min(self.idnet.gemm_mode, 1))
 
     # ------------------------------------------------------------------ stage A + B  (explore_model)
     def emit(self, gen_points: int, seed: int, point_range: Optional[Tuple[int, int]] = None, seed_offset=None):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 2
+#define IFF_ABI_VERSION 3
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -42,10 +42,17 @@ extern "C" {
  *   BF16X3  every fp32 operand split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product block, fp32 accumulation;
  *           dropped terms < 2^-25 relative -- the error class of an fp32 re-association, at ~2.7x the throughput
  *   BF16X3_LAYERED  the same arithmetic with one launch per encoder layer (BF16X3 runs the three ReLU layers of a
- *           256-wide encoder as one launch with the activations kept in LDS; other widths always run layered) */
+ *           256-wide encoder as one launch with the activations kept in LDS; other widths always run layered)
+ *   F16X2   every fp32 operand scaled by a power of two and split into two fp16 pieces (22 significant bits), 3 fp16 MFMAs
+ *           per product block: the fused encoder + logits launch of a 256-wide encoder at half the matrix-core work of
+ *           BF16X3 and the same accuracy class; power-of-two scales are planned at iff_idnet_create from worst-case
+ *           activation bounds (ray origins must satisfy |o| <= 64 scene units), and a network whose bounds do not fit
+ *           fp16's range keeps BF16X3 -- iff_idnet_gemm_mode() reports which arithmetic the handle runs.  Every other
+ *           entry point (per-layer calls, unfolded projections) runs BF16X3 in this mode. */
 #define IFF_GEMM_F32    0
 #define IFF_GEMM_BF16X3 1
 #define IFF_GEMM_BF16X3_LAYERED 2
+#define IFF_GEMM_F16X2  3
 
 #define IFF_ISOCELL_DIRS 27         /* pose_estimation/sampling.py:229-234, isocell.py:6-68 (27 targets, N0=3) */
 #define IFF_RAY_FEATURES 384        /* DINOv2 ViT-S/14 width: pose_estimation/backbone.py:12-14 */
@@ -187,6 +194,8 @@ typedef struct iff_idnet_desc {
     int32_t fea;                    /* 384 */
     int32_t img_fea;                /* 398 = 384 + 14 */
     int32_t gemm_mode;              /* IFF_GEMM_* */
+    int32_t trunk_variant;          /* work split of the fused F16X2 launch: 0 = choose; 1 = 8 waves x 64 rays per workgroup,
+                                       2 = 4 waves x 64 rays (two workgroups per CU), 3 = 8 waves x 128 rays.  Same bits. */
     const float* l1_w; const float* l1_b;   /* ray_preprocessor.mlp.0   [feature_c,141] */
     const float* l2_w; const float* l2_b;   /* ray_preprocessor.mlp.2   [feature_c,feature_c] */
     const float* l3_w; const float* l3_b;   /* ray_preprocessor.mlp2.0  [feature_c,feature_c+141] */
@@ -197,6 +206,9 @@ typedef struct iff_idnet_desc {
 
 int  iff_idnet_create(const iff_idnet_desc* desc, void* stream, iff_idnet** out);
 void iff_idnet_destroy(iff_idnet* net);
+/* the IFF_GEMM_* arithmetic the handle's fused encoder / logits launch actually runs (F16X2 may have fallen back to
+ * BF16X3 at create time; ray_preprocessor.py:29-39 is computed to fp32 accuracy either way) */
+int32_t iff_idnet_gemm_mode(const iff_idnet* net);
 
 /* RayPreprocessor.forward (ray_preprocessor.py:29-39) and, when k_out != NULL, k_proj
  * (multihead_attention.py:61).  o,d,rgb [N,3] -> feat_opt [N,fea] (nullable), k_out [N,fea] (nullable). */
