@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
 _lib = None
-ABI_VERSION = 3          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -52,6 +52,10 @@ SIGNATURES = {
     "iff_field_create": (C.c_int, [C.POINTER(FieldDesc), _VP, C.POINTER(_VP)]),
     "iff_field_destroy": (None, [_VP]),
     "iff_field_table_bytes": (_SZ, [_VP]),
+    "iff_field_save": (C.c_int, [_VP, C.c_char_p, _VP]),
+    "iff_field_load": (C.c_int, [C.c_char_p, _VP, C.POINTER(_VP)]),
+    "iff_idnet_save": (C.c_int, [_VP, C.c_char_p, _VP]),
+    "iff_idnet_load": (C.c_int, [C.c_char_p, _VP, C.POINTER(_VP)]),
     "iff_normalize_coord": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_mask_sample": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_density_feature": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
@@ -62,6 +66,7 @@ SIGNATURES = {
     "iff_ref_normals": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_isocell_emit": (C.c_int, [c_float_p, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     "iff_march_workspace": (_SZ, [_VP, _I64, _I32, _I32]),
+    "iff_march_default_samples": (_I32, [_VP, _I32]),
     "iff_march_shade": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, c_float_p, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_march_shade_timed": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, c_float_p, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, c_float_p, _VP]),
     "iff_surface_sample_workspace": (_SZ, [_I64]),
@@ -71,6 +76,7 @@ SIGNATURES = {
     "iff_idnet_create": (C.c_int, [C.POINTER(IdNetDesc), _VP, C.POINTER(_VP)]),
     "iff_idnet_destroy": (None, [_VP]),
     "iff_idnet_gemm_mode": (_I32, [_VP]),
+    "iff_idnet_dims": (C.c_int, [_VP, _VP, _VP, _VP]),
     "iff_ray_encode_workspace": (_SZ, [_VP, _I64]),
     "iff_ray_encode": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _SZ, _VP]),
     "iff_k_proj": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
@@ -87,6 +93,11 @@ SIGNATURES = {
     "iff_ray_logits_folded_batched_workspace": (_SZ, [_VP, _I32, _I64, _I32]),
     "iff_ray_logits_folded_batched": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_ray_logits_folded_timed": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, c_float_p, _VP]),
+    "iff_ray_cache_bytes": (_SZ, [_VP, _I64]),
+    "iff_ray_cache_workspace": (_SZ, [_VP, _I64]),
+    "iff_ray_cache_build": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _SZ, _VP, _SZ, _VP]),
+    "iff_logits_from_cache_workspace": (_SZ, [_VP, _I64, _I32]),
+    "iff_logits_from_cache": (C.c_int, [_VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_attn_colsum": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
     "iff_topk_workspace": (_SZ, [_I64, _I32]),
     "iff_topk": (C.c_int, [_VP, _I64, _I32, _VP, _VP, _VP, _SZ, _VP]),

@@ -243,6 +243,8 @@ static int march_samples(const iff_field* f, int32_t mode, int32_t n_samples) {
     return n_samples > 0 ? n_samples : (mode == IFF_MARCH_POINT_CENTRED ? 20 : f->dev.n_samples);
 }
 
+extern "C" int32_t iff_march_default_samples(const iff_field* f, int32_t mode) { return f ? march_samples(f, mode, 0) : 0; }
+
 extern "C" size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples) {
     if (!f || R <= 0) return 0;
     return march_workspace_bytes(R, march_samples(f, mode, n_samples));
@@ -414,6 +416,12 @@ static bool plan_f16_scales(const float* W1, const float* b1, const float* W2, c
     if (e3h + v.e_h2 - v.e_x > e3x) e3h = e3x - v.e_h2 + v.e_x;
     v.e_w3h = e3h; v.e_w3x = e3h + v.e_h2 - v.e_x;
     return std::isfinite(H3) && v.e_h1 >= -3 && v.e_h2 >= -3 && v.e_h3 >= -3 && v.e_w3x >= -8 && v.e_w3h >= -8;
+}
+
+extern "C" int iff_idnet_dims(const iff_idnet* n, int32_t* feature_c, int32_t* fea, int32_t* img_fea) {
+    IFF_REQUIRE(n && feature_c && fea && img_fea, "iff_idnet_dims: null argument");
+    *feature_c = n->dev.feature_c; *fea = n->dev.fea; *img_fea = n->dev.img_fea;
+    return 0;
 }
 
 extern "C" int32_t iff_idnet_gemm_mode(const iff_idnet* n) {
@@ -625,6 +633,63 @@ extern "C" int iff_ray_logits_folded_timed(const iff_idnet* n, int32_t B, const 
                              workspace_bytes, trunk_ms_host, stream);
 }
 
+// ---- per-model encoder cache
+static size_t up256a(size_t v) { return (v + 255) & ~(size_t)255; }
+extern "C" size_t iff_ray_cache_bytes(const iff_idnet* n, int64_t N) {
+    if (!n || N <= 0) return 0;
+    // F16X2: fp16 hi/lo planes [2][N][C]; otherwise the fp32 activation [N][C]
+    return (size_t)N * n->dev.feature_c * 4;
+}
+extern "C" size_t iff_ray_cache_workspace(const iff_idnet* n, int64_t N) {
+    return (n && N > 0 && !n->dev.trunk_f16) ? ray_trunk_workspace_bytes(n->dev, N) : 0;
+}
+extern "C" int iff_ray_cache_build(const iff_idnet* n, const float* o, const float* d, const float* rgb, int64_t N, void* cache,
+                                   size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(n && N >= 0, "iff_ray_cache_build: bad argument");
+    if (N == 0) return 0;
+    IFF_REQUIRE(o && d && rgb && cache, "iff_ray_cache_build: null buffer");
+    if (cache_bytes < iff_ray_cache_bytes(n, N)) return fail(IFF_ERR_WORKSPACE, "iff_ray_cache_build: cache %zu < %zu bytes", cache_bytes, iff_ray_cache_bytes(n, N));
+    if (n->dev.trunk_f16) {
+        IFF_HIP(launch_trunk_h_cache(n->dev, o, d, rgb, N, cache, (hipStream_t)stream));
+        return 0;
+    }
+    if (!workspace || workspace_bytes < ray_trunk_workspace_bytes(n->dev, N))
+        return fail(IFF_ERR_WORKSPACE, "iff_ray_cache_build: workspace %zu < %zu bytes", workspace_bytes, ray_trunk_workspace_bytes(n->dev, N));
+    IFF_HIP(launch_ray_trunk(n->dev, o, d, rgb, N, (float*)cache, workspace, workspace_bytes, (hipStream_t)stream));
+    return 0;
+}
+extern "C" size_t iff_logits_from_cache_workspace(const iff_idnet* n, int64_t N, int32_t M) {
+    if (!n || N <= 0 || M <= 0 || !n->dev.trunk_f16) return 0;
+    const size_t n_tb = (size_t)(M + 255) / 256, n_blk = (size_t)(N + 63) / 64;
+    return up256a(n_tb * (n->dev.feature_c / 16) * 2 * 8 * 64 * 16) + up256a(n_blk * n_tb * 256 * 8) + up256a(n_tb * 256 * 4) + 256;
+}
+extern "C" int iff_logits_from_cache(const iff_idnet* n, const void* cache, int64_t N, const float* qf, int32_t M, float divisor,
+                                     float* logits, float* row_max, float* row_sumexp, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    IFF_REQUIRE(n && N >= 0 && M >= 0, "iff_logits_from_cache: bad argument");
+    if (N == 0 || M == 0) return 0;
+    IFF_REQUIRE(cache && qf && logits, "iff_logits_from_cache: null buffer");
+    IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_logits_from_cache: pass both row statistics or neither");
+    if (!n->dev.trunk_f16) {
+        IFF_HIP(launch_attn_logits_folded(qf, n->dev.qf_ld, (const float*)cache, M, N, n->dev.feature_c, divisor, logits, row_max,
+                                          row_sumexp, (hipStream_t)stream));
+        return 0;
+    }
+    if (!workspace || workspace_bytes < iff_logits_from_cache_workspace(n, N, M))
+        return fail(IFF_ERR_WORKSPACE, "iff_logits_from_cache: workspace %zu < %zu bytes", workspace_bytes, iff_logits_from_cache_workspace(n, N, M));
+    const size_t n_tb = (size_t)(M + 255) / 256, n_blk64 = (size_t)(N + 63) / 64;
+    char* base = (char*)workspace;
+    void* Qf = base;
+    float2* part = (float2*)(base + up256a(n_tb * (n->dev.feature_c / 16) * 2 * 8 * 64 * 16));
+    float* qscale = (float*)((char*)part + up256a(n_blk64 * n_tb * 256 * 8));
+    IFF_HIP(launch_trunk_h_logits_cached(n->dev, cache, N, qf, M, divisor, logits, Qf, qscale, part, (hipStream_t)stream));
+    if (row_max) {
+        const int rpw = trunk_h_rays_per_wg(n->dev.trunk_variant);
+        IFF_HIP(launch_merge_stats(part, (int)((N + rpw - 1) / rpw), (int)(n_tb * 256), M, 1, row_max, row_sumexp, (hipStream_t)stream));
+    }
+    return 0;
+}
+
 extern "C" int iff_k_proj(const iff_idnet* n, const float* ray_features, int64_t N, float* k_out, void* stream) {
     IFF_REQUIRE(n && N >= 0, "iff_k_proj: bad argument");
     if (N == 0) return 0;
@@ -714,5 +779,157 @@ extern "C" int iff_pose_from_topk_batched(const int64_t* idx, const float* val, 
     IFF_REQUIRE(idx && val && rays_o && rays_d && up_host && c2w, "iff_pose_from_topk_batched: null buffer");
     IFF_REQUIRE(k >= 1 && k <= 1024, "iff_pose_from_topk_batched: k = %d outside [1, 1024]", k);
     IFF_HIP(launch_pose(idx, val, Q, k, rays_o, rays_d, N, ray_batch_stride, up_host, c2w, nullptr, (hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ table files
+// A handle's slab (tables already in kernel layout) written to / read from one file, so that a serving process skips the
+// reference-layout checkpoint and the K0 re-layout (models/tensorBase.py:424-458 is the reference's on-disk format; this is
+// its pre-laid-out counterpart).  Layout, little-endian:
+//   header (64 B) | device-side descriptor struct with every pointer replaced by (offset into the slab + 1, 0 = null) |
+//   slab bytes | extra (field: the occupied-voxel list, int32 each)
+// The descriptor struct's size is stored and checked, so a file written by a build with another struct layout is refused
+// rather than misread; IFF_TABLE_FILE_VERSION changes whenever a table's layout does.
+#define IFF_TABLE_FILE_VERSION 1
+struct TableFileHeader {
+    char magic[8];              // "IFFTABLE"
+    uint32_t version, kind;     // kind 1 = field, 2 = idnet
+    uint32_t abi, struct_bytes;
+    uint64_t slab_bytes, extra_count;
+    uint64_t reserved[3];
+};
+static_assert(sizeof(TableFileHeader) == 64, "header is 64 bytes");
+
+template <typename Dev>
+static void rebase(Dev& v, const std::vector<const void**>& ptrs, const char* from, const char* to) {
+    // from != null: pointer -> offset + 1;  to != null: offset + 1 -> pointer
+    for (const void** pp : ptrs) {
+        if (from) *pp = *pp ? (const void*)(uintptr_t)((const char*)*pp - from + 1) : nullptr;
+        else *pp = *pp ? (const void*)(to + ((uintptr_t)*pp - 1)) : nullptr;
+    }
+    (void)v;
+}
+static std::vector<const void**> field_ptrs(FieldDev& v) {
+    std::vector<const void**> p;
+    for (int i = 0; i < 3; ++i) {
+        p.push_back((const void**)&v.dplane[i]); p.push_back((const void**)&v.dline[i]);
+        p.push_back((const void**)&v.aplane[i]); p.push_back((const void**)&v.aline[i]);
+    }
+    p.push_back((const void**)&v.basis_l); p.push_back((const void**)&v.basis_l12); p.push_back((const void**)&v.basis);
+    p.push_back((const void**)&v.mask); p.push_back((const void**)&v.head);
+    return p;
+}
+static std::vector<const void**> idnet_ptrs(IdNetDev& v) {
+    std::vector<const void**> p;
+    const void** all[] = {(const void**)&v.w1, (const void**)&v.b1, (const void**)&v.w2, (const void**)&v.b2, (const void**)&v.w3,
+                          (const void**)&v.b3, (const void**)&v.w4, (const void**)&v.b4, (const void**)&v.wk, (const void**)&v.bk,
+                          (const void**)&v.wq, (const void**)&v.bq, &v.p1, &v.p2, &v.p3, &v.p4, &v.pk, (const void**)&v.wqf,
+                          (const void**)&v.bqf, &v.f1, &v.f2, &v.f3, &v.h1, &v.h2, &v.h3h, &v.h3x};
+    for (auto q : all) p.push_back(q);
+    return p;
+}
+
+static int write_table_file(const char* path, uint32_t kind, const void* dev_struct, size_t struct_bytes, const void* slab,
+                            size_t slab_bytes, const int* extra_dev, size_t extra_count, hipStream_t s) {
+    std::vector<char> host(slab_bytes);
+    std::vector<int> extra(extra_count);
+    IFF_HIP(hipStreamSynchronize(s));
+    IFF_HIP(hipMemcpy(host.data(), slab, slab_bytes, hipMemcpyDeviceToHost));
+    if (extra_count) IFF_HIP(hipMemcpy(extra.data(), extra_dev, extra_count * sizeof(int), hipMemcpyDeviceToHost));
+    FILE* fh = fopen(path, "wb");
+    if (!fh) return fail(IFF_ERR_INVALID_ARGUMENT, "cannot open %s for writing", path);
+    TableFileHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "IFFTABLE", 8);
+    h.version = IFF_TABLE_FILE_VERSION; h.kind = kind; h.abi = IFF_ABI_VERSION; h.struct_bytes = (uint32_t)struct_bytes;
+    h.slab_bytes = slab_bytes; h.extra_count = extra_count;
+    bool ok = fwrite(&h, sizeof(h), 1, fh) == 1 && fwrite(dev_struct, struct_bytes, 1, fh) == 1 &&
+              (slab_bytes == 0 || fwrite(host.data(), slab_bytes, 1, fh) == 1) &&
+              (extra_count == 0 || fwrite(extra.data(), extra_count * sizeof(int), 1, fh) == 1);
+    ok = (fclose(fh) == 0) && ok;
+    return ok ? 0 : fail(IFF_ERR_INVALID_ARGUMENT, "short write to %s", path);
+}
+
+static int read_table_file(const char* path, uint32_t kind, void* dev_struct, size_t struct_bytes, std::vector<char>& slab,
+                           std::vector<int>& extra) {
+    FILE* fh = fopen(path, "rb");
+    if (!fh) return fail(IFF_ERR_INVALID_ARGUMENT, "cannot open %s", path);
+    TableFileHeader h;
+    int rc = 0;
+    if (fread(&h, sizeof(h), 1, fh) != 1 || memcmp(h.magic, "IFFTABLE", 8) != 0) rc = fail(IFF_ERR_INVALID_ARGUMENT, "%s is not an IFFTABLE file", path);
+    else if (h.version != IFF_TABLE_FILE_VERSION || h.kind != kind || h.struct_bytes != struct_bytes)
+        rc = fail(IFF_ERR_UNSUPPORTED, "%s: table file version %u kind %u descriptor %u B; this build reads version %u kind %u descriptor %zu B",
+                  path, h.version, h.kind, h.struct_bytes, IFF_TABLE_FILE_VERSION, kind, struct_bytes);
+    else if (h.slab_bytes > ((uint64_t)1 << 40) || h.extra_count > ((uint64_t)1 << 32)) rc = fail(IFF_ERR_INVALID_ARGUMENT, "%s: implausible sizes", path);
+    else {
+        slab.resize(h.slab_bytes);
+        extra.resize(h.extra_count);
+        bool ok = fread(dev_struct, struct_bytes, 1, fh) == 1 && (h.slab_bytes == 0 || fread(slab.data(), h.slab_bytes, 1, fh) == 1) &&
+                  (h.extra_count == 0 || fread(extra.data(), h.extra_count * sizeof(int), 1, fh) == 1);
+        if (!ok) rc = fail(IFF_ERR_INVALID_ARGUMENT, "%s is truncated", path);
+    }
+    fclose(fh);
+    return rc;
+}
+
+extern "C" int iff_field_save(const iff_field* f, const char* path, void* stream) {
+    IFF_REQUIRE(f && path, "iff_field_save: null argument");
+    FieldDev v = f->dev;
+    rebase(v, field_ptrs(v), (const char*)f->slab, nullptr);
+    return write_table_file(path, 1, &v, sizeof(v), f->slab, f->slab_bytes, f->occ_list, (size_t)f->n_occ, (hipStream_t)stream);
+}
+
+extern "C" int iff_field_load(const char* path, void* stream, iff_field** out) {
+    IFF_REQUIRE(path && out, "iff_field_load: null argument");
+    *out = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    FieldDev v;
+    std::vector<char> slab;
+    std::vector<int> occ;
+    int rc = read_table_file(path, 1, &v, sizeof(v), slab, occ);
+    if (rc) return rc;
+    iff_field* f = new iff_field();
+    f->slab_bytes = slab.size();
+    f->n_occ = (int)occ.size();
+    IFF_CREATE_HIP(hipMalloc(&f->slab, slab.size()));
+    IFF_CREATE_HIP(hipMemcpyAsync(f->slab, slab.data(), slab.size(), hipMemcpyHostToDevice, s));
+    if (f->n_occ > 0) {
+        IFF_CREATE_HIP(hipMalloc((void**)&f->occ_list, occ.size() * sizeof(int)));
+        IFF_CREATE_HIP(hipMemcpyAsync(f->occ_list, occ.data(), occ.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    IFF_CREATE_HIP(hipStreamSynchronize(s));
+    rebase(v, field_ptrs(v), nullptr, (const char*)f->slab);
+    f->dev = v;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) f->n_cus = prop.multiProcessorCount;
+    *out = f;
+    return 0;
+}
+
+extern "C" int iff_idnet_save(const iff_idnet* n, const char* path, void* stream) {
+    IFF_REQUIRE(n && path, "iff_idnet_save: null argument");
+    IdNetDev v = n->dev;
+    rebase(v, idnet_ptrs(v), (const char*)n->slab, nullptr);
+    return write_table_file(path, 2, &v, sizeof(v), n->slab, n->slab_bytes, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int iff_idnet_load(const char* path, void* stream, iff_idnet** out) {
+    IFF_REQUIRE(path && out, "iff_idnet_load: null argument");
+    *out = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    IdNetDev v;
+    std::vector<char> slab;
+    std::vector<int> none;
+    int rc = read_table_file(path, 2, &v, sizeof(v), slab, none);
+    if (rc) return rc;
+    iff_idnet* n = new iff_idnet();
+    n->slab_bytes = slab.size();
+    IFF_NET_HIP(hipMalloc(&n->slab, slab.size()));
+    IFF_NET_HIP(hipMemcpyAsync(n->slab, slab.data(), slab.size(), hipMemcpyHostToDevice, s));
+    IFF_NET_HIP(hipStreamSynchronize(s));
+    rebase(v, idnet_ptrs(v), nullptr, (const char*)n->slab);
+    n->dev = v;
+    *out = n;
     return 0;
 }

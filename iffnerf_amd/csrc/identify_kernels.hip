@@ -808,6 +808,11 @@ __global__ void __launch_bounds__(FG == 2 ? 256 : 512) k5_trunk(const float* __r
     }
 }
 
+hipError_t launch_merge_stats(const float2* part, int n_blk, int Mpad, int M, int B, float* row_max, float* row_sumexp, hipStream_t s) {
+    hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4), (unsigned)B), dim3(256), 0, s, part, n_blk, Mpad, M, row_max, row_sumexp);
+    return hipGetLastError();
+}
+
 size_t ray_encode_workspace_bytes(const IdNetDev& n, int64_t N) {
     // x [N,XW] + two ping-pong activations [N, max(feature_c, fea)]
     int wide = n.feature_c > n.fea ? n.feature_c : n.fea;

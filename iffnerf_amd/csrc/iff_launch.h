@@ -88,6 +88,11 @@ hipError_t launch_frag_order_h(const float* W, int ld, int col0, int ncols, int 
 int trunk_h_rays_per_wg(int variant);
 hipError_t launch_trunk_h_features(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, int B, float* h3,
                                    hipStream_t s);
+hipError_t launch_trunk_h_cache(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, void* planes,
+                                hipStream_t s);
+hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, int64_t N, const float* qf, int M, float divisor,
+                                        float* logits, void* Qf, float* qscale, float2* part, hipStream_t s);
+hipError_t launch_merge_stats(const float2* part, int n_blk, int Mpad, int M, int B, float* row_max, float* row_sumexp, hipStream_t s);
 hipError_t launch_trunk_h_logits(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf, int M,
                                  int B, float divisor, float* logits, void* Qf, float* qscale, float2* part, hipStream_t s);
 hipError_t launch_split_rows(const float* w, void* planes, int out_f, int in_f, int in_pad, hipStream_t s);

@@ -120,7 +120,8 @@ struct TrunkHArgs {
     float inv1, s1;           // h1 = relu(acc inv1 + b1); its planes hold h1 s1
     float inv2, s2;
     float inv3, s3;           // layer 3: the h-part and the x-part accumulate at one common scale
-    float* h3;                // LOGITS = false: [N][256] fp32 out
+    float* h3;                // MODE 0: [N][256] fp32 out
+    _Float16* planes;         // MODE 2 (out) / MODE 3 (in): the h3 hi/lo planes [2][N][256], times s3 -- the per-model cache
     const uint4* Qf; const float* qscale; const float* rowc; int rowc_ld; int M; float divisor;
     float* logits; float2* part; int Mpad;
 };
@@ -166,8 +167,12 @@ __device__ inline void trunk_mfma_ht(f32x16 (&acc)[FG][RG], const WFragH<FG>& w,
 struct __attribute__((packed, aligned(4))) f4uh { float x, y, z, w; };     // 16-byte store at 4-byte alignment
 
 // FG = 32-feature groups per wave (8 / FG waves per workgroup), RG = 32-ray groups per workgroup (TR = 32 RG rays).
-template <bool LOGITS, int FG, int RG>
+// MODE 0: rays -> h3 [N][256] fp32 (iff_ray_trunk).  MODE 1: rays -> logits + softmax partials (the fused per-query launch).
+// MODE 2: rays -> the h3 hi/lo planes in HBM (iff_ray_cache_build: the encoder once per resident ray set).
+// MODE 3: cached planes -> logits + softmax partials (iff_logits_from_cache: every later query batch skips the encoder).
+template <int MODE, int FG, int RG>
 __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_trunk_h(TrunkHArgs a) {
+    constexpr bool LOGITS = MODE == 1 || MODE == 3;
     constexpr int TR = 32 * RG, NT = 64 * 8 / FG, NWAVE = 8 / FG;
     __shared__ __attribute__((aligned(16))) _Float16 S[2][TR][HSLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,67 +182,81 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
     {   // blockIdx.y = query of a batch: its own rays [N,3], folded query planes, logits [M,N] and partials
         const size_t qb = blockIdx.y;
         a.ray_o += qb * N * 3; a.ray_d += qb * N * 3; a.ray_c += qb * N * 3;
+        if (MODE == 2 || MODE == 3) a.planes += qb * 2 * (size_t)N * HC;
         if (LOGITS) {
             a.Qf += qb * (size_t)(a.Mpad / 256) * (HC / 16) * 2 * 8 * 64;
             a.qscale += qb * (size_t)a.Mpad;
             a.rowc += qb * (size_t)a.M * a.rowc_ld;
             a.logits += qb * (size_t)a.M * N;
             a.part += qb * (size_t)gridDim.x * a.Mpad;
-        } else {
+        } else if (MODE == 0) {
             a.h3 += qb * N * HC;
         }
     }
-
-    // encoder input x (ray_preprocessor.py:30-37, tensorBase.py:14-20) straight into LDS as hi/lo planes:
-    // x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141 columns, zero-padded to 160; rows beyond N are zero).
-    // Work items per ray: 66 (source component, frequency) pairs -- one sincosf serves the sin and the cos column --
-    // plus the 9 raw values and the 19 pad columns: 94 items x TR rays over NT threads.
-    {
-        const float sx = a.sx;
-        auto put = [&](int ray, int col, float v) {
-            _Float16 hi, lo;
-            split_h(fminf(fmaxf(v * sx, -H_MAX), H_MAX), hi, lo);
-            S[0][ray][col] = hi; S[1][ray][col] = lo;
-        };
-        const int ray = tid % TR;
-        const int64_t gr = row0 + ray;
-        const bool ok = gr < N;
-        float src[9];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            src[c] = ok ? a.ray_o[3 * gr + c] : 0.0f;
-            src[3 + c] = ok ? a.ray_d[3 * gr + c] : 0.0f;
-            src[6 + c] = ok ? a.ray_c[3 * gr + c] : 0.0f;
+    if (MODE == 3) {
+        // the cached planes of this workgroup's rays straight into LDS (rows of 512 B, 16 B per lane; rows beyond N are zero)
+        for (int t = tid; t < 2 * TR * (HC / 8); t += NT) {
+            const int pl = t / (TR * (HC / 8)), rem = t - pl * (TR * (HC / 8)), ray = rem / (HC / 8), ch = rem - ray * (HC / 8);
+            const int64_t gr = row0 + ray;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gr < N) v = *reinterpret_cast<const uint4*>(a.planes + ((size_t)pl * N + gr) * HC + 8 * ch);
+            *reinterpret_cast<uint4*>(&S[pl][ray][8 * ch]) = v;
         }
-        for (int item = tid / TR; item < 94; item += NT / TR) {       // wave-uniform item -> no divergence
-            if (item < 66) {
-                // blocks: PE(o) at column 9, PE(d) at 57, PE(rgb) at 105; each [sin (F*3) | cos (F*3)], component-major
-                int blk = item < 24 ? 0 : (item < 48 ? 1 : 2);
-                int b = item - 24 * blk;
-                int F = blk == 2 ? 6 : 8;
-                int j = b / F, k = b - j * F;
-                // select instead of src[3 * blk + j]: a dynamically indexed local array would live in scratch memory
-                const float c0 = blk == 0 ? src[0] : (blk == 1 ? src[3] : src[6]);
-                const float c1 = blk == 0 ? src[1] : (blk == 1 ? src[4] : src[7]);
-                const float c2 = blk == 0 ? src[2] : (blk == 1 ? src[5] : src[8]);
-                float arg = (j == 0 ? c0 : (j == 1 ? c1 : c2)) * (float)(1 << k);
-                float sv, cv;
-                sincosf(arg, &sv, &cv);               // one argument reduction for both columns
-                int col = 9 + 48 * blk + b;
-                put(ray, col, sv);
-                put(ray, col + 3 * F, cv);
-            } else if (item < 75) {
-                const int ci = item - 66;
-                float rv = src[0];
-#pragma unroll
-                for (int u = 1; u < 9; ++u) rv = (ci == u) ? src[u] : rv;
-                put(ray, ci, rv);
-            } else {
-                put(ray, 141 + (item - 75), 0.0f);
+        __syncthreads();
+    }
+
+    if (MODE != 3) {
+        // encoder input x (ray_preprocessor.py:30-37, tensorBase.py:14-20) straight into LDS as hi/lo planes:
+        // x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141 columns, zero-padded to 160; rows beyond N are zero).
+        // Work items per ray: 66 (source component, frequency) pairs -- one sincosf serves the sin and the cos column --
+        // plus the 9 raw values and the 19 pad columns: 94 items x TR rays over NT threads.
+        {
+            const float sx = a.sx;
+            auto put = [&](int ray, int col, float v) {
+                _Float16 hi, lo;
+                split_h(fminf(fmaxf(v * sx, -H_MAX), H_MAX), hi, lo);
+                S[0][ray][col] = hi; S[1][ray][col] = lo;
+            };
+            const int ray = tid % TR;
+            const int64_t gr = row0 + ray;
+            const bool ok = gr < N;
+            float src[9];
+    #pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                src[c] = ok ? a.ray_o[3 * gr + c] : 0.0f;
+                src[3 + c] = ok ? a.ray_d[3 * gr + c] : 0.0f;
+                src[6 + c] = ok ? a.ray_c[3 * gr + c] : 0.0f;
+            }
+            for (int item = tid / TR; item < 94; item += NT / TR) {       // wave-uniform item -> no divergence
+                if (item < 66) {
+                    // blocks: PE(o) at column 9, PE(d) at 57, PE(rgb) at 105; each [sin (F*3) | cos (F*3)], component-major
+                    int blk = item < 24 ? 0 : (item < 48 ? 1 : 2);
+                    int b = item - 24 * blk;
+                    int F = blk == 2 ? 6 : 8;
+                    int j = b / F, k = b - j * F;
+                    // select instead of src[3 * blk + j]: a dynamically indexed local array would live in scratch memory
+                    const float c0 = blk == 0 ? src[0] : (blk == 1 ? src[3] : src[6]);
+                    const float c1 = blk == 0 ? src[1] : (blk == 1 ? src[4] : src[7]);
+                    const float c2 = blk == 0 ? src[2] : (blk == 1 ? src[5] : src[8]);
+                    float arg = (j == 0 ? c0 : (j == 1 ? c1 : c2)) * (float)(1 << k);
+                    float sv, cv;
+                    sincosf(arg, &sv, &cv);               // one argument reduction for both columns
+                    int col = 9 + 48 * blk + b;
+                    put(ray, col, sv);
+                    put(ray, col + 3 * F, cv);
+                } else if (item < 75) {
+                    const int ci = item - 66;
+                    float rv = src[0];
+    #pragma unroll
+                    for (int u = 1; u < 9; ++u) rv = (ci == u) ? src[u] : rv;
+                    put(ray, ci, rv);
+                } else {
+                    put(ray, 141 + (item - 75), 0.0f);
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     auto load_act = [&](f16x8 (&v)[RG][2], int ks) {
 #pragma unroll
@@ -322,25 +341,40 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
     constexpr bool LEAN = (FG == 1 && RG == 2);
     constexpr int DEPTH_DUAL = LEAN ? 2 : 3, DEPTH_ONE = LEAN ? 3 : 4;
 
-    // layer 1 and the x-part of layer 3, one pass over x
-    phase(integral_constant<int, KX>{}, integral_constant<int, DEPTH_DUAL>{}, yes_t{}, no_t{}, acc, a.W1, acc3, a.W3x);
-    __syncthreads();                      // every wave has finished reading x
-    write_planes(acc, a.b1, a.inv1, a.s1);
-    __syncthreads();
-
-    // layer 2
-    zero(acc);
-    phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc, a.W2, acc, a.W2);
-    __syncthreads();
-    write_planes(acc, a.b2, a.inv2, a.s2);
-    __syncthreads();
-
-    // layer 3, h-part, on top of the x-part
-    phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc3, a.W3h, acc3, a.W3h);
-    __syncthreads();                      // every wave has finished reading h2
-    if (LOGITS) {
-        write_planes(acc3, a.b3, a.inv3, a.s3);           // h3 planes
+    if (MODE != 3) {
+        // layer 1 and the x-part of layer 3, one pass over x
+        phase(integral_constant<int, KX>{}, integral_constant<int, DEPTH_DUAL>{}, yes_t{}, no_t{}, acc, a.W1, acc3, a.W3x);
+        __syncthreads();                      // every wave has finished reading x
+        write_planes(acc, a.b1, a.inv1, a.s1);
         __syncthreads();
+
+        // layer 2
+        zero(acc);
+        phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc, a.W2, acc, a.W2);
+        __syncthreads();
+        write_planes(acc, a.b2, a.inv2, a.s2);
+        __syncthreads();
+
+        // layer 3, h-part, on top of the x-part
+        phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc3, a.W3h, acc3, a.W3h);
+        __syncthreads();                      // every wave has finished reading h2
+    }
+    if (MODE == 2) {
+        // the cache: h3 planes from LDS to HBM, whole 512-B rows per 32 lanes
+        write_planes(acc3, a.b3, a.inv3, a.s3);
+        __syncthreads();
+        for (int t = tid; t < 2 * TR * (HC / 8); t += NT) {
+            const int pl = t / (TR * (HC / 8)), rem = t - pl * (TR * (HC / 8)), ray = rem / (HC / 8), ch = rem - ray * (HC / 8);
+            const int64_t gr = row0 + ray;
+            if (gr < N) *reinterpret_cast<uint4*>(a.planes + ((size_t)pl * N + gr) * HC + 8 * ch) = *reinterpret_cast<const uint4*>(&S[pl][ray][8 * ch]);
+        }
+        return;
+    }
+    if (LOGITS) {
+        if (MODE == 1) {
+            write_planes(acc3, a.b3, a.inv3, a.s3);           // h3 planes
+            __syncthreads();
+        }
         const int n_tb = a.Mpad / 256;
         const float divisor = a.divisor, inv_div = 1.0f / divisor;
         for (int tb = 0; tb < n_tb; ++tb) {
@@ -438,16 +472,16 @@ static TrunkHArgs base_args(const IdNetDev& n, const float* o, const float* d, c
     a.inv1 = ldexpf(1.0f, -(n.e_w1 + n.e_x)); a.s1 = ldexpf(1.0f, n.e_h1);
     a.inv2 = ldexpf(1.0f, -(n.e_w2 + n.e_h1)); a.s2 = ldexpf(1.0f, n.e_h2);
     a.inv3 = ldexpf(1.0f, -(n.e_w3h + n.e_h2)); a.s3 = ldexpf(1.0f, n.e_h3);
-    a.h3 = nullptr; a.Qf = nullptr; a.qscale = nullptr; a.rowc = nullptr; a.rowc_ld = 0; a.M = 0; a.divisor = 1.0f;
+    a.h3 = nullptr; a.planes = nullptr; a.Qf = nullptr; a.qscale = nullptr; a.rowc = nullptr; a.rowc_ld = 0; a.M = 0; a.divisor = 1.0f;
     a.logits = nullptr; a.part = nullptr; a.Mpad = 0;
     return a;
 }
 
-template <bool LOGITS>
+template <int MODE>
 static hipError_t launch_variant(int variant, dim3 grid, const TrunkHArgs& a, hipStream_t s) {
-    if (variant == 1) hipLaunchKernelGGL((k5_trunk_h<LOGITS, 2, 2>), grid, dim3(256), 0, s, a);
-    else if (variant == 2) hipLaunchKernelGGL((k5_trunk_h<LOGITS, 1, 4>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k5_trunk_h<LOGITS, 1, 2>), grid, dim3(512), 0, s, a);
+    if (variant == 1) hipLaunchKernelGGL((k5_trunk_h<MODE, 2, 2>), grid, dim3(256), 0, s, a);
+    else if (variant == 2) hipLaunchKernelGGL((k5_trunk_h<MODE, 1, 4>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k5_trunk_h<MODE, 1, 2>), grid, dim3(512), 0, s, a);
     return hipGetLastError();
 }
 
@@ -456,7 +490,7 @@ hipError_t launch_trunk_h_features(const IdNetDev& n, const float* o, const floa
     TrunkHArgs a = base_args(n, o, d, rgb, N);
     a.h3 = h3;
     const int TR = trunk_h_rays_per_wg(n.trunk_variant);
-    return launch_variant<false>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
+    return launch_variant<0>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
 }
 
 // qf [B*M][qf_ld] -> Qf planes + qscale in `ws` (layout: Qf | qscale | part), then the fused launch; `part_out` / `n_blk_out`
@@ -472,5 +506,29 @@ hipError_t launch_trunk_h_logits(const IdNetDev& n, const float* o, const float*
     a.Qf = (const uint4*)Qf; a.qscale = qscale; a.rowc = qf + HC; a.rowc_ld = n.qf_ld; a.M = M; a.divisor = divisor;
     a.logits = logits; a.part = part; a.Mpad = Mpad;
     const int TR = trunk_h_rays_per_wg(n.trunk_variant);
-    return launch_variant<true>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
+    return launch_variant<1>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
+}
+
+// The per-model cache: the encoder's last hidden activation as fp16 hi/lo planes [2][N][256] (1 KB per ray),
+// and the logits of a batch of token rows against it.
+hipError_t launch_trunk_h_cache(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, void* planes,
+                                hipStream_t s) {
+    TrunkHArgs a = base_args(n, o, d, rgb, N);
+    a.planes = (_Float16*)planes;
+    const int TR = trunk_h_rays_per_wg(n.trunk_variant);
+    return launch_variant<2>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), 1u), a, s);
+}
+
+hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, int64_t N, const float* qf, int M, float divisor,
+                                        float* logits, void* Qf, float* qscale, float2* part, hipStream_t s) {
+    const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
+    hipLaunchKernelGGL(k_qf_frag_h, dim3((unsigned)(Mpad / 32), 1u), dim3(256), 0, s, qf, n.qf_ld, M, n_tb, n.e_h3, (_Float16*)Qf, qscale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    TrunkHArgs a = base_args(n, nullptr, nullptr, nullptr, N);
+    a.planes = (_Float16*)const_cast<void*>(planes);
+    a.Qf = (const uint4*)Qf; a.qscale = qscale; a.rowc = qf + HC; a.rowc_ld = n.qf_ld; a.M = M; a.divisor = divisor;
+    a.logits = logits; a.part = part; a.Mpad = Mpad;
+    const int TR = trunk_h_rays_per_wg(n.trunk_variant);
+    return launch_variant<3>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), 1u), a, s);
 }

@@ -84,6 +84,30 @@ class FieldHandle:
         self._h = out
         self.table_bytes = int(L.iff_field_table_bytes(out))
 
+    # ------------------------------------------------------------------ table files (include/iffnerf_hip.h iff_field_save / _load)
+    def save(self, path: str) -> None:
+        """Write the handle's tables, already in kernel layout, to ``path`` (a pre-laid-out counterpart of the ``.th``
+        checkpoint: a serving process loads it with ``FieldHandle.from_file`` and skips TensorBase.load + the re-layout)."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().iff_field_save(self._h, str(path).encode(), stream_ptr(self.device)), "iff_field_save")
+
+    @classmethod
+    def from_file(cls, path: str, device) -> "FieldHandle":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"FieldHandle needs a GPU device (got {device}); libiffnerf_hip has no CPU path")
+        L = _lib.lib()
+        self = cls.__new__(cls)
+        self._h, self.device = None, device
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            check(L.iff_field_load(str(path).encode(), stream_ptr(device), C.byref(out)), "iff_field_load")
+        self._h = out
+        self.app_dim = 27
+        self.n_samples_default = int(L.iff_march_default_samples(out, MARCH_SLAB))
+        self.table_bytes = int(L.iff_field_table_bytes(out))
+        return self
+
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if getattr(self, "_h", None):

@@ -62,6 +62,30 @@ class IdNetHandle:
         self.requested_gemm_mode = self.gemm_mode
         self.gemm_mode = int(_lib.lib().iff_idnet_gemm_mode(out))       # F16X2 falls back to BF16X3 when fp16's range is too small
 
+    # ------------------------------------------------------------------ table files (include/iffnerf_hip.h iff_idnet_save / _load)
+    def save(self, path: str) -> None:
+        """Write every Linear in its MFMA layouts (and the planned F16X2 scales) to ``path``; ``IdNetHandle.from_file`` loads it."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().iff_idnet_save(self._h, str(path).encode(), stream_ptr(self.device)), "iff_idnet_save")
+
+    @classmethod
+    def from_file(cls, path: str, device) -> "IdNetHandle":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"IdNetHandle needs a GPU device (got {device}); libiffnerf_hip has no CPU path")
+        L = _lib.lib()
+        self = cls.__new__(cls)
+        self._h, self.device = None, device
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            check(L.iff_idnet_load(str(path).encode(), stream_ptr(device), C.byref(out)), "iff_idnet_load")
+        self._h = out
+        dims = [C.c_int32() for _ in range(3)]
+        check(L.iff_idnet_dims(out, *[C.byref(v) for v in dims]), "iff_idnet_dims")
+        self.feature_c, self.fea, self.img_fea = (int(v.value) for v in dims)
+        self.gemm_mode = self.requested_gemm_mode = int(L.iff_idnet_gemm_mode(out))
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().iff_idnet_destroy(self._h)
@@ -198,6 +222,39 @@ class IdNetHandle:
             check(L.iff_ray_logits_folded_batched(self._h, batch, dptr(o), dptr(d), dptr(rgb), N, dptr(qf), M,
                                                   float(math.sqrt(self.fea)), dptr(logits), dptr(rmax), dptr(rsum), ws.data_ptr(),
                                                   ws_bytes, stream_ptr(self.device)), "iff_ray_logits_folded_batched")
+        return logits, rmax, rsum
+
+    # ------------------------------------------------------------------ per-model encoder cache
+    def build_ray_cache(self, o, d, rgb) -> torch.Tensor:
+        """The encoder once per resident ray set -> opaque cache (uint8 tensor) for ``logits_from_cache``."""
+        o, d, rgb = _gpu(o, "rays_ori", 3), _gpu(d, "rays_dir", 3), _gpu(rgb, "rays_rgb", 3)
+        N = o.shape[0]
+        if d.shape[0] != N or rgb.shape[0] != N:
+            raise RuntimeError("rays_ori / rays_dir / rays_rgb must have the same number of rows")
+        L = _lib.lib()
+        nbytes = int(L.iff_ray_cache_bytes(self._h, N))
+        cache = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=o.device)
+        ws_bytes = int(L.iff_ray_cache_workspace(self._h, N))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=o.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_ray_cache_build(self._h, dptr(o), dptr(d), dptr(rgb), N, cache.data_ptr(), nbytes, ws.data_ptr(), ws_bytes,
+                                        stream_ptr(self.device)), "iff_ray_cache_build")
+        return cache
+
+    def logits_from_cache(self, qf, cache: torch.Tensor, n_rays: int, want_stats: bool = True):
+        """Folded token rows qf [M, width] x cached rays -> (logits [M,N], row_max, row_sumexp): no encoder work."""
+        qf = _gpu(qf, "qf")
+        M, N = qf.shape[0], int(n_rays)
+        L = _lib.lib()
+        logits = qf.new_empty(M, N)
+        rmax = qf.new_empty(M) if want_stats else None
+        rsum = qf.new_empty(M) if want_stats else None
+        ws_bytes = int(L.iff_logits_from_cache_workspace(self._h, N, M))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=qf.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_logits_from_cache(self._h, cache.data_ptr(), N, dptr(qf), M, float(math.sqrt(self.fea)), dptr(logits),
+                                          dptr(rmax), dptr(rsum), ws.data_ptr(), ws_bytes, stream_ptr(self.device)),
+                  "iff_logits_from_cache")
         return logits, rmax, rsum
 
     def k_proj(self, ray_features):

@@ -51,6 +51,17 @@ class PosePipeline:
         return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device, gemm_mode, trunk_variant),
                    jitter_scale_from_kwargs(field_ckpt["kwargs"], "alphaMask.aabb" in field_ckpt), model_up, fold_heads)
 
+    def save_tables(self, field_path: str, idnet_path: str) -> None:
+        """Both handles as pre-laid-out table files; ``from_table_files`` is the matching loader."""
+        self.field.save(field_path)
+        self.idnet.save(idnet_path)
+
+    @classmethod
+    def from_table_files(cls, field_path: str, idnet_path: str, device, rho: float, model_up=(0.0, 0.0, 1.0)):
+        """Serving-side constructor: no ``.th`` checkpoint, no re-layout.  ``rho`` is the sampler's jitter scale
+        (``jitter_scale_from_kwargs``: a property of the checkpoint's grid, not stored in the tables)."""
+        return cls(FieldHandle.from_file(field_path, device), H.IdNetHandle.from_file(idnet_path, device), rho, model_up)
+
     def logits(self, tokens, ori, dirs, rgb):
         """tokens [M, C+14] x rays -> (logits [M,N], row_max [M], row_sumexp [M])."""
         if self.fold_heads:
@@ -100,6 +111,25 @@ class PosePipeline:
         score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
         idx, val = H.topk_batched(score, k)
         return H.pose_from_topk_batched(idx, val, ori, dirs, self.model_up), idx, val
+
+    # ------------------------------------------------------------------ resident rays: the encoder cached per model
+    def make_resident(self, ori, dirs, rgb) -> "ResidentRays":
+        """Rays of a model kept for many query images (the reference's eval loop emits once per model,
+        train_eval_pose_est.py:131-149): the ray encoder runs here, once; ``identify_resident`` then serves any number of
+        query batches without it.  Re-emission or new weights need a new ResidentRays."""
+        if not self.fold_heads:
+            raise RuntimeError("resident rays use the folded path (fold_heads=True)")
+        return ResidentRays(ori, dirs, rgb, self.idnet.build_ray_cache(ori, dirs, rgb))
+
+    def identify_resident(self, tokens, rays: "ResidentRays", k: int = 100):
+        """tokens [Q,M,C+14] against resident rays -> (c2w [Q,4,4], idx [Q,k], val [Q,k]); query q equals
+        ``identify(tokens[q], rays.ori, rays.dirs, rays.rgb)`` (bit for bit under F16X2)."""
+        Q, M, C = tokens.shape
+        qf = self.idnet.q_fold(tokens.reshape(Q * M, C))
+        logits, rmax, rsum = self.idnet.logits_from_cache(qf, rays.cache, rays.ori.shape[0])
+        score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
+        idx, val = H.topk_batched(score, k)
+        return H.pose_from_topk_batched(idx, val, rays.ori, rays.dirs, self.model_up), idx, val
 
     def query(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None, materialize_map: bool = False):
         """Cold per-query path: emission + identification + pose -> (c2w, top-k idx, top-k val).  The attention map is not
@@ -261,6 +291,13 @@ class PosePipeline:
 
     def capture_query_batch_sharded(self, tokens_shape, gen_points: int, seed: int = 0, k: int = 100, group=None) -> "CapturedShardedBatch":
         return CapturedShardedBatch(self, tokens_shape, gen_points, seed, k, group)
+
+
+class ResidentRays:
+    """A model's emitted rays plus the cached encoder output for them (PosePipeline.make_resident)."""
+
+    def __init__(self, ori, dirs, rgb, cache):
+        self.ori, self.dirs, self.rgb, self.cache = ori, dirs, rgb, cache
 
 
 class CapturedQuery:

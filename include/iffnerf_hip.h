@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 3
+#define IFF_ABI_VERSION 5
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -110,6 +110,13 @@ int  iff_field_create(const iff_field_desc* desc, void* stream, iff_field** out)
 void iff_field_destroy(iff_field* f);
 /* bytes of HBM the handle's tables occupy (for DESIGN.md / roofline bookkeeping) */
 size_t iff_field_table_bytes(const iff_field* f);
+/* Pre-laid-out table file: the handle's tables exactly as the kernels read them (channels-last planes / lines, byte
+ * occupancy, packed Ref head, occupied-voxel list) behind a versioned header, so a serving process builds its handle with
+ * one read and one copy instead of TensorBase.load + the re-layout of iff_field_create.  Counterpart of the reference's
+ * checkpoint file, models/tensorBase.py:424-458 (save / load).  `path` is a host string.  A handle loaded from a file is
+ * bit-for-bit the handle it was saved from; files of another IFF_TABLE_FILE_VERSION / descriptor layout are refused. */
+int iff_field_save(const iff_field* f, const char* path, void* stream);
+int iff_field_load(const char* path, void* stream, iff_field** out);
 
 /* TensorBase.normalize_coord, models/tensorBase.py:389-397.  xyz,out: [n,3] */
 int iff_normalize_coord(const iff_field* f, const float* xyz, int64_t n, float* out, void* stream);
@@ -145,6 +152,9 @@ int iff_isocell_emit(const float* cells_host, const float* points, const float* 
  *   Workspace (the [R,S] compositing weights between the two launches): iff_march_workspace(f, R, mode, n_samples).
  * Also what renderer.OctreeRender_trilinear_fast (renderer.py:12-25) calls per chunk. */
 size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples);
+/* samples per ray when n_samples <= 0: 20 for the point-centred sampler (pose_estimation/sampling.py:247), the handle's
+ * nSamples (models/tensorBase.py:368) for the slab sampler */
+int32_t iff_march_default_samples(const iff_field* f, int32_t mode);
 int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                     int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
                     float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream);
@@ -209,6 +219,14 @@ void iff_idnet_destroy(iff_idnet* net);
 /* the IFF_GEMM_* arithmetic the handle's fused encoder / logits launch actually runs (F16X2 may have fallen back to
  * BF16X3 at create time; ray_preprocessor.py:29-39 is computed to fp32 accuracy either way) */
 int32_t iff_idnet_gemm_mode(const iff_idnet* net);
+/* layer widths of the handle: featureC of RayPreprocessor (pose_estimation/ray_preprocessor.py:6), its output width and the
+ * image-token width of MultiHeadAttention (multihead_attention.py:31-45) */
+int iff_idnet_dims(const iff_idnet* net, int32_t* feature_c, int32_t* fea, int32_t* img_fea);
+/* Table file of the identification net (every Linear in its MFMA layouts: k-major fp32, bf16 planes, fragment-ordered
+ * bf16 / fp16 planes with their planned scales, the folded token-side Linear), as iff_field_save / iff_field_load.
+ * Counterpart of id_module.th (pose_estimation/train.py:226-234, reloaded at train_eval_pose_est.py:59-66). */
+int iff_idnet_save(const iff_idnet* net, const char* path, void* stream);
+int iff_idnet_load(const char* path, void* stream, iff_idnet** out);
 
 /* RayPreprocessor.forward (ray_preprocessor.py:29-39) and, when k_out != NULL, k_proj
  * (multihead_attention.py:61).  o,d,rgb [N,3] -> feat_opt [N,fea] (nullable), k_out [N,fea] (nullable). */
@@ -262,6 +280,23 @@ int iff_ray_logits_folded_timed(const iff_idnet* net, int32_t B, const float* o,
                                 const float* qf, int32_t M, float divisor, float* logits, float* row_max,
                                 float* row_sumexp, void* workspace, size_t workspace_bytes, float* trunk_ms_host,
                                 void* stream);
+
+/* The encoder cached per resident ray set.  The reference re-runs RayPreprocessor + k_proj for every query image
+ * (pose_estimation/identification_module.py:164 inside the loop of pose_estimation/test.py:67-91) although the rays of a model
+ * do not change between images (train_eval_pose_est.py:131-149) and the weights are frozen in eval: here the encoder's last
+ * hidden activation is computed ONCE per ray set (iff_ray_cache_build: ray_preprocessor.py:29-38 up to the last ReLU) and
+ * every later batch of token rows only pays the folded logits product against it (iff_logits_from_cache:
+ * multihead_attention.py:6-8).  The cache is opaque: fp16 hi/lo planes [2][N][feature_c] under IFF_GEMM_F16X2, the fp32
+ * activation [N][feature_c] otherwise; iff_ray_cache_bytes sizes it.  Results equal the uncached calls
+ * (iff_ray_logits_folded) bit for bit under F16X2.  The caller rebuilds the cache when it re-emits rays or changes weights. */
+size_t iff_ray_cache_bytes(const iff_idnet* net, int64_t N);
+size_t iff_ray_cache_workspace(const iff_idnet* net, int64_t N);
+int iff_ray_cache_build(const iff_idnet* net, const float* o, const float* d, const float* rgb, int64_t N, void* cache,
+                        size_t cache_bytes, void* workspace, size_t workspace_bytes, void* stream);
+size_t iff_logits_from_cache_workspace(const iff_idnet* net, int64_t N, int32_t M);
+int iff_logits_from_cache(const iff_idnet* net, const void* cache, int64_t N, const float* qf, int32_t M, float divisor,
+                          float* logits, float* row_max, float* row_sumexp, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* scaled_attention_product (multihead_attention.py:4-12, mask=None), split so that ray shards on several
  * GPUs can exchange row statistics between the two halves:

@@ -180,3 +180,28 @@ def test_warm_batch_equals_per_image_identification(dev):
         for q in range(5):
             w_c2w, w_idx, w_val = pipe.identify(tok[q], ori, dirs, rgb, 100, materialize_map=False)
             assert torch.equal(idx[q], w_idx) and torch.equal(val[q], w_val) and torch.equal(c2w[q], w_c2w), (M, q)
+
+
+def test_resident_rays_cache_in_every_gemm_mode(dev):
+    """The per-model encoder cache (iff_ray_cache_build / iff_logits_from_cache): bit-identical to the uncached fused call
+    under F16X2; under the other arithmetic modes the cache is the fp32 activation and the logits product a separate launch --
+    same scores to fp32 rounding, same top-100."""
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.pipeline import PosePipeline
+    w = synthetic.make_id_weights(seed=99)
+    tok = torch.stack([synthetic.make_tokens(137, 384, seed=60 + q) for q in range(3)]).to(dev)
+    for mode in (H.GEMM_F16X2, H.GEMM_BF16X3, H.GEMM_F32):
+        pipe = PosePipeline.from_checkpoints(util.ckpt("small"), w, dev, model_up=(0.1, 0.2, 0.9), gemm_mode=mode)
+        ori, dirs, rgb = pipe.emit(75, seed=3)
+        rays = pipe.make_resident(ori, dirs, rgb)
+        c2w, idx, val = pipe.identify_resident(tok, rays, 100)
+        for q in range(3):
+            w_c2w, w_idx, w_val = pipe.identify(tok[q], ori, dirs, rgb, 100, materialize_map=False)
+            if mode == H.GEMM_F16X2:
+                assert torch.equal(idx[q], w_idx) and torch.equal(val[q], w_val) and torch.equal(c2w[q], w_c2w), q
+            else:
+                assert idx[q].tolist() == w_idx.tolist(), (mode, q)
+                torch.testing.assert_close(val[q], w_val, atol=1e-7, rtol=1e-4)
+                torch.testing.assert_close(c2w[q], w_c2w, atol=1e-5, rtol=0)
+    # empty batch of rays: nothing to cache, nothing crashes
+    assert pipe.idnet.build_ray_cache(ori[:0], dirs[:0], rgb[:0]).numel() >= 0

@@ -231,6 +231,36 @@ def test_identify_and_pose(st, dev, idw):
         assert torch.equal(idx2, idx) and torch.equal(val2, val) and torch.equal(c2w2.cpu(), c2w)
 
 
+def test_resident_rays_encoder_cache(st, dev, idw):
+    """the encoder cached per resident ray set (PosePipeline.make_resident / identify_resident), the warm
+    batched path of the reference's eval loop (pose_estimation/test.py:67-91 with identification_module.py:164 hoisted out of
+    it) -- compared per image with the ORACLE's test_image + pose, at the config's full size, over two successive batches
+    served from one cache."""
+    from oracle import identify as oid, pose as opose
+    pipe = st.pipe
+    o, d, c = st.ori.cpu(), st.dirs.cpu(), st.rgb.cpu()
+    rays = pipe.make_resident(st.ori, st.dirs, st.rgb)
+    rf = oid.ray_encode(idw, o, d, c)                        # the oracle may hoist it too: identical per image
+    n_swapped = 0
+    for batch in range(2):
+        Q, M = (3, 256) if batch == 0 else (2, 137)
+        tok = torch.stack([synthetic.make_tokens(M, 384, seed=900 + 10 * batch + q) for q in range(Q)])
+        c2w, idx, val = pipe.identify_resident(tok.to(dev), rays, k=100)
+        for q in range(Q):
+            score_ref = oid.attention_map(idw, tok[q], rf).sum(0)
+            n_swapped += int(util.assert_topk_matches(idx[q].cpu(), score_ref, 100, rel_tie=TIE_REL) > 0)
+            top = torch.topk(score_ref, 100)
+            torch.testing.assert_close(val[q].cpu(), top.values, atol=1e-7, rtol=5e-4)
+            want = opose.pose_from_topk(top.indices, top.values, o, d, torch.tensor(st.up))
+            assert float((c2w[q].cpu()[:3, 3] - want[:3, 3]).abs().max()) <= 2e-5
+            assert _rotation_angle(c2w[q, :3, :3].cpu(), want[:3, :3]) <= TOL_POSE_RAD
+            # and the cached path IS the uncached one: same bits as a per-image call that re-runs the encoder
+            c1, i1, v1 = pipe.identify(tok[q].to(dev), st.ori, st.dirs, st.rgb, k=100, materialize_map=False)
+            assert torch.equal(i1, idx[q]) and torch.equal(v1, val[q]) and torch.equal(c1, c2w[q])
+    record(st.name, "resident_cache_lists_with_a_near_tie_swap_of_5", n_swapped)
+    assert n_swapped <= 1
+
+
 def test_batch_of_64_queries_sharded_over_emulated_ranks(dev, idw):
     """BASELINE configs[3]: 64 query images against one emitted ray set whose surface points are sharded over the ranks
     (PosePipeline.query_sharded's three segments; the two all_gathers are emulated by stacking the per-rank messages, which is
