@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
 _lib = None
-ABI_VERSION = 5          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 6          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -93,6 +93,8 @@ SIGNATURES = {
     "iff_ray_logits_folded_batched_workspace": (_SZ, [_VP, _I32, _I64, _I32]),
     "iff_ray_logits_folded_batched": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_ray_logits_folded_timed": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, c_float_p, _VP]),
+    "iff_token_assemble": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _F, c_float_p, c_float_p, _VP, _VP, _VP]),
+    "iff_mask_token_rows": (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
     "iff_ray_cache_bytes": (_SZ, [_VP, _I64]),
     "iff_ray_cache_workspace": (_SZ, [_VP, _I64]),
     "iff_ray_cache_build": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _SZ, _VP, _SZ, _VP]),

@@ -633,6 +633,25 @@ extern "C" int iff_ray_logits_folded_timed(const iff_idnet* n, int32_t B, const 
                              workspace_bytes, trunk_ms_host, stream);
 }
 
+// ---- image side of stage C
+extern "C" int iff_token_assemble(const float* patch_tokens, int32_t Q, int32_t gh, int32_t gw, int32_t C, const float* mask_grid_opt,
+                                  float mask_thres, const float* lin_h_host, const float* lin_w_host, float* tokens_out,
+                                  uint8_t* keep_out, void* stream) {
+    IFF_REQUIRE(Q >= 0 && gh >= 1 && gh <= 32 && gw >= 1 && gw <= 32 && C >= 1, "iff_token_assemble: bad shape Q=%d grid=%dx%d C=%d", Q, gh, gw, C);
+    if (Q == 0) return 0;
+    IFF_REQUIRE(patch_tokens && lin_h_host && lin_w_host && tokens_out && keep_out, "iff_token_assemble: null buffer");
+    IFF_HIP(launch_token_assemble(patch_tokens, Q, gh, gw, C, mask_grid_opt, mask_thres, lin_h_host, lin_w_host, tokens_out, keep_out,
+                                  (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_mask_token_rows(const uint8_t* keep, int64_t rows, float* row_max, float* row_sumexp, void* stream) {
+    IFF_REQUIRE(rows >= 0, "iff_mask_token_rows: bad argument");
+    if (rows == 0) return 0;
+    IFF_REQUIRE(keep && row_max && row_sumexp, "iff_mask_token_rows: null buffer");
+    IFF_HIP(launch_mask_token_rows(keep, rows, row_max, row_sumexp, (hipStream_t)stream));
+    return 0;
+}
+
 // ---- per-model encoder cache
 static size_t up256a(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t iff_ray_cache_bytes(const iff_idnet* n, int64_t N) {

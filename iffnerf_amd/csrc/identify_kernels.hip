@@ -1255,3 +1255,55 @@ hipError_t launch_topk(const float* score, int Q, int64_t N, int k, int64_t* idx
     hipLaunchKernelGGL(k7_topk, dim3((unsigned)Q), dim3(TK_THREADS), 0, s, score, N, k, idx, val);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------ image-token assembly
+// IdentificationModule.image_processing after the backbone (identification_module.py:149-160): every patch token gets the
+// 14-channel position code of get_img_position_encoding (:76-99) appended -- [pos_i, pos_j, sin(pos_i {1,2,4}), sin(pos_j
+// {1,2,4}), cos(...)], pos = torch.linspace(-1, 1, g) per axis, 'ij' indexing (the two linspace tables come from the host
+// so that their bits are torch's) -- and the boolean row selection `[mask > 0.1]` (:157-160) becomes a keep flag per token:
+// the rows stay in place (static shapes, no host sync) and k_mask_token_rows later removes the dropped rows' contribution
+// from the column sums exactly (exp(l - inf) = 0), which is what deleting the rows does.
+struct LinTab { float h[32], w[32]; };
+__global__ void k_token_assemble(const float* __restrict__ tok, int Q, int gh, int gw, int C, const float* __restrict__ mask,
+                                 float thres, LinTab lt, float* __restrict__ out, uint8_t* __restrict__ keep) {
+    const int G = gh * gw, CO = C + 14;
+    const int64_t n = (int64_t)Q * G * CO;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(t % CO);
+        const int64_t row = t / CO;                  // q * G + cell
+        const int cell = (int)(row % G), i = cell / gw, j = cell - i * gw;
+        float v;
+        if (col < C) v = tok[row * C + col];
+        else {
+            const int c = col - C;
+            const float pi = lt.h[i], pj = lt.w[j];
+            if (c < 2) v = c == 0 ? pi : pj;
+            else {
+                const int u = (c - 2) % 6;                              // (axis, octave) = (u / 3, u % 3)
+                const float ang = (u < 3 ? pi : pj) * (float)(1 << (u % 3));
+                v = (c - 2) < 6 ? sinf(ang) : cosf(ang);
+            }
+        }
+        out[t] = v;
+        if (col == 0) keep[row] = (!mask || mask[row] > thres) ? 1 : 0;
+    }
+}
+hipError_t launch_token_assemble(const float* tok, int Q, int gh, int gw, int C, const float* mask, float thres, const float* lin_h,
+                                 const float* lin_w, float* out, uint8_t* keep, hipStream_t s) {
+    LinTab lt;
+    for (int i = 0; i < 32; ++i) { lt.h[i] = i < gh ? lin_h[i] : 0.0f; lt.w[i] = i < gw ? lin_w[i] : 0.0f; }
+    const int64_t n = (int64_t)Q * gh * gw * (C + 14);
+    int64_t grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_token_assemble, dim3((unsigned)grid), dim3(256), 0, s, tok, Q, gh, gw, C, mask, thres, lt, out, keep);
+    return hipGetLastError();
+}
+
+__global__ void k_mask_token_rows(const uint8_t* __restrict__ keep, int64_t rows, float* __restrict__ row_max, float* __restrict__ row_sumexp) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < rows && !keep[i]) { row_max[i] = INFINITY; row_sumexp[i] = 1.0f; }
+}
+hipError_t launch_mask_token_rows(const uint8_t* keep, int64_t rows, float* row_max, float* row_sumexp, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_token_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, keep, rows, row_max, row_sumexp);
+    return hipGetLastError();
+}

@@ -1,0 +1,85 @@
+"""Image side of stage C: query images -> token tensors, without a host round trip.
+
+The reference's ``IdentificationModule.image_processing`` (pose_estimation/identification_module.py:130-160) resizes and
+crops the image and its alpha mask, runs DINOv2 ViT-S/14, appends a 14-channel position code and selects the tokens whose
+mask value exceeds 0.1 with a boolean index (a device->host sync per image, and a token count that changes per image).
+Here the same steps run as one static-shape sequence that a hipGraph can hold together with stage C:
+
+  preprocessing + backbone   stock PyTorch-ROCm ops (the backbone is third-party and stays a torch module; offline it is the
+                             seeded stand-in of pose_estimation/backbone.py)
+  token assembly             ``iff_token_assemble``: position code appended in one kernel, mask select -> keep flags
+  mask select                ``iff_mask_token_rows`` on the softmax row statistics: dropped rows contribute exactly 0
+
+``PosePipeline.identify_images_resident`` chains this with the cached-encoder logits, column sums, top-k and pose solve, so a
+batch of query images goes image-in -> pose-out in one captured graph (``CapturedImageQuery``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, fvec, stream_ptr
+from .pose_estimation.identification_module import IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, _center_crop, _resize_short_edge
+
+
+def token_assemble(patch_tokens: torch.Tensor, grid, mask_grid: Optional[torch.Tensor] = None, mask_thres: float = 0.1):
+    """patch_tokens [Q, gh*gw, C] (+ mask_grid [Q, gh*gw]) -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw] uint8)."""
+    gh, gw = int(grid[0]), int(grid[1])
+    if not patch_tokens.is_cuda:
+        raise RuntimeError("patch tokens must live on the GPU; libiffnerf_hip has no CPU path")
+    t = patch_tokens.detach().to(torch.float32).contiguous()
+    Q, G, Cc = t.shape
+    if G != gh * gw:
+        raise RuntimeError(f"patch tokens have {G} rows, the grid {gh}x{gw} has {gh * gw}")
+    m = None
+    if mask_grid is not None:
+        m = mask_grid.detach().to(device=t.device, dtype=torch.float32).reshape(Q, G).contiguous()
+    out = t.new_empty(Q, G, Cc + 14)
+    keep = torch.empty(Q, G, dtype=torch.uint8, device=t.device)
+    lin_h = fvec(torch.linspace(-1.0, 1.0, steps=gh, dtype=torch.float32).tolist())
+    lin_w = fvec(torch.linspace(-1.0, 1.0, steps=gw, dtype=torch.float32).tolist())
+    with torch.cuda.device(t.device):
+        check(_lib.lib().iff_token_assemble(dptr(t), Q, gh, gw, Cc, dptr(m), float(mask_thres), lin_h, lin_w, dptr(out),
+                                            keep.data_ptr(), stream_ptr(t.device)), "iff_token_assemble")
+    return out, keep
+
+
+def mask_token_rows(keep: torch.Tensor, row_max: torch.Tensor, row_sumexp: torch.Tensor) -> None:
+    """In place: statistics of the rows with keep == 0 become (+inf, 1), so they add 0 to every column sum."""
+    k = keep.reshape(-1)
+    if k.numel() != row_max.numel() or k.numel() != row_sumexp.numel():
+        raise RuntimeError("one keep flag per statistics row expected")
+    with torch.cuda.device(row_max.device):
+        check(_lib.lib().iff_mask_token_rows(k.data_ptr(), k.numel(), dptr(row_max), dptr(row_sumexp), stream_ptr(row_max.device)),
+              "iff_mask_token_rows")
+
+
+class ImageFrontEnd:
+    """Resize / crop / normalise + backbone + token assembly for a batch of query images, all on the device."""
+
+    def __init__(self, backbone: torch.nn.Module, grid=(16, 16), resize_size: int = 256, crop_size: int = 224):
+        self.backbone, self.grid, self.resize_size, self.crop_size = backbone, (int(grid[0]), int(grid[1])), resize_size, crop_size
+        self._norm = {}      # device -> (mean, std): made once, outside any capture (a host->device copy cannot be captured)
+
+    def _mean_std(self, x):
+        key = (x.device, x.dtype)
+        if key not in self._norm:
+            self._norm[key] = (torch.tensor(IMAGENET_DEFAULT_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1),
+                               torch.tensor(IMAGENET_DEFAULT_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1))
+        return self._norm[key]
+
+    @torch.no_grad()
+    def tokens(self, imgs: torch.Tensor, masks: Optional[torch.Tensor] = None):
+        """imgs [Q,H,W,3] in [0,1], masks [Q,H,W] (alpha) -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw]).
+        The same arithmetic as identification_module.py:130-160 (``transformations`` / ``mask_transformations`` of the mirror)."""
+        x = _center_crop(_resize_short_edge(imgs.permute(0, 3, 1, 2), self.resize_size, "bicubic"), self.crop_size)
+        mean, std = self._mean_std(x)
+        feats = self.backbone.forward_features((x - mean) / std)["x_norm_patchtokens"]
+        mg = None
+        if masks is not None:
+            m = _center_crop(_resize_short_edge(masks[:, None] * 1.0, self.resize_size, "bilinear"), self.crop_size)
+            mg = _resize_short_edge(m, self.grid[0], "bilinear").reshape(masks.shape[0], -1)
+        return token_assemble(feats, self.grid, mg, 0.1)

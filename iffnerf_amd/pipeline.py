@@ -131,6 +131,20 @@ class PosePipeline:
         idx, val = H.topk_batched(score, k)
         return H.pose_from_topk_batched(idx, val, rays.ori, rays.dirs, self.model_up), idx, val
 
+    def identify_images_resident(self, frontend, imgs, masks, rays: "ResidentRays", k: int = 100):
+        """Image in -> pose out against resident rays: imgs [Q,H,W,3], masks [Q,H,W] -> (c2w [Q,4,4], idx, val).  Static shapes
+        throughout (the mask select is applied to the softmax rows, image_frontend.py), so the whole call captures as ONE
+        hipGraph (CapturedImageQuery).  Equals ``IdentificationModule.test_image`` + the pose solve per image."""
+        from .image_frontend import mask_token_rows
+        tokens, keep = frontend.tokens(imgs, masks)
+        Q, M, C = tokens.shape
+        qf = self.idnet.q_fold(tokens.reshape(Q * M, C))
+        logits, rmax, rsum = self.idnet.logits_from_cache(qf, rays.cache, rays.ori.shape[0])
+        mask_token_rows(keep, rmax, rsum)
+        score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
+        idx, val = H.topk_batched(score, k)
+        return H.pose_from_topk_batched(idx, val, rays.ori, rays.dirs, self.model_up), idx, val
+
     def query(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None, materialize_map: bool = False):
         """Cold per-query path: emission + identification + pose -> (c2w, top-k idx, top-k val).  The attention map is not
         part of the result, so by default it is not written back (scores come straight from logits + row statistics)."""
@@ -490,3 +504,31 @@ class CapturedShardedBatch:
         D.all_gather_into(self.cand_all, self.cand, self.group)
         self.g4.replay()
         return self.poses
+
+
+class CapturedImageQuery:
+    """``PosePipeline.identify_images_resident`` as one hipGraph: a batch of query images in, poses out.  Static buffers:
+    ``imgs`` [Q,H,W,3], ``masks`` [Q,H,W] in; ``c2w`` [Q,4,4], ``idx`` / ``val`` [Q,k] out."""
+
+    def __init__(self, pipe: PosePipeline, frontend, imgs_shape, rays: ResidentRays, k: int = 100):
+        dev = pipe.device
+        self.imgs = torch.zeros(imgs_shape, dtype=torch.float32, device=dev)
+        self.masks = torch.ones(imgs_shape[:3], dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                 # warm-up outside capture (library handles, autotuning, allocator)
+            for _ in range(3):
+                pipe.identify_images_resident(frontend, self.imgs, self.masks, rays, k)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.c2w, self.idx, self.val = pipe.identify_images_resident(frontend, self.imgs, self.masks, rays, k)
+
+    def replay(self, imgs: Optional[torch.Tensor] = None, masks: Optional[torch.Tensor] = None):
+        if imgs is not None:
+            self.imgs.copy_(imgs, non_blocking=True)
+        if masks is not None:
+            self.masks.copy_(masks, non_blocking=True)
+        self.graph.replay()
+        return self.c2w

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 5
+#define IFF_ABI_VERSION 6
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -280,6 +280,22 @@ int iff_ray_logits_folded_timed(const iff_idnet* net, int32_t B, const float* o,
                                 const float* qf, int32_t M, float divisor, float* logits, float* row_max,
                                 float* row_sumexp, void* workspace, size_t workspace_bytes, float* trunk_ms_host,
                                 void* stream);
+
+/* Image tokens for stage C: what IdentificationModule.image_processing does after the backbone
+ * (pose_estimation/identification_module.py:149-160) -- append the 14-channel position code of get_img_position_encoding
+ * (:76-99: grid position in [-1,1]^2, 'ij' indexing, then sin / cos of it at octaves 1, 2, 4) to every patch token, and turn
+ * the row selection `[mask > mask_thres]` (:157-160, mask = the resized alpha channel) into one keep flag per token.
+ *   patch_tokens [Q, gh*gw, C] (backbone output, row-major over the grid), mask_grid_opt [Q, gh*gw] or NULL (keep all),
+ *   lin_h_host / lin_w_host: torch.linspace(-1, 1, gh / gw) as host floats -> tokens_out [Q, gh*gw, C+14], keep_out [Q, gh*gw].
+ * Rows are NOT compacted (shapes stay static, nothing is read back to the host): run the logits on all gh*gw rows, then
+ * iff_mask_token_rows on the row statistics before iff_attn_colsum -- a dropped row then contributes exp(l - inf) / 1 = 0 to
+ * every column sum, which is exactly what deleting it (identification_module.py:157-160 before :167) does. */
+int iff_token_assemble(const float* patch_tokens, int32_t Q, int32_t gh, int32_t gw, int32_t C, const float* mask_grid_opt,
+                       float mask_thres, const float* lin_h_host, const float* lin_w_host, float* tokens_out, uint8_t* keep_out,
+                       void* stream);
+/* keep [rows] (iff_token_assemble), statistics [rows]: rows with keep == 0 get (row_max, row_sumexp) = (+inf, 1)
+ * (the mask select of pose_estimation/identification_module.py:157-160 applied to the softmax rows of :165-167) */
+int iff_mask_token_rows(const uint8_t* keep, int64_t rows, float* row_max, float* row_sumexp, void* stream);
 
 /* The encoder cached per resident ray set.  The reference re-runs RayPreprocessor + k_proj for every query image
  * (pose_estimation/identification_module.py:164 inside the loop of pose_estimation/test.py:67-91) although the rays of a model

@@ -1,0 +1,133 @@
+"""GPU: the image side of stage C: token assembly kernel, mask select on the softmax rows, and the
+image-in -> pose-out capture, against the oracle's / the mirrored module's compacting formulation."""
+import pytest
+import torch
+
+from iffnerf_amd import synthetic
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _keep_pattern(q, g=16):
+    gen = torch.Generator().manual_seed(100 + q)
+    yy, xx = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
+    cy, cx, r = 4 + 2 * q, 9 - q, 5.5 + 0.5 * q
+    blob = ((yy - cy) ** 2 + (xx - cx) ** 2) <= r * r
+    return blob | (torch.rand(g, g, generator=gen) > 0.93)
+
+
+def test_token_assemble_matches_get_img_position_encoding(dev):
+    from iffnerf_amd.image_frontend import token_assemble
+    from oracle import identify as oid
+    gen = torch.Generator().manual_seed(4)
+    patch = torch.randn(3, 256, 384, generator=gen)
+    keep = torch.stack([_keep_pattern(q) for q in range(3)])
+    mask_grid = torch.where(keep, torch.rand(3, 16, 16, generator=gen) * 0.8 + 0.15, torch.rand(3, 16, 16, generator=gen) * 0.09)
+    out, flags = token_assemble(patch.to(dev), (16, 16), mask_grid.to(dev), 0.1)
+    assert out.shape == (3, 256, 398) and torch.equal(flags.cpu().bool(), keep.reshape(3, 256))
+    assert torch.equal(out[..., :384].cpu(), patch)
+    for q in range(3):
+        want = oid.tokens_with_pe(patch[q], keep[q])                    # identification_module.py:149-160, compacting
+        got = out[q].cpu()[keep[q].reshape(-1)]
+        assert got.shape == want.shape
+        assert torch.equal(got[:, :386], want[:, :386])                 # features and the two raw positions: exact
+        torch.testing.assert_close(got[:, 386:], want[:, 386:], atol=1e-6, rtol=0)      # sin / cos: libm
+    # no mask: every row kept; a non-square grid follows 'ij' indexing
+    out2, flags2 = token_assemble(patch[:1, :12 * 20].contiguous().to(dev), (12, 20))
+    assert bool(flags2.all()) and out2.shape == (1, 240, 398)
+    pe = oid.image_position_encoding((12, 20), 3).reshape(240, 14)
+    torch.testing.assert_close(out2[0, :, 384:].cpu(), pe, atol=1e-6, rtol=0)
+    with pytest.raises(RuntimeError):
+        token_assemble(patch, (16, 16))                                 # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        token_assemble(patch.to(dev), (16, 15))
+
+
+def test_mask_select_on_the_softmax_rows_equals_dropping_the_rows(dev):
+    """All 256 rows through the logits, dropped rows' statistics set to (+inf, 1): the scores are those of the compacted
+    token tensor (what identification_module.py:157-160 hands to :165-167), and so are the top-100 and the pose."""
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.image_frontend import mask_token_rows, token_assemble
+    from iffnerf_amd.pipeline import PosePipeline
+    from oracle import identify as oid
+    w = synthetic.make_id_weights(seed=99)
+    pipe = PosePipeline.from_checkpoints(util.ckpt("small"), w, dev, model_up=(0.1, 0.2, 0.9))
+    ori, dirs, rgb = pipe.emit(75, seed=3)
+    rays = pipe.make_resident(ori, dirs, rgb)
+    gen = torch.Generator().manual_seed(8)
+    patch = torch.randn(2, 256, 384, generator=gen)
+    keep = torch.stack([_keep_pattern(q) for q in range(2)])
+    tokens, flags = token_assemble(patch.to(dev), (16, 16), keep.float().to(dev), 0.1)
+    qf = pipe.idnet.q_fold(tokens.reshape(512, 398))
+    logits, rmax, rsum = pipe.idnet.logits_from_cache(qf, rays.cache, ori.shape[0])
+    mask_token_rows(flags, rmax, rsum)
+    score = H.attn_colsum_batched(logits, rmax, rsum, 2, write_attention=False)
+    for q in range(2):
+        compact = tokens[q][flags[q].bool()].contiguous()
+        M = compact.shape[0]
+        assert 60 < M < 256
+        want, _ = pipe.scores(compact, ori, dirs, rgb, materialize_map=False)
+        torch.testing.assert_close(score[q], want, atol=0, rtol=2e-6)
+        assert abs(float(score[q].sum()) - M) < 1e-2
+        idx, val = H.topk(score[q], 100)
+        assert idx.tolist() == H.topk(want, 100)[0].tolist()
+        score_ref = oid.test_image(w, compact.cpu(), ori.cpu(), dirs.cpu(), rgb.cpu(), 100)[2]
+        util.assert_topk_matches(idx.cpu(), score_ref, 100)
+
+
+def test_image_in_pose_out_capture(dev, monkeypatch):
+    """ImageFrontEnd reproduces the mirrored module's image_processing (same torch ops + the assembly kernel), and the
+    captured image -> pose graph equals the per-image drop-in calls (IdentificationModule.test_image + pose solve)."""
+    import iffnerf_amd
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.image_frontend import ImageFrontEnd
+    from iffnerf_amd.pipeline import CapturedImageQuery, PosePipeline
+    from iffnerf_amd.pose_estimation import backbone as bb, identification_module as im
+    net, grid, C = bb.create_standin_backbone(seed=5)
+    net = net.to(dev)
+    monkeypatch.setattr(im, "create_backbone", lambda **kw: (net, grid, C))
+    mod = im.IdentificationModule("dino").to(dev).eval()
+    w = synthetic.make_id_weights(seed=99)
+    mod.load_state_dict({k: v for k, v in w.items()}, strict=False)
+    pipe = PosePipeline.from_checkpoints(util.ckpt("small"), w, dev, model_up=(0.1, 0.2, 0.9))
+    ori, dirs, rgb = pipe.emit(75, seed=3)
+    rays = pipe.make_resident(ori, dirs, rgb)
+    fe = ImageFrontEnd(net, grid)
+    gen = torch.Generator().manual_seed(2)
+    Q, Hh, Ww = 3, 200, 260
+    imgs = torch.rand(Q, Hh, Ww, 3, generator=gen).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(Hh), torch.arange(Ww), indexing="ij")
+    masks = torch.stack([(((yy - 100) ** 2 / (60 + 10 * q) ** 2 + (xx - 130) ** 2 / (90 - 10 * q) ** 2) <= 1).float() for q in range(Q)]).to(dev)
+    tokens, keep = fe.tokens(imgs, masks)
+    c2w, idx, val = pipe.identify_images_resident(fe, imgs, masks, rays, 100)
+    for q in range(Q):
+        # one image at a time: the very ops of the mirrored module, so the tokens agree to the PE's libm difference ...
+        t_pe, t = mod.image_processing(imgs[q], masks[q])
+        tok1, keep1 = fe.tokens(imgs[q:q + 1], masks[q:q + 1])
+        got = tok1[0][keep1[0].bool()]
+        assert got.shape == t_pe.shape and 30 < got.shape[0] < 256
+        assert torch.equal(got[:, :386], t_pe[:, :386])
+        torch.testing.assert_close(got[:, 386:], t_pe[:, 386:], atol=1e-6, rtol=0)
+        # ... and image -> pose equals IdentificationModule.test_image + the pose solve
+        c1, i1, v1 = pipe.identify_images_resident(fe, imgs[q:q + 1], masks[q:q + 1], rays, 100)
+        i2, v2, _, _ = mod.test_image(imgs[q], masks[q], ori, dirs, rgb, rays_to_output=100)
+        assert len(set(i1[0].tolist()) & set(i2.tolist())) >= 98               # PE libm + row-sum order: near-ties may swap
+        torch.testing.assert_close(v1[0], v2, atol=1e-6, rtol=1e-3)
+        torch.testing.assert_close(c1[0], H.pose_from_topk(i2, v2, ori, dirs, pipe.model_up), atol=1e-4, rtol=0)
+        # the batched front end runs the backbone's GEMMs at another batch size: same tokens to GEMM rounding, same answer
+        assert torch.equal(keep[q], keep1[0])
+        torch.testing.assert_close(tokens[q], tok1[0], atol=5e-4, rtol=0)
+        assert len(set(idx[q].tolist()) & set(i1[0].tolist())) >= 90
+        torch.testing.assert_close(c2w[q], c1[0], atol=5e-3, rtol=0)
+    cq = CapturedImageQuery(pipe, fe, imgs.shape, rays, 100)
+    for rep in range(2):
+        cq.replay(imgs, masks)
+        torch.cuda.synchronize()
+        assert torch.equal(cq.idx, idx) and torch.equal(cq.val, val) and torch.equal(cq.c2w, c2w)
