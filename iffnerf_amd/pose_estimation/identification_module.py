@@ -5,7 +5,10 @@ libiffnerf_hip (fp32 MFMA).  The image side up to the token tensor (resize / cro
 PyTorch-ROCm module: it is outside the accelerated path.
 ``state_dict`` keys equal the reference's (``norm_mean``, ``norm_std``, ``image_preprocessing_net.*``,
 ``ray_preprocessor.mlp*.{0,2}.*``, ``attention.{q,k}_proj.*``), so ``id_module.th`` loads unchanged.
-Inference only: calling the module with parameters that require grad under grad mode raises RuntimeError.
+Grad mode: under ``torch.no_grad`` / with frozen parameters (the whole north-star path) stage C
+runs in libiffnerf_hip; when autograd has to flow -- ``pose_estimation/train.py:97-119`` calls the module with trainable
+parameters -- the ray encoder and the attention evaluate the same formulas in differentiable PyTorch-ROCm ops on the GPU
+(ray_preprocessor.py / multihead_attention.py of this package), so ``train_id_module`` back-propagates unchanged.
 """
 from __future__ import annotations
 
@@ -109,17 +112,20 @@ class IdentificationModule(torch.nn.Module):
             self._net = IdNetHandle(w, dev)
         return self._net
 
-    def _inference_only(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in list(self.ray_preprocessor.parameters()) +
-                                           list(self.attention.parameters())):
-            raise RuntimeError("IdentificationModule: the MI355X path is inference-only (training the identification "
-                               "module, pose_estimation/train.py, is out of scope); call under torch.no_grad() / eval")
+    def _training_graph(self, *tensors) -> bool:
+        """Autograd has to flow through stage C (trainable parameters under grad mode): use the differentiable formulation."""
+        from .ray_preprocessor import needs_autograd
+        return needs_autograd(self.ray_preprocessor, *tensors) or needs_autograd(self.attention, *tensors)
 
     # ------------------------------------------------------------------ stage C
     def attention_from_tokens(self, features_img_w_pe_flat, rays_ori, rays_dir, rays_rgb, materialize_map=True):
         """Token boundary -> (score [N], attention map [M,N] or None).  The ray encoder + k_proj are recomputed per
         call, exactly as the reference does per image (identification_module.py:164)."""
         from .. import hip_identify as H
+        if self._training_graph(features_img_w_pe_flat, rays_ori, rays_dir, rays_rgb):
+            # identification_module.py:164-167 in differentiable torch ops (the modules dispatch the same way themselves)
+            attention_map = self.attention(features_img_w_pe_flat, self.ray_preprocessor(rays_ori, rays_dir, rays_rgb))
+            return attention_map.sum(0), attention_map
         net = self._idnet()
         if getattr(self, "fold_heads", True):
             # mlp2.2, k_proj and q_proj folded into one token-side Linear; encoder + logits in one launch
@@ -132,7 +138,6 @@ class IdentificationModule(torch.nn.Module):
         return score, (logits if materialize_map else None)
 
     def run_attention(self, img, mask, rays_ori, rays_dir, rays_rgb):
-        self._inference_only()
         tokens_pe, tokens = self.image_processing(img, mask)
         score, attention_map = self.attention_from_tokens(tokens_pe, rays_ori, rays_dir, rays_rgb)
         return score, attention_map, tokens

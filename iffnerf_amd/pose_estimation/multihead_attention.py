@@ -4,6 +4,9 @@
 (multihead_attention.py:31-54).  ``forward`` (reference :56-66) = ``iff_q_proj`` + ``iff_k_proj`` + ``iff_attn_logits`` +
 ``iff_attn_colsum`` and returns the attention map; the column-sum score computed on the way is kept on the module as
 ``last_score`` so ``IdentificationModule.run_attention`` does not reduce the map a second time.
+
+Grad mode: as in ray_preprocessor.py -- when autograd has to flow (``pose_estimation/train.py``) the same
+formula runs in differentiable PyTorch-ROCm ops on the GPU; inference never takes that branch.
 """
 from __future__ import annotations
 
@@ -38,8 +41,14 @@ class MultiHeadAttention(torch.nn.Module):
 
     def forward(self, img_features, ray_features, mask=None):
         from .. import hip_identify as H
+        from .ray_preprocessor import needs_autograd
         if mask is not None:
             raise RuntimeError("MultiHeadAttention.forward: masks are not on the IFFNeRF path")
+        if needs_autograd(self, img_features, ray_features):
+            q, k = self.q_proj(img_features), self.k_proj(ray_features)                 # multihead_attention.py:60-61
+            att = torch.softmax(torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(q.size()[-1]), dim=-1)    # :4-12
+            self.last_score = att.sum(0)
+            return att
         if self._owner is None:
             raise RuntimeError("MultiHeadAttention.forward runs through its IdentificationModule's kernel handle")
         net = self._owner()._idnet()
