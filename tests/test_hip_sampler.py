@@ -62,31 +62,96 @@ def test_invariants_and_determinism(small, dev):
     assert not torch.equal(s4, s5)
 
 
-def test_distribution_matches_oracle(small, dev):
+def _ks(a: torch.Tensor, b: torch.Tensor) -> float:
+    """Two-sample Kolmogorov-Smirnov statistic sup |F_a - F_b|."""
+    a, b = torch.sort(a.double().flatten()).values, torch.sort(b.double().flatten()).values
+    allv = torch.cat((a, b))
+    fa = torch.searchsorted(a, allv, right=True).double() / a.numel()
+    fb = torch.searchsorted(b, allv, right=True).double() / b.numel()
+    return float((fa - fb).abs().max())
+
+
+@pytest.mark.parametrize("model", ["small", "small_sharp"])
+def test_distribution_matches_oracle(model, dev):
+    """Epoch by epoch, CONDITIONALLY: whole runs are not i.i.d. samples (all P points of a run share the epoch thresholds, which
+    are quantiles of that run's own random alphas -- two oracle runs with different seeds already differ by KS 0.05-0.1), so
+    the device sampler and the oracle are compared one epoch at a time from the SAME state.  The device run with
+    n_epochs = e gives the state after e epochs (its first e epochs do not depend on how many follow); from it, epoch e + 1 is
+    taken once by the device (n_epochs = e + 1) and once by the oracle's sampling_epoch (torch CPU generator, the reference's
+    op chain, sampling.py:143-213).  Given the state the P samples move independently, so the two-sample Kolmogorov-Smirnov
+    statistic applies: every feature of the moved samples -- displacement, distance from the blob's centre, coordinates,
+    density -- must stay below the 1e-4 critical value for 3000 vs 3000 points, 2.23 sqrt(2 / 3000) = 0.058, in all four
+    epochs on both models, and the epochs' iteration counts must agree to within one."""
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
     from oracle import emit as oemit, field as ofield
-    ck = util.ckpt("small")
+    ck = util.ckpt("small") if model == "small" else util.ckpt("small", seed=33, peak=26.0, blob_sigma=0.36)
     f = ofield.field_from_ckpt(ck)
-    P = 3000
-    torch.manual_seed(7)
-    so, ao, stats = oemit.surface_samples(f, P, 4, 200, return_stats=True)
-    sh, ah, st = small.surface_sample(P, rho_of(ck), n_epochs=4, max_iterations=200, seed=99)
-    sh, ah = sh.cpu(), ah.cpu()
+    h = field_handle_from_ckpt(ck, dev)
+    P, rho, seed = 3000, rho_of(ck), 77
     c = (ck["kwargs"]["aabb"][0] + ck["kwargs"]["aabb"][1]) / 2
-    ro, rh = torch.linalg.norm(so - c, dim=-1), torch.linalg.norm(sh - c, dim=-1)
-    # two independent draws of 3000 samples from the same process: compare quantiles of radius and of alpha
-    for qv in (0.1, 0.5, 0.9):
-        a, b = torch.quantile(ro, qv).item(), torch.quantile(rh, qv).item()
-        assert abs(a - b) < 0.05 * max(a, b) + 0.01, ("radius quantile", qv, a, b)
     sig = lambda al: -torch.log1p(-al.double().clamp(max=1 - 1e-12))     # compare in sigma space: alpha saturates near 1
-    for qv in (0.1, 0.5, 0.9):
-        a, b = torch.quantile(sig(ao), qv).item(), torch.quantile(sig(ah), qv).item()
-        assert abs(a - b) < 0.12 * max(a, b) + 0.05, ("sigma quantile", qv, a, b)
-    # per-axis means: the blob is centred, so both should sit near the centre
-    assert torch.allclose(so.mean(0), sh.mean(0), atol=0.03)
-    # iteration counts are of the same order
-    it_o = sum(s[1] for s in stats)
-    it_h = int(st.cpu()[:, 0].sum())
-    assert 0.4 * it_o <= it_h <= 2.5 * it_o + 4, (it_o, it_h)
+    worst = 0.0
+    for e in range(4):
+        s_e, a_e, _ = h.surface_sample(P, rho, n_epochs=e, max_iterations=200, seed=seed)
+        s_h, a_h, st = h.surface_sample(P, rho, n_epochs=e + 1, max_iterations=200, seed=seed)
+        st = st.cpu()
+        assert (st[:, 3] != -1).all() and int(st[e, 1]) == 0
+        s_e, a_e, s_h, a_h = s_e.cpu(), a_e.cpu(), s_h.cpu(), a_h.cpu()
+        torch.manual_seed(100 + e)
+        s_o, a_o, it_o, left_o = oemit.sampling_epoch(f, s_e.clone(), a_e.clone(), rho, max_iterations=200)
+        assert int(left_o) == 0 and abs(int(st[e, 0]) - it_o) <= 1, (e, int(st[e, 0]), it_o)
+        thr = st[e, 2:3].view(torch.float32).item()
+        assert abs(thr - torch.quantile(a_e, q=0.6).item()) <= 1e-6 and bool((a_o > thr).all()) and bool((a_h > thr).all())
+        feats = {"step": lambda s, a: torch.linalg.norm(s - s_e, dim=-1), "radius": lambda s, a: torch.linalg.norm(s - c, dim=-1),
+                 "x": lambda s, a: s[:, 0], "y": lambda s, a: s[:, 1], "z": lambda s, a: s[:, 2], "sigma": lambda s, a: sig(a)}
+        for name, fn in feats.items():
+            d = _ks(fn(s_o, a_o), fn(s_h, a_h))
+            worst = max(worst, d)
+            assert d < 0.058, (model, e, name, d)
+    assert worst > 0.0
+
+
+def _philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al.), the counter-based generator of csrc/sampler_kernels.hip, restated with Python ints."""
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    x, y, z, w = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = M0 * x, M1 * z
+        x, y, z, w = ((p1 >> 32) ^ y ^ k0) & mask, p1 & mask, ((p0 >> 32) ^ w ^ k1) & mask, p0 & mask
+        k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+    return x, y, z, w
+
+
+def test_one_candidate_step_is_the_references_arithmetic(small, dev):
+    """One iteration of one epoch from known seeds: every sample that moved must sit on one of ITS m = 5 jittered candidates
+    as the reference constructs them (pose_estimation/sampling.py:38-66: direction from theta = 2 pi u, phi = arccos(1 - 2 u),
+    radius |N(0, rho)|) from the very uniforms the kernel's counter-based generator yields -- recomputed here in float64
+    from an independent restatement of Philox and of the formulas -- and must beat the epoch's threshold."""
+    import math
+    ck = util.ckpt("small")
+    rho, P, seed = rho_of(ck), 200, 4242
+    s0, a0, _ = small.surface_sample(P, rho, n_epochs=0, seed=seed)
+    s1, a1, st = small.surface_sample(P, rho, n_epochs=1, max_iterations=1, seed=seed)
+    st = st.cpu()
+    assert int(st[0, 0]) == 1 and int(st[0, 3]) == 5               # one iteration, m = 5P // P candidates per sample
+    thresh = st[0, 2:3].view(torch.float32).item()
+    s0c, s1c, a1c = s0.cpu().double(), s1.cpu().double(), a1.cpu()
+    moved = (s1c != s0c).any(-1)
+    assert 0.2 * P < int(moved.sum()) <= P and int(st[0, 1]) == P - int(moved.sum())
+    u01 = lambda v: (v >> 8) / 16777216.0
+    for i in torch.nonzero(moved).flatten().tolist():
+        best = float("inf")
+        for j in range(5):
+            r = _philox4x32_10((i, j, 0 * 4096 + 0, 0xA5), (seed & 0xFFFFFFFF, seed >> 32))
+            theta, phi = 2 * math.pi * u01(r[0]), math.acos(1 - 2 * u01(r[1]))
+            g = math.sqrt(-2 * math.log(1 - u01(r[2]))) * math.cos(2 * math.pi * u01(r[3]))        # Box-Muller normal
+            d = torch.tensor([math.sin(phi) * math.cos(theta), math.sin(phi) * math.sin(theta), math.cos(phi)], dtype=torch.float64)
+            cand = s0c[i] + d * abs(g * rho)
+            best = min(best, float((cand - s1c[i]).abs().max()))
+        assert best < 5e-6, (i, best)
+        assert float(a1c[i]) > thresh
+    assert torch.equal(s1[~moved.to(dev)], s0[~moved.to(dev)])
 
 
 def test_small_and_degenerate(small, dev):
