@@ -111,7 +111,7 @@ class IdNetHandle:
 
     def trunk_kernel_name(self) -> str:
         """Name of the fused encoder + logits kernel as rocprofv3 prints it (profiles/*.csv)."""
-        return {GEMM_F16X2: "k5_trunk_h<true>"}.get(self.gemm_mode, "k5_trunk<true, 1>")
+        return {GEMM_F16X2: "k5_trunk_h<1, 1, 2>"}.get(self.gemm_mode, "k5_trunk<true, 1>")
 
     # ------------------------------------------------------------------ K5
     def ray_encode(self, o, d, rgb, want_features: bool = True, want_k: bool = False):

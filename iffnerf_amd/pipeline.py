@@ -396,6 +396,7 @@ class CapturedShardedQuery:
         self.cand_all = self.cand.new_zeros((self.ws,) + tuple(self.cand.shape))
         with torch.cuda.graph(self.g3, **opts):
             self.poses, self.val, self.idx = pipe.shard_global_poses(self.cand_all, k)
+        self.c2w = self.poses
 
     def _gather(self, out, src):
         from . import distributed as D
