@@ -156,27 +156,48 @@ struct ShadeArgs {
     int64_t n;
     float* rgb;
 };
+// The packed head (~5.3 k floats, 21 KB) is copied to LDS once per workgroup and every weight is read from there: with the
+// weights in global memory a wave issued ~130 vector loads per 4 rays, and the CU's vector-memory pipeline spends ~16 cycles
+// on a wave-level load whatever its width -- that, not arithmetic, was this kernel's time (profiles/README.md).  Workgroups
+// loop over 16-ray tiles; the LDS pointer is made opaque per tile so that LLVM does not hoist the (loop-invariant) weight
+// reads out of the loop into 300+ registers.
 template <int APP, bool BLEND>
-__global__ void __launch_bounds__(256) k_ref_shade(FieldDev f, ShadeArgs a) {
+__global__ void __launch_bounds__(256) k_ref_shade(FieldDev f, ShadeArgs a, int64_t n_tiles) {
+    extern __shared__ __align__(16) float s_head[];
     const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
-    // No grid-stride loop on purpose: inside one, the ~5 k head weights are loop-invariant and LLVM hoists their loads out
-    // of the loop (300+ live registers, one wave per SIMD).  One (ray, lane) item per thread, exact grid.
-    int64_t nt = a.n * 16;
-    {
-        int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-        bool live = t < nt;
-        int64_t ri = live ? (t >> 4) : 0;
-        int l16 = (int)(t & 15);
+    for (int i = threadIdx.x; i < ho.total / 4; i += 256)
+        reinterpret_cast<float4*>(s_head)[i] = reinterpret_cast<const float4*>(f.head)[i];
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t rr = tile * 16 + (threadIdx.x >> 4);
+        const bool live = rr < a.n;
+        const int64_t ri = live ? rr : 0;
         constexpr int LD = (APP + 3) & ~3;
+        static_assert(!BLEND || LD == 28, "the march's feature rows are 28 floats: 27 features + the shaded flag");
         const float* dp = a.dirs + ri * a.dir_stride;
         const float* fp = a.feat + ri * a.feat_stride;
         float F[LD], d[3] = {dp[0], dp[1], dp[2]}, c[3];
+        float flag = 0.0f;
+        if (BLEND) {        // rows of 28 floats, 16-B aligned (march workspace): seven 16-B loads instead of 28 scalar ones
 #pragma unroll
-        for (int k = 0; k < LD; ++k) F[k] = (k < APP) ? fp[k] : 0.0f;
-        ref_shade_group16<LD>(f.head, ho, f.feature_c, F, d, l16, c);
+            for (int k4 = 0; k4 < LD; k4 += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(fp + k4);
+                F[k4] = v.x; F[k4 + 1] = v.y; F[k4 + 2] = v.z; F[k4 + 3] = v.w;
+            }
+            flag = F[APP];
+            F[APP] = 0.0f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < LD; ++k) F[k] = (k < APP) ? fp[k] : 0.0f;
+        }
+        int opaque0 = 0;
+        asm volatile("" : "+v"(opaque0));            // a zero the optimiser cannot see through (see the comment above the kernel)
+        const lds_cfloat_p hp = (lds_cfloat_p)s_head + opaque0;
+        ref_shade_group16<LD, lds_cfloat_p>(hp, ho, f.feature_c, F, d, l16, c);
         if (live && l16 == 0) {
             if (BLEND) {
-                const bool any = fp[APP] != 0.0f;
+                const bool any = flag != 0.0f;
                 const float acc = a.acc[ri];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -257,20 +278,27 @@ hipError_t launch_point_normals(const FieldDev& f, const float* xyz, int64_t n, 
     hipLaunchKernelGGL((k2_point_app<1, 12, 27>), dim3(grid_for(n * 4)), dim3(256), 0, s, f, xyz, n, out);
     return hipGetLastError();
 }
+template <bool BLEND>
+static hipError_t launch_shade_kernel(const FieldDev& f, const ShadeArgs& a, int64_t n, hipStream_t s) {
+    const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
+    const size_t lds = (size_t)((ho.total + 3) & ~3) * sizeof(float);
+    const int64_t n_tiles = (n + 15) / 16;
+    const int64_t grid = n_tiles < 256 * 5 ? n_tiles : 256 * 5;
+    hipLaunchKernelGGL((k_ref_shade<27, BLEND>), dim3((unsigned)grid), dim3(256), lds, s, f, a, n_tiles);
+    return hipGetLastError();
+}
 hipError_t launch_ref_shade(const FieldDev& f, const float* dirs, const float* feat, int64_t n, float* rgb, hipStream_t s) {
     ShadeArgs a;
     a.dirs = dirs; a.dir_stride = 3; a.feat = feat; a.feat_stride = f.app_dim; a.acc = nullptr;
     a.bg[0] = a.bg[1] = a.bg[2] = 0.0f; a.n = n; a.rgb = rgb;
-    hipLaunchKernelGGL((k_ref_shade<27, false>), dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, f, a);
-    return hipGetLastError();
+    return launch_shade_kernel<false>(f, a, n, s);
 }
 hipError_t launch_shade_blend(const FieldDev& f, const float* rays, int ray_cols, const float* feat28, const float* acc,
                               const float* bg, int64_t n, float* rgb, hipStream_t s) {
     ShadeArgs a;
     a.dirs = rays + 3; a.dir_stride = ray_cols; a.feat = feat28; a.feat_stride = 28; a.acc = acc;
     a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2]; a.n = n; a.rgb = rgb;
-    hipLaunchKernelGGL((k_ref_shade<27, true>), dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, f, a);
-    return hipGetLastError();
+    return launch_shade_kernel<true>(f, a, n, s);
 }
 hipError_t launch_ref_normals(const FieldDev& f, const float* feat, int64_t n, float* out, hipStream_t s) {
     hipLaunchKernelGGL((k_ref_normals<27>), dim3(grid_for(n)), dim3(256), 0, s, f, feat, n, out);

@@ -927,13 +927,103 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
     }
 }
 
+// Token-side Linears for MANY token rows (a batch of query images: 16 x 256 rows): Y [M][Nout] = A [M][K] Wt + bias with
+// Wt [K_pad][Nout] k-major (zero rows beyond K), on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).  A
+// workgroup owns 32 token rows and ALL output columns: the 16-deep k-tile of Wt (17 KB for 272 columns) is staged in LDS
+// once and read by the four waves (row half x column half), instead of every 16 x 16 output tile streaming its own 51 KB
+// of operands from L2 as k_gemm_small does -- that kernel stays for a single image's <= 256 rows, where it has 4x the
+// workgroups.  NTW = 16-column tiles per wave (ceil(Nout / 32)).
+template <int NTW>
+__global__ void __launch_bounds__(256) k_gemm_tokens(const float* __restrict__ A, int K, int K_pad, const float* __restrict__ Wt,
+                                                     int Nout, const float* __restrict__ bias, float* __restrict__ Y, int M) {
+    constexpr int BK = 16, A_LD = 33;
+    extern __shared__ float smem_tok[];
+    float* As = smem_tok;                        // [BK][A_LD]   (k-major: As[k][row])
+    float* Bs = smem_tok + BK * A_LD;            // [BK][Nout]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rh = wave & 1, ch = wave >> 1;
+    const int r = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.x * 32;
+    const int NT = Nout / 16, t0 = ch == 0 ? 0 : (NT + 1) / 2, nt = ch == 0 ? (NT + 1) / 2 : NT - (NT + 1) / 2;
+    // two accumulators per tile, by parity of the 4-deep k-step, added at the end: k_gemm_small's association, so a token row
+    // gets the same bits whichever of the two kernels serves it (batched and per-image calls stay bit-identical)
+    f32x4 acc[NTW][2];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n4 = Nout / 4, nb4 = BK * n4;      // float4s of one Wt k-tile
+    // staging registers: A 32 rows x 16 k = 512 floats -> 2 per thread; Wt k-tile: ceil(nb4 / 256) float4 per thread (<= 7)
+    const int arow = tid >> 3, ak = (tid & 7) * 2;
+    float a_reg[2];
+    float4 b_reg[7];
+    auto load_tile = [&](int k0) {
+        const int gr = m0 + arow;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) a_reg[e] = (gr < M && k0 + ak + e < K) ? A[(size_t)gr * K + k0 + ak + e] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int f = tid + u * 256;
+            b_reg[u] = f < nb4 ? *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + f / n4) * Nout + 4 * (f % n4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+        As[(ak + 0) * A_LD + arow] = a_reg[0];
+        As[(ak + 1) * A_LD + arow] = a_reg[1];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int f = tid + u * 256;
+            if (f < nb4) *reinterpret_cast<float4*>(Bs + (size_t)(f / n4) * Nout + 4 * (f % n4)) = b_reg[u];
+        }
+    };
+    load_tile(0);
+    for (int k0 = 0; k0 < K_pad; k0 += BK) {
+        __syncthreads();                 // the previous tile's operand reads are done
+        store_tile();
+        __syncthreads();
+        if (k0 + BK < K_pad) load_tile(k0 + BK);      // in flight while this tile is multiplied
+#pragma unroll
+        for (int k4 = 0; k4 < BK; k4 += 4) {
+            const float av = As[(k4 + kk) * A_LD + rh * 16 + r];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                if (j < nt) acc[j][(k4 >> 2) & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(size_t)(k4 + kk) * Nout + 16 * (t0 + j) + r],
+                                                                                          acc[j][(k4 >> 2) & 1], 0, 0, 0);
+        }
+    }
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        if (j >= nt) continue;
+        const int col = 16 * (t0 + j) + r;
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = m0 + rh * 16 + 4 * kk + g;
+            if (row < M) Y[(size_t)row * Nout + col] = (acc[j][0][g] + acc[j][1][g]) + bv;
+        }
+    }
+}
+
+static hipError_t gemm_tokens(const float* A, int K, int K_pad, const float* Wt, int Nout, const float* bias, float* Y, int M,
+                              hipStream_t s) {
+    // many rows: the LDS-tiled form; few rows (one image): one wave per 16 x 16 tile fills the chip better
+    const int NT = Nout / 16;
+    if (M > 512 && Nout % 16 == 0 && Nout / 4 * 16 <= 7 * 256 && (NT + 1) / 2 <= 12) {
+        const size_t lds = (size_t)(16 * 33 + 16 * Nout) * sizeof(float);
+        dim3 grid((unsigned)((M + 31) / 32));
+        if ((NT + 1) / 2 <= 9) hipLaunchKernelGGL((k_gemm_tokens<9>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+        else hipLaunchKernelGGL((k_gemm_tokens<12>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+        return hipGetLastError();
+    }
+    dim3 grid((unsigned)((M + 15) / 16), (unsigned)((Nout + 63) / 64));
+    hipLaunchKernelGGL(k_gemm_small, grid, dim3(256), 0, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+    return hipGetLastError();
+}
+
 hipError_t launch_q_proj(const IdNetDev& n, const float* img, int M, float* q, void* scratch, hipStream_t s) {
     (void)scratch;
     if (M == 0) return hipSuccess;
     int kp = (n.img_fea + 15) / 16 * 16;
-    dim3 grid((unsigned)((M + 15) / 16), (unsigned)((n.fea + 63) / 64));
-    hipLaunchKernelGGL(k_gemm_small, grid, dim3(256), 0, s, img, n.img_fea, kp, n.wq, n.fea, n.bq, q, M);
-    return hipGetLastError();
+    return gemm_tokens(img, n.img_fea, kp, n.wq, n.fea, n.bq, q, M, s);
 }
 
 // ------------------------------------------------------------------------------------------------ K6
@@ -1003,9 +1093,7 @@ hipError_t launch_attn_logits(const float* q, const float* k, int M, int64_t N, 
 hipError_t launch_q_fold(const IdNetDev& n, const float* img, int M, float* qf, hipStream_t s) {
     if (M == 0) return hipSuccess;
     int kp = (n.img_fea + 15) / 16 * 16;
-    dim3 grid((unsigned)((M + 15) / 16), (unsigned)((n.qf_ld + 63) / 64));
-    hipLaunchKernelGGL(k_gemm_small, grid, dim3(256), 0, s, img, n.img_fea, kp, n.wqf, n.qf_ld, n.bqf, qf, M);
-    return hipGetLastError();
+    return gemm_tokens(img, n.img_fea, kp, n.wqf, n.qf_ld, n.bqf, qf, M, s);
 }
 
 hipError_t launch_attn_logits_folded(const float* qf, int ldq, const float* h3, int M, int64_t N, int C, float divisor,

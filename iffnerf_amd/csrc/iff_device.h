@@ -326,18 +326,45 @@ __device__ inline float row_dot(const float* __restrict__ row, const float* F) {
 // Ref.forward (models/ref.py:103-152, normals=None) evaluated by a group of 16 consecutive lanes for one ray.
 // Every lane passes the same F[LD] (app_dim features, zero padded to LD = 28) and d[3]; `l16` is the lane's index in the
 // group; `head` is the packed head (LDS or global).  All 16 lanes return the rgb triple.
-template <int LD>
-__device__ inline void ref_shade_group16(const float* head, const HeadOff& ho, int feature_c, const float* F,
+// pointer into LDS that keeps its address space through pointer arithmetic (reads compile to ds_read, not flat_load)
+typedef float f32q __attribute__((ext_vector_type(4)));       // a plain 16-B vector (HIP's float4 class cannot be read from LDS-typed pointers)
+typedef const __attribute__((address_space(3))) float* lds_cfloat_p;
+typedef const __attribute__((address_space(3))) f32q* lds_cfloat4_p;
+template <typename P> struct quad_ptr { typedef const f32q* type; };
+template <> struct quad_ptr<lds_cfloat_p> { typedef lds_cfloat4_p type; };
+
+// HP: `const float*` (head in global memory) or `lds_cfloat_p` (head staged in LDS by the caller)
+template <int LD, typename HP>
+__device__ inline void ref_shade_group16(HP head, const HeadOff& ho, int feature_c, const float* F,
                                          const float d[3], int l16, float rgb[3]) {
-    // small heads, computed redundantly by every lane
+    // small heads: ten rows (normal 0-2, tint 3-5, diffuse 6-8, roughness 9), ONE per lane -- each value is the same fmaf
+    // chain, bias add and activation as before, computed once per ray instead of sixteen times and handed round the group
     float nr[3], tint[3], diff[3], rough;
+    {
+        const int row = l16 < 10 ? l16 : 9;
+        const int blk = row / 3, o = row - 3 * blk;                       // blk 0 normal, 1 tint, 2 diffuse, 3 roughness
+        const int w_off = blk == 0 ? ho.normal_w : (blk == 1 ? ho.tint_w : (blk == 2 ? ho.diffuse_w : ho.rough_w));
+        const int b_off = blk == 0 ? ho.normal_b : (blk == 1 ? ho.tint_b : (blk == 2 ? ho.diffuse_b : ho.rough_b));
+        const HP wr = head + w_off + o * LD;
+        float acc = 0.0f;
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        nr[o] = row_dot<LD>(head + ho.normal_w + o * LD, F) + head[ho.normal_b + o];
-        tint[o] = sigmoidf_(row_dot<LD>(head + ho.tint_w + o * LD, F) + head[ho.tint_b + o]);
-        diff[o] = sigmoidf_((row_dot<LD>(head + ho.diffuse_w + o * LD, F) + head[ho.diffuse_b + o]) + -1.0986122886681098f);
+        for (int k4 = 0; k4 < LD; k4 += 4) {
+            const f32q w4 = *(typename quad_ptr<HP>::type)(wr + k4);
+            acc = fmaf(w4.x, F[k4], acc); acc = fmaf(w4.y, F[k4 + 1], acc); acc = fmaf(w4.z, F[k4 + 2], acc); acc = fmaf(w4.w, F[k4 + 3], acc);
+        }
+        const float raw = acc + head[b_off + o];
+        const float x = raw + (blk == 2 ? -1.0986122886681098f : -1.0f);     // diffuse: - ln 3; roughness: - 1
+        const float sg = sigmoidf_(blk == 1 ? raw : x), sp = softplusf_(x);
+        const float mine = blk == 0 ? raw : (blk == 3 ? sp : sg);
+        const int g0 = (threadIdx.x & 63) & ~15;                            // first lane of this ray's group inside the wave
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            nr[q] = __shfl(mine, g0 + q, 64);
+            tint[q] = __shfl(mine, g0 + 3 + q, 64);
+            diff[q] = __shfl(mine, g0 + 6 + q, 64);
+        }
+        rough = __shfl(mine, g0 + 9, 64);
     }
-    rough = softplusf_((row_dot<LD>(head + ho.rough_w, F) + head[ho.rough_b]) + -1.0f);
     float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
     float n[3] = {-(nr[0] / nn), -(nr[1] / nn), -(nr[2] / nn)};   // normal_mlp: normalise then * -1
     float v[3] = {-d[0], -d[1], -d[2]};
@@ -372,8 +399,18 @@ __device__ inline void ref_shade_group16(const float* head, const HeadOff& ho, i
                            fmaf(head[ho.spec_w + o * KL + feature_c + 2 * i + 1], im, part[o]));
     }
     // bottleneck slice j = l16 + 16 t
+    // (the rows differ per lane, so these are vector loads: 16 B at a time -- one load per weight made this kernel bound by
+    // load instructions, ~250 per wave)
+#pragma unroll 1
     for (int j = l16; j < feature_c; j += 16) {
-        float b = row_dot<LD>(head + ho.bott_w + j * LD, F) + head[ho.bott_b + j];
+        const HP wr = head + ho.bott_w + j * LD;
+        float b = 0.0f;
+#pragma unroll
+        for (int k4 = 0; k4 < LD; k4 += 4) {
+            const f32q w4 = *(typename quad_ptr<HP>::type)(wr + k4);
+            b = fmaf(w4.x, F[k4], b); b = fmaf(w4.y, F[k4 + 1], b); b = fmaf(w4.z, F[k4 + 2], b); b = fmaf(w4.w, F[k4 + 3], b);
+        }
+        b = b + head[ho.bott_b + j];
 #pragma unroll
         for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * KL + j], b, part[o]);
     }
@@ -381,11 +418,22 @@ __device__ inline void ref_shade_group16(const float* head, const HeadOff& ho, i
 #pragma unroll
         for (int o = 0; o < 3; ++o) part[o] = fmaf(head[ho.spec_w + o * KL + K - 1], dot, part[o]) + head[ho.spec_b + o];
     }
+    // the three colour channels on three lanes: one pass of sigmoid + sRGB (a powf) through the instruction stream instead
+    // of three; lane o of the group finishes channel o, the results are handed round (same operations per channel: same bits)
+    float ps[3];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        float s = sigmoidf_(sum16(part[o]));
-        float c = srgbf_(tint[o] * s + diff[o]);
+    for (int o = 0; o < 3; ++o) ps[o] = sum16(part[o]);
+    {
+        const int ch = l16 < 3 ? l16 : 0;
+        const float p_ = ch == 0 ? ps[0] : (ch == 1 ? ps[1] : ps[2]);
+        const float t_ = ch == 0 ? tint[0] : (ch == 1 ? tint[1] : tint[2]);
+        const float d_ = ch == 0 ? diff[0] : (ch == 1 ? diff[1] : diff[2]);
+        const float s = sigmoidf_(p_);
+        float c = srgbf_(t_ * s + d_);
         c = fminf(fmaxf(c, 0.0f), 1.0f);
-        rgb[o] = c * 1.002f - 0.001f;
+        c = c * 1.002f - 0.001f;
+        const int g0 = (threadIdx.x & 63) & ~15;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) rgb[o] = __shfl(c, g0 + o, 64);
     }
 }

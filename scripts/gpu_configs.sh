@@ -20,9 +20,10 @@ except Exception as e:
     print('  parse failed', e)
 PY
 }
-run lego16k --steps 60 --warmup 10
-run truck32k --config truck32k --steps 40 --warmup 6
-run bicycle64k --config bicycle64k --steps 30 --warmup 5
-run lego_b64 --config lego_b64 --steps 40 --warmup 6
-run lego16k_sharded1 --force-sharded --steps 40 --warmup 6 --no-cpu-baseline
-run lego_gpus1 --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-instrument
+timeout -k 10 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+run lego16k --steps 100 --warmup 10 --no-cpu-baseline
+
+
+
+
+
