@@ -243,3 +243,62 @@ def test_resident_rays_cache_in_every_gemm_mode(dev):
                 torch.testing.assert_close(c2w[q], w_c2w, atol=1e-5, rtol=0)
     # empty batch of rays: nothing to cache, nothing crashes
     assert pipe.idnet.build_ray_cache(ori[:0], dirs[:0], rgb[:0]).numel() >= 0
+
+
+def test_evaluation_loop_over_the_slab_march(dev):
+    """renderer.evaluation (renderer.py:28-140) on a duck-typed dataset of pinhole views: PSNR list, view subsampling by
+    N_vis, RGBA ground truth on white, chunk-size independence -- against the oracle's slab march of the same rays."""
+    import types
+    from iffnerf_amd import renderer as R
+    from iffnerf_amd.pose_estimation import model_utils as mu
+    from oracle import field as ofield
+    ck = dict(util.ckpt("small"))
+    ck["kwargs"] = dict(ck["kwargs"], near_far=[0.5, 6.0])
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.th")
+        torch.save(ck, path)
+        model = mu.load_model(path, dev)
+    f = ofield.field_from_ckpt(ck)
+    W, H, n = 20, 24, 4
+    gen = torch.Generator().manual_seed(3)
+    views = []
+    for v in range(n):
+        ang = 2 * 3.14159 * v / n
+        o = torch.tensor([2.6 * torch.cos(torch.tensor(ang)), 2.6 * torch.sin(torch.tensor(ang)), 0.4 + 0.2 * v])
+        fwd = -o / o.norm()
+        right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0])); right = right / right.norm()
+        up = torch.linalg.cross(right, fwd)
+        ys, xs = torch.meshgrid(torch.linspace(0.45, -0.45, H), torch.linspace(-0.4, 0.4, W), indexing="ij")
+        d = fwd[None, None] + xs[..., None] * right + ys[..., None] * up
+        d = d / d.norm(dim=-1, keepdim=True)
+        views.append(torch.cat((o.expand(H, W, 3), d), -1).reshape(H * W, 6))
+    all_rays = torch.stack(views)
+    want = torch.stack([ofield.march(f, r, "slab", -1, white_bg=True)[0] for r in all_rays])       # [n, H*W, 3]
+    assert float(want.std()) > 0.05                                                                   # the views do see the object
+    alpha = (torch.rand(n, H, W, 1, generator=gen) > 0.3).float()
+    noise = 0.02 * torch.randn(n, H, W, 3, generator=gen)
+    rgba = torch.cat(((want.view(n, H, W, 3) + noise).clamp(0, 1), alpha), -1)
+    ds = types.SimpleNamespace(all_rays=all_rays, all_rgbs=rgba, img_wh=(W, H), near_far=[0.5, 6.0])
+    args = types.SimpleNamespace(test_batch_size=-1, batch_size=4096, n_iters=1)
+    psnrs = R.evaluation(ds, model, args, R.OctreeRender_trilinear_fast, N_vis=-1, white_bg=True, compute_extra_metrics=False, device=dev)
+    assert len(psnrs) == n
+    for v in range(n):
+        gt = (rgba[v, ..., :3] * rgba[v, ..., 3:] + (1 - rgba[v, ..., 3:])).clamp(0, 1)
+        ref = -10.0 * torch.log10(torch.mean((want[v].view(H, W, 3).clamp(0, 1) - gt) ** 2))
+        assert abs(psnrs[v] - float(ref)) < 1e-2, (v, psnrs[v], float(ref))
+    two, info = R.evaluation(ds, model, args, R.OctreeRender_trilinear_fast, N_vis=2, white_bg=True, compute_extra_metrics=False,
+                             device=dev, return_result=True)
+    assert len(two) == 2 and abs(two[1] - psnrs[2]) < 1e-9 and abs(info["avg_psnr"] - sum(two) / 2) < 1e-9
+    # the renderer alone: pieces of any size give the same image
+    old = R.MAX_RAYS_PER_LAUNCH
+    try:
+        a = R.OctreeRender_trilinear_fast(all_rays[0], model, white_bg=True, device=dev)[0]
+        R.MAX_RAYS_PER_LAUNCH = 100
+        b = R.OctreeRender_trilinear_fast(all_rays[0], model, chunk=7, white_bg=True, device=dev)[0]
+    finally:
+        R.MAX_RAYS_PER_LAUNCH = old
+    assert torch.equal(a, b)
+    torch.testing.assert_close(a.cpu(), want[0], atol=5e-5, rtol=0)
+    with pytest.raises(RuntimeError, match="SSIM"):
+        R.evaluation(ds, model, args, R.OctreeRender_trilinear_fast, device=dev)
