@@ -252,10 +252,11 @@ extern "C" size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mod
 
 static int march_impl(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                       int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc, float* alpha_opt,
-                      int32_t* counts_opt, void* workspace, size_t workspace_bytes, float* stage_ms_host, void* stream) {
+                      int32_t* counts_opt, void* workspace, size_t workspace_bytes, float* stage_ms_host, void* stream,
+                      float* feat_out = nullptr) {
     IFF_REQUIRE(f != nullptr && R >= 0, "iff_march_shade: bad argument");
     if (R == 0) return 0;
-    IFF_REQUIRE(rays && rgb && depth && acc && bg_host, "iff_march_shade: null buffer");
+    IFF_REQUIRE(rays && (rgb || feat_out) && depth && acc && bg_host, "iff_march_shade: null buffer");
     IFF_REQUIRE(ray_cols == 6 || ray_cols == 7, "iff_march_shade: rays must have 6 or 7 columns (got %d)", ray_cols);
     IFF_REQUIRE(mode == IFF_MARCH_POINT_CENTRED || mode == IFF_MARCH_SLAB, "iff_march_shade: unknown mode %d", mode);
     int S = march_samples(f, mode, n_samples);
@@ -265,8 +266,44 @@ static int march_impl(const iff_field* f, const float* rays, int32_t ray_cols, i
     if (mode == IFF_MARCH_SLAB && f->dev.unisphere)
         return fail(IFF_ERR_UNSUPPORTED, "slab sampler with contraction_type='unisphere' is not built "
                                          "(the reference's own branch is unfinished: models/tensorBase.py:511-525)");
-    IFF_HIP(launch_march(f->dev, rays, ray_cols, R, mode, S, bg_host, rgb, depth, acc, alpha_opt, counts_opt, workspace,
-                         workspace_bytes, stage_ms_host, (hipStream_t)stream));
+    IFF_HIP(launch_march(f->dev, rays, ray_cols, R, mode, S, bg_host, rgb, depth, acc, alpha_opt, counts_opt, feat_out,
+                         workspace, workspace_bytes, stage_ms_host, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_march_features(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                                  int32_t n_samples, float* feat28, float* depth, float* acc, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(feat28 != nullptr, "iff_march_features: feat28 is null");
+    const float bg[3] = {0.0f, 0.0f, 0.0f};
+    return march_impl(f, rays, ray_cols, R, mode, n_samples, bg, nullptr, depth, acc, nullptr, nullptr, workspace,
+                      workspace_bytes, nullptr, stream, feat28);
+}
+
+extern "C" size_t iff_march_grad_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples) {
+    if (!f || R <= 0) return 0;
+    return march_grad_workspace_bytes(R, march_samples(f, mode, n_samples));
+}
+
+extern "C" int iff_march_grad(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                              int32_t n_samples, const float* g_feat28, const float* g_acc, float* g_rays6,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(f != nullptr && R >= 0, "iff_march_grad: bad argument");
+    if (R == 0) return 0;
+    IFF_REQUIRE(rays && g_feat28 && g_acc && g_rays6, "iff_march_grad: null buffer");
+    IFF_REQUIRE(ray_cols == 6 || ray_cols == 7, "iff_march_grad: rays must have 6 or 7 columns (got %d)", ray_cols);
+    IFF_REQUIRE(mode == IFF_MARCH_POINT_CENTRED || mode == IFF_MARCH_SLAB, "iff_march_grad: unknown mode %d", mode);
+    int S = march_samples(f, mode, n_samples);
+    IFF_REQUIRE(S >= 1 && S <= (1 << 20), "iff_march_grad: n_samples = %d out of range", S);
+    IFF_REQUIRE(f->dev.n_density % 4 == 0 && f->dev.n_app % 4 == 0 && f->dev.basis != nullptr && f->dev.dplane[0] != nullptr,
+                "iff_march_grad: the handle carries no VM tables");
+    if (f->dev.unisphere)
+        return fail(IFF_ERR_UNSUPPORTED, "iff_march_grad: contraction_type='unisphere' is not built (the reference's slab "
+                                         "sampler for it is unfinished: models/tensorBase.py:511-525)");
+    if (!workspace || workspace_bytes < march_grad_workspace_bytes(R, S))
+        return fail(IFF_ERR_WORKSPACE, "iff_march_grad: workspace %zu < %zu bytes", workspace_bytes, march_grad_workspace_bytes(R, S));
+    IFF_HIP(launch_march_grad(f->dev, rays, ray_cols, R, mode, S, g_feat28, 28, g_acc, g_rays6, workspace, workspace_bytes,
+                              (hipStream_t)stream));
     return 0;
 }
 

@@ -25,8 +25,12 @@ hipError_t launch_isocell_emit(const float* cells27x3_host, const float* pts, co
                                float* dirs, float* rays6, hipStream_t s);
 size_t march_workspace_bytes(int64_t R, int S);
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
-                        float* rgb, float* depth, float* acc, float* alpha, int* counts, void* ws, size_t ws_bytes,
-                        float* stage_ms_host, hipStream_t s);
+                        float* rgb, float* depth, float* acc, float* alpha, int* counts, float* feat_out, void* ws,
+                        size_t ws_bytes, float* stage_ms_host, hipStream_t s);
+size_t march_grad_workspace_bytes(int64_t R, int S);
+hipError_t launch_march_grad(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S,
+                             const float* g_feat, int g_feat_ld, const float* g_acc, float* g_rays, void* ws, size_t ws_bytes,
+                             hipStream_t s);
 
 // sampler_kernels.hip
 size_t sampler_workspace_bytes(int64_t P);

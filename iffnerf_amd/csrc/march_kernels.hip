@@ -322,8 +322,8 @@ static size_t march_feat_offset(int64_t R, int S) { return ((size_t)R * (size_t)
 size_t march_workspace_bytes(int64_t R, int S) { return march_feat_offset(R, S) + (size_t)R * 28 * sizeof(float); }
 
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
-                        float* rgb, float* depth, float* acc, float* alpha, int* counts, void* ws, size_t ws_bytes,
-                        float* stage_ms_host, hipStream_t s) {
+                        float* rgb, float* depth, float* acc, float* alpha, int* counts, float* feat_out, void* ws,
+                        size_t ws_bytes, float* stage_ms_host, hipStream_t s) {
     if (ws_bytes < march_workspace_bytes(R, S)) return hipErrorInvalidValue;
     // optional per-launch timing (bench.py's roofline): events on the launch stream, one synchronise at the end
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -334,7 +334,9 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     MarchArgs a;
     a.rays = rays; a.ray_cols = ray_cols; a.R = R; a.mode = mode; a.S = S;
     a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2];
-    a.rgb = rgb; a.depth = depth; a.acc = acc; a.alpha = alpha; a.counts = counts; a.weights = (float*)ws; a.feat = (float*)((char*)ws + march_feat_offset(R, S));
+    a.rgb = rgb; a.depth = depth; a.acc = acc; a.alpha = alpha; a.counts = counts; a.weights = (float*)ws;
+    // feat_out: stop before the Ref head and hand the per-ray features [R][28] to the caller (iff_march_features)
+    a.feat = feat_out ? feat_out : (float*)((char*)ws + march_feat_offset(R, S));
     a.n_tiles = (R + RPB - 1) / RPB;
     if (a.n_tiles == 0) return hipSuccess;
     // one lane per sample when the density texel is one 64-B line (n_density = 16, every reference config)
@@ -353,7 +355,7 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);
-    e = launch_shade_blend(f, rays, ray_cols, a.feat, acc, a.bg, R, rgb, s);
+    if (!feat_out) e = launch_shade_blend(f, rays, ray_cols, a.feat, acc, a.bg, R, rgb, s);
     if (stage_ms_host) {
         (void)hipEventRecord(ev[3], s);
         hipError_t es = hipEventSynchronize(ev[3]);

@@ -236,6 +236,37 @@ class FieldHandle:
                 stage_ms[:] = [float(v) for v in ms]
         return rgb, depth, acc, alpha, counts, S
 
+    def march_features(self, rays: torch.Tensor, mode: int, n_samples: int = -1):
+        """``iff_march_features``: the march up to the Ref head -> (feat28 [R,28], depth [R], acc [R], S)."""
+        if rays.dim() != 2 or rays.shape[-1] not in (6, 7) or not rays.is_cuda:
+            raise RuntimeError(f"rays_chunk must be a GPU tensor [R,6] or [R,7] (got {tuple(rays.shape)})")
+        r = rays.detach().to(torch.float32).contiguous()
+        R = r.shape[0]
+        S = n_samples if n_samples > 0 else (20 if mode == MARCH_POINT else self.n_samples_default)
+        feat, depth, acc = r.new_zeros(R, 28), r.new_empty(R), r.new_empty(R)
+        ws_bytes = int(_lib.lib().iff_march_workspace(self._h, R, mode, S)) if R > 0 else 0
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=r.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().iff_march_features(self._h, dptr(r), r.shape[1], R, mode, S, dptr(feat), dptr(depth), dptr(acc),
+                                                ws.data_ptr(), ws.numel() * 4, stream_ptr(self.device)), "iff_march_features")
+        return feat, depth, acc, S
+
+    def march_grad(self, rays: torch.Tensor, mode: int, n_samples: int, g_feat28: torch.Tensor, g_acc: torch.Tensor):
+        """``iff_march_grad``: dL/d(o, d) [R,6] from dL/dfeat28 [R,28] and dL/dacc [R]."""
+        r = rays.detach().to(torch.float32).contiguous()
+        R = r.shape[0]
+        gf = g_feat28.detach().to(torch.float32).contiguous()
+        ga = g_acc.detach().to(torch.float32).contiguous()
+        if gf.shape != (R, 28) or ga.shape != (R,):
+            raise RuntimeError(f"march_grad: gradients must be [R,28] and [R] (got {tuple(gf.shape)}, {tuple(ga.shape)})")
+        out = r.new_zeros(R, 6)
+        ws_bytes = int(_lib.lib().iff_march_grad_workspace(self._h, R, mode, n_samples)) if R > 0 else 0
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=r.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().iff_march_grad(self._h, dptr(r), r.shape[1], R, mode, n_samples, dptr(gf), dptr(ga), dptr(out),
+                                            ws.data_ptr(), ws.numel() * 4, stream_ptr(self.device)), "iff_march_grad")
+        return out
+
     # ------------------------------------------------------------------ surface sampler
     def surface_sample(self, n_points: int, rho: float, n_epochs: int = 4, max_iterations: int = 200, seed: int = 0,
                        seed_offset: Optional[torch.Tensor] = None):

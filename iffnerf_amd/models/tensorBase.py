@@ -49,6 +49,29 @@ def raw2alpha(sigma, dist):
     return alpha, alpha * trans[:, :-1], trans[:, -1:]
 
 
+class _MarchFeatures(torch.autograd.Function):
+    """(feat28, depth, acc) = march(rays) with dL/d(o, d) from ``iff_march_grad`` (csrc/march_grad_kernels.hip).  depth is
+    not differentiable (reference :903-905 computes it under no_grad); a 7th ray column (radius) receives zero."""
+
+    @staticmethod
+    def forward(ctx, rays, handle, mode, n_samples):
+        feat28, depth, acc, S = handle.march_features(rays, mode, n_samples)
+        ctx.handle, ctx.mode, ctx.S = handle, mode, S
+        ctx.save_for_backward(rays.detach())
+        ctx.mark_non_differentiable(depth)
+        return feat28, depth, acc
+
+    @staticmethod
+    def backward(ctx, g_feat, g_depth, g_acc):
+        (rays,) = ctx.saved_tensors
+        g_feat = torch.zeros(rays.shape[0], 28, device=rays.device) if g_feat is None else g_feat
+        g_acc = torch.zeros(rays.shape[0], device=rays.device) if g_acc is None else g_acc
+        g6 = ctx.handle.march_grad(rays, ctx.mode, ctx.S, g_feat, g_acc)
+        if rays.shape[1] > 6:
+            g6 = torch.cat((g6, torch.zeros(rays.shape[0], rays.shape[1] - 6, device=g6.device, dtype=g6.dtype)), -1)
+        return g6.to(rays.dtype), None, None, None
+
+
 class AlphaGridMask(torch.nn.Module):
     """Occupancy volume of reference tensorBase.py:50-83; ``sample_alpha`` runs ``iff_mask_sample``."""
 
@@ -249,9 +272,35 @@ class TensorBase(torch.nn.Module):
         return self.field_handle().march(rays_chunk, MARCH_POINT if point_centred else MARCH_SLAB, N_samples, bg,
                                          want_alpha=want_alpha, want_counts=want_counts)
 
+    def _forward_ray_grad(self, rays_chunk, point, N_samples, white_bg, bg_color):
+        """``forward`` for rays that require grad (inerf/estimate_pose_inerf.py:164-176 optimises the camera pose through
+        ``model(rays_chunk, ...)``): the march and its gradient w.r.t. (o, d) are HIP launches (``_MarchFeatures``); the Ref
+        head -- a per-ray MLP -- and the background blend (reference :889-901) run as torch ops on the GPU, so autograd
+        also reaches the view directions.  Field parameters stay frozen (load_model, model_utils.py:12-13)."""
+        h = self.field_handle()
+        mode = MARCH_POINT if point else MARCH_SLAB
+        S = int(N_samples) if N_samples > 0 else (20 if point else h.n_samples_default)
+        feat28, depth, acc = _MarchFeatures.apply(rays_chunk, h, mode, S)
+        d = rays_chunk[:, 3:6]
+        rows = torch.nonzero(feat28[:, 27] > 0)[:, 0]                                          # rays_to_consider, :887
+        rgb = torch.zeros(rays_chunk.shape[0], 3, dtype=acc.dtype, device=acc.device)
+        if rows.numel():
+            rgb = rgb.index_put((rows,), self.renderModule.forward_autograd(d[rows], feat28[rows, :27]))
+        if bg_color is None:
+            bg_color = torch.ones(3, device=rgb.device) if white_bg else torch.zeros(3, device=rgb.device)
+        rgb = (rgb * acc[..., None] + torch.as_tensor(bg_color, device=rgb.device) * (1.0 - acc[..., None])).clamp(0, 1)
+        o = rays_chunk[:, :3]
+        if point:
+            z_vals = (self.stepSize * torch.arange(-(S // 2), S - S // 2, dtype=o.dtype, device=o.device))[None]
+        else:
+            z_vals = self.sample_ray(o, d, None, is_train=False, N_samples=S)[1]
+        dists = torch.cat((z_vals[:, 1:] - z_vals[:, :-1], torch.zeros_like(z_vals[:, :1])), dim=-1)
+        return rgb, depth, acc, None, z_vals, dists
+
     def forward(self, rays_chunk, white_bg=False, bg_color=None, is_train=False, ndc_ray=False, sample_func=None,
                 N_samples=-1):
-        """Reference :775-917.  Returns (rgb_map, depth_map, acc_map, alpha, z_vals, dists)."""
+        """Reference :775-917.  Returns (rgb_map, depth_map, acc_map, alpha, z_vals, dists); with rays that require grad
+        (``_forward_ray_grad``) ``alpha`` is None -- the per-sample alphas are not kept for the backward pass."""
         if is_train or ndc_ray:
             raise RuntimeError("forward(is_train/ndc_ray=True) is outside the inference path built for MI355X")
         if sample_func is None:
@@ -260,6 +309,9 @@ class TensorBase(torch.nn.Module):
             point = True
         else:
             raise RuntimeError("forward: sample_func must be None (slab sampler) or this model's sample_point_color")
+        if torch.is_grad_enabled() and rays_chunk.requires_grad:
+            self._no_grad_only("forward")
+            return self._forward_ray_grad(rays_chunk, point, N_samples, white_bg, bg_color)
         rgb, depth, acc, alpha, _, S = self.march(rays_chunk, point, N_samples, white_bg, bg_color, want_alpha=True)
         o, d = rays_chunk[:, :3], rays_chunk[:, 3:6]
         if point:

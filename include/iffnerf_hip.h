@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 6
+#define IFF_ABI_VERSION 7
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -165,6 +165,25 @@ int iff_march_shade_timed(const iff_field* f, const float* rays, int32_t ray_col
                           int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
                           float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes,
                           float* stage_ms_host, void* stream);
+
+/* The march up to, not including, the Ref head: the differentiable quantities of TensorBase.forward
+ * (models/tensorBase.py:886-888: acc_map and the weighted feature sum).  feat28 [R,28] = the 27 summed features + a
+ * "has shaded samples" flag (rays_to_consider, :887); depth, acc [R].  Workspace: iff_march_workspace.
+ * With iff_march_grad it carries the gradient path of inerf/estimate_pose_inerf.py:151-176 (`model(rays_chunk, ...)`
+ * followed by loss.backward() on the camera pose): the caller runs the Ref head (models/ref.py:103-152, a per-ray MLP) in
+ * its autograd framework between the two. */
+int iff_march_features(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
+                       int32_t n_samples, float* feat28, float* depth, float* acc, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* Gradient of (feat28[:, :27], acc) with respect to the rays (models/tensorBase.py:775-888 as autograd differentiates it
+ * for inerf/estimate_pose_inerf.py:176: through sample_ray's slab entry :499-502, the plane/line grid_sample coordinates
+ * tensoRF.py:216-256, feature2density :750-754 and raw2alpha :23-35; masks and the weight threshold are constants).
+ * g_feat28 [R,28] (column 27 ignored), g_acc [R] -> g_rays6 [R,6] = dL/d(o, d).  'aabb' contraction only (IFF_ERR_UNSUPPORTED
+ * otherwise).  Workspace: iff_march_grad_workspace (3 floats per sample). */
+size_t iff_march_grad_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples);
+int iff_march_grad(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode, int32_t n_samples,
+                   const float* g_feat28, const float* g_acc, float* g_rays6, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------- surface sampler
  * iterative_surface_sampling_process, pose_estimation/sampling.py:509-532 (+ :78-116,131-213,35-67):

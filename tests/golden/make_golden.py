@@ -18,6 +18,8 @@ Vectors (names follow SURVEY.md section 8c):
   g9_sampler        iterative_surface_sampling_process: exact stream (CPU RNG) + invariants
   g10_march_slab    forward(rays) with the default slab sampler
   g11_unisphere     normalize_coord / compute_alpha with contraction_type="unisphere"
+  g12_march_grad    d loss / d rays through forward(rays) (slab sampler) and through the point-centred sampler, the
+                    autograd path of inerf/estimate_pose_inerf.py:164-176 (`python make_golden.py g12` writes only this one)
 """
 import hashlib
 import io
@@ -104,10 +106,44 @@ def surface_rays(ck, n, seed):
     return torch.cat([o, d], -1).contiguous()
 
 
+def camera_rays(ck, n, seed):
+    """[n,7] rays of cameras outside the box looking at the blob (o, unit d, radius), the layout iNeRF marches."""
+    g = torch.Generator().manual_seed(seed)
+    aabb = ck["kwargs"]["aabb"]
+    c, h = (aabb[0] + aabb[1]) / 2, (aabb[1] - aabb[0]) / 2
+    cam = c + torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * h.norm() * 1.3
+    target = c + h * (torch.rand(n, 3, generator=g) - 0.5) * 0.9
+    d = torch.nn.functional.normalize(target - cam, dim=-1)
+    return torch.cat([cam, d, torch.full((n, 1), 1e-3)], -1).contiguous()
+
+
+def g12(ref):
+    """Gradients of a fixed linear functional of (rgb, acc) with respect to the rays, as autograd gives them."""
+    m2, ck2 = build_ref_model(ref, SMALL)
+    m2.near_far = [0.05, 6.0]
+    gen = torch.Generator().manual_seed(1201)
+    out = {}
+    for tag, rays, kw in (("slab", camera_rays(ck2, 192, 1202), {}),
+                          ("point", surface_rays(ck2, 192, 1203), dict(N_samples=20, sample_func=m2.sample_point_color))):
+        rays = rays.clone().requires_grad_(True)
+        c_rgb, c_acc = torch.randn(rays.shape[0], 3, generator=gen), torch.randn(rays.shape[0], generator=gen)
+        bg = torch.tensor([0.3, 0.6, 0.1])
+        rgb, depth, acc, alpha, z, dists = m2(rays, bg_color=bg, is_train=False, **kw)
+        loss = (rgb * c_rgb).sum() + (acc * c_acc).sum()
+        (grad,) = torch.autograd.grad(loss, rays)
+        out.update({f"{tag}_rays": rays.detach(), f"{tag}_c_rgb": c_rgb, f"{tag}_c_acc": c_acc, f"{tag}_rgb": rgb.detach(),
+                    f"{tag}_acc": acc.detach(), f"{tag}_grad": grad, f"{tag}_n_shaded":
+                    (alpha.detach() > 0).sum(-1).to(torch.int64)})
+    save("g12_march_grad", bg=bg, near_far=np.asarray(m2.near_far, dtype=np.float32), n_samples=np.int64(m2.nSamples), **out)
+
+
 def main():
     ref = ri.install()
     torch.set_num_threads(4)
     S = ref.sampling
+    if sys.argv[1:] == ["g12"]:
+        g12(ref)
+        return
 
     # ---------------------------------------------------------------- G1
     m, ck = build_ref_model(ref, TINY)
@@ -295,6 +331,7 @@ def main():
     xu = probe_points(cku, 256, 1101) * 2.0
     save("g11_unisphere", xyz=xu, xn=mu.normalize_coord(xu), alpha=mu.compute_alpha(xu), step_size=mu.stepSize,
          n_samples=np.int64(mu.nSamples), mask_value=mu.alphaMask.sample_alpha(xu))
+    g12(ref)
     print("done")
 
 

@@ -187,3 +187,29 @@ def test_install_registers_reference_module_names():
         for k in [k for k in sys.modules if k.split(".")[0] in ("models", "pose_estimation", "renderer")]:
             del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_ref_head_torch_formulation(golden):
+    """Ref.forward_autograd (the grad-mode head: real-arithmetic IDE, torch ops) against the reference's outputs (G3) and,
+    for its gradients w.r.t. features and view directions, against autograd through the oracle's complex-pow restatement."""
+    from oracle import field
+    from iffnerf_amd.models.ref import Ref
+    ck = util.ckpt("tiny")
+    f = field.field_from_ckpt(ck)
+    head = Ref(27, viewpe=2, feature_c=128)
+    head.load_state_dict({k[len("renderModule."):]: v for k, v in ck["state_dict"].items() if k.startswith("renderModule.")})
+    for p in head.parameters():
+        p.requires_grad = False
+    dirs, feat = golden.t("g3_ref_head", "dirs"), golden.t("g3_ref_head", "feat")
+    rgb = head.forward_autograd(dirs, feat)
+    torch.testing.assert_close(rgb, golden.t("g3_ref_head", "rgb"), rtol=0, atol=2e-6)
+    c = torch.randn(rgb.shape, generator=torch.Generator().manual_seed(5))
+    grads = []
+    for fn in (lambda d, x: head.forward_autograd(d, x), lambda d, x: field.ref_shade(f.head, d, x)):
+        d, x = dirs.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        grads.append(torch.autograd.grad((fn(d, x) * c).sum(), (d, x)))
+        # Ref.forward routes to the torch formulation when its inputs require grad
+    for mine, ref in zip(*grads):
+        torch.testing.assert_close(mine, ref, rtol=0, atol=2e-5 * float(ref.abs().max()))
+    d = dirs.clone().requires_grad_(True)
+    assert head(None, d, feat, None)[0].requires_grad

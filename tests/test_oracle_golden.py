@@ -179,3 +179,25 @@ def test_gridsample_restatement(golden):
     planes = [g[f"sd.density_plane.{i}"][0] for i in range(3)]
     lines = [g[f"sd.density_line.{i}"][0, :, :, 0] for i in range(3)]
     np.testing.assert_allclose(gs.vm_density_feature(planes, lines, g["xn"]), g["density_feature"], rtol=2e-6, atol=2e-5)
+
+
+def _g12_case(golden, tag):
+    g = golden["g12_march_grad"]
+    f = field.field_from_ckpt(util.ckpt("small"))
+    f.near_far = tuple(float(v) for v in g["near_far"])
+    rays = golden.t("g12_march_grad", f"{tag}_rays").clone().requires_grad_(True)
+    mode = dict(slab=("slab", -1), point=("point", 20))[tag]
+    rgb, _, acc, _, _, _, _ = field.march(f, rays, mode[0], mode[1], bg_color=golden.t("g12_march_grad", "bg"))
+    loss = (rgb * golden.t("g12_march_grad", f"{tag}_c_rgb")).sum() + (acc * golden.t("g12_march_grad", f"{tag}_c_acc")).sum()
+    (grad,) = torch.autograd.grad(loss, rays)
+    return g, rgb.detach(), acc.detach(), grad
+
+
+def test_g12_march_grad(golden):
+    """The oracle's march is differentiable torch code: autograd through it gives the reference's d loss / d rays
+    (inerf/estimate_pose_inerf.py:164-176), bit for bit on the same CPU kernels."""
+    for tag in ("slab", "point"):
+        g, rgb, acc, grad = _g12_case(golden, tag)
+        _eq(rgb, g[f"{tag}_rgb"]); _eq(acc, g[f"{tag}_acc"])
+        _eq(grad, g[f"{tag}_grad"], tol=1e-5 * float(np.abs(g[f"{tag}_grad"]).max()))
+        assert (np.abs(g[f"{tag}_grad"][:, :6]).sum(-1) > 0).mean() > 0.9       # the fixture exercises the gradient path
