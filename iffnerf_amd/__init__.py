@@ -8,7 +8,7 @@ Layout
   distributed.py              ray sharding over torch.distributed (RCCL) for multi-GPU runs
 
 ``install()`` registers the mirror under the reference's top-level module names (``models``, ``renderer``,
-``pose_estimation``) so the reference driver imports it unchanged; see INTEGRATION.md.
+``pose_estimation``, ``inerf``, ``ray_utils``) so the reference driver imports it unchanged; see INTEGRATION.md.
 """
 from __future__ import annotations
 
@@ -34,6 +34,11 @@ _ALIASES = {
     "pose_estimation.pose_geometry": "iffnerf_amd.pose_estimation.pose_geometry",
     "pose_estimation.errors": "iffnerf_amd.pose_estimation.errors",
     "pose_estimation.test": "iffnerf_amd.pose_estimation.test",
+    "ray_utils": "iffnerf_amd.ray_utils",
+    "inerf": "iffnerf_amd.inerf",
+    "inerf.inerf": "iffnerf_amd.inerf.inerf",
+    "inerf.dice_loss": "iffnerf_amd.inerf.dice_loss",
+    "inerf.estimate_pose_inerf": "iffnerf_amd.inerf.estimate_pose_inerf",
 }
 
 

@@ -20,6 +20,7 @@ Vectors (names follow SURVEY.md section 8c):
   g11_unisphere     normalize_coord / compute_alpha with contraction_type="unisphere"
   g12_march_grad    d loss / d rays through forward(rays) (slab sampler) and through the point-centred sampler, the
                     autograd path of inerf/estimate_pose_inerf.py:164-176 (`python make_golden.py g12` writes only this one)
+  g13_inerf_host    CameraTransfer, get_ray_directions_Ks / get_rays, SoftDiceLossV2 of the iNeRF loop (`... g13`)
 """
 import hashlib
 import io
@@ -137,7 +138,53 @@ def g12(ref):
     save("g12_march_grad", bg=bg, near_far=np.asarray(m2.near_far, dtype=np.float32), n_samples=np.int64(m2.nSamples), **out)
 
 
+def g13():
+    """Host pieces of the iNeRF loop: CameraTransfer, get_ray_directions_Ks / get_rays, SoftDiceLossV2 (values + gradients).
+    inerf/inerf.py imports cv2 and kornia at module top for find_POI / a commented-out variant; neither is called here."""
+    import importlib
+    import types
+    for name in ("inerf", "inerf.estimate_pose_inerf"):                 # _reference_import's placeholders for pose_estimation.test
+        sys.modules.pop(name, None)
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
+    for attr in ("cvtColor", "COLOR_RGB2GRAY", "SIFT_create"):          # names find_POI binds at import; never called here
+        if not hasattr(cv2, attr):
+            setattr(cv2, attr, None)
+    sys.modules["cv2"] = cv2
+    for name in ("kornia", "kornia.geometry", "kornia.geometry.liegroup"):
+        if name not in sys.modules or not hasattr(sys.modules[name], "__path__"):
+            m = types.ModuleType(name); m.__path__ = []; sys.modules[name] = m
+    sys.modules["kornia.geometry.liegroup"].Se3 = object
+    inerf = importlib.import_module("inerf.inerf")
+    dice = importlib.import_module("inerf.dice_loss")
+    ru = importlib.import_module("ray_utils")
+    gen = torch.Generator().manual_seed(1301)
+    start = torch.eye(4)
+    start[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0]
+    start[:3, 3] = torch.randn(3, generator=gen)
+    ct = inerf.CameraTransfer(start)
+    with torch.no_grad():
+        ct.w.copy_(torch.tensor([0.3, -0.2, 0.5])); ct.v.copy_(torch.tensor([0.1, 0.4, -0.3])); ct.theta.copy_(torch.tensor(0.7))
+    T = ct()
+    c = torch.randn(4, 4, generator=gen)
+    gw, gv, gth = torch.autograd.grad((T * c).sum(), (ct.w, ct.v, ct.theta))
+    K = torch.tensor([[[55.0, 0.0, 15.5], [0.0, 60.0, 12.0], [0.0, 0.0, 1.0]]])
+    d, dx, dy = ru.get_ray_directions_Ks(24, 32, K, use_pixel_centers=True)
+    unit = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+    ro, rd, rad = ru.get_rays(unit, T.detach(), directions=d, dx=dx, dy=dy, keepdim=True)
+    logits = torch.rand(64, generator=gen).requires_grad_(True)
+    labels = (torch.rand(64, 1, generator=gen) > 0.4).float()
+    dl = dice.SoftDiceLossV2()(logits[..., None], labels)
+    (gl,) = torch.autograd.grad(dl[0], logits)
+    save("g13_inerf_host", start=start, cam_w=ct.w.detach(), cam_v=ct.v.detach(), cam_theta=ct.theta.detach(), T=T.detach(),
+         c=c, g_w=gw, g_v=gv, g_theta=gth, K=K, dirs=d, dx=dx, dy=dy, rays_o=ro, rays_d=rd, radii=rad,
+         dice_logits=logits.detach(), dice_labels=labels, dice_loss=dl.detach(), dice_grad=gl)
+
+
 def main():
+    if sys.argv[1:] == ["g13"]:
+        ri.install()
+        g13()
+        return
     ref = ri.install()
     torch.set_num_threads(4)
     S = ref.sampling
@@ -332,6 +379,7 @@ def main():
     save("g11_unisphere", xyz=xu, xn=mu.normalize_coord(xu), alpha=mu.compute_alpha(xu), step_size=mu.stepSize,
          n_samples=np.int64(mu.nSamples), mask_value=mu.alphaMask.sample_alpha(xu))
     g12(ref)
+    g13()
     print("done")
 
 

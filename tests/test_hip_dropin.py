@@ -102,6 +102,18 @@ def test_reference_module_paths_run_on_the_gpu(golden, dev, tmp_path, monkeypatc
     pred = torch.tensor([r["pred_c2w"] for r in res])
     torch.testing.assert_close(pred, torch.from_numpy(g8["pred_c2w"]), atol=1e-4, rtol=0)
     assert abs(te - float(g8["avg_translation_error"])) < 1e-4 and abs(ae - float(g8["avg_angular_error"])) < 1e-2
+    # inerf_refinement=True (reference test.py:196-211) runs the iNeRF loop on every image; 3 steps here, only the plumbing
+    # (test_inerf_refinement_loop checks that it converges)
+    import pose_estimation.test as pt
+    monkeypatch.setattr(pt, "INERF_ITERS", 3)
+    monkeypatch.setattr(pt, "INERF_BATCH", 128)                      # the fixture's images are 16 x 16
+    ds.K = torch.tensor([[[20.0, 0.0, 8.0], [0.0, 20.0, 8.0], [0.0, 0.0, 1.0]]])
+    with pytest.raises(RuntimeError, match="nerf_model"):
+        test_pose_estimation(ds, idm, ro, rd, rc, golden.t("g8_end_to_end", "model_up").to(dev), inerf_refinement=True)
+    res_i, _, _, _, _ = test_pose_estimation(ds, idm, ro, rd, rc, golden.t("g8_end_to_end", "model_up").to(dev),
+                                             inerf_refinement=True, nerf_model=model)
+    moved = torch.tensor([r["pred_c2w"] for r in res_i])
+    assert torch.isfinite(moved).all() and 0 < float((moved - pred).abs().max()) < 0.2        # three lr=0.02 Adam steps
     # test_image returns the reference's 4-tuple; the attention map rows are softmaxes over the rays
     idx, val, scores, amap = idm.test_image(ds.all_rgbs[0, ..., :3].to(dev), ds.all_rgbs[0, ..., 3].to(dev), ro, rd, rc)
     assert idx.shape == (100,) and idx.dtype == torch.int64 and scores.shape == (2025,) and amap.shape[1] == 2025
@@ -386,3 +398,46 @@ def test_pose_refinement_descends_through_the_march(dev):
     assert losses[-1] < 0.1 * losses[0], (losses[0], losses[-1])
     # translation and small rotations trade off against each other in 384 rays; the offset must shrink, not vanish
     assert float(t.detach().norm()) < 0.6 * 0.0877, t
+
+
+@pytest.mark.gpu
+def test_inerf_refinement_loop(dev):
+    """inerf.estimate_pose_inerf.pose_estimation (reference :23-195, 'random' pixel batches, Adam on the se(3) offset, MSE +
+    soft Dice on the opacity) over the HIP march forward/backward: from a pose 0.1 off, the refined pose is several times
+    closer to the pose the observation was rendered from."""
+    from iffnerf_amd.inerf.estimate_pose_inerf import pose_estimation
+    from iffnerf_amd import ray_utils as ru
+    model, _ = _load_small(dev, [0.05, 6.0])
+    H = W = 40
+    K = torch.tensor([[60.0, 0.0, W / 2], [0.0, 60.0, H / 2], [0.0, 0.0, 1.0]], device=dev)
+    cam = torch.tensor([2.3, 0.8, 1.0])
+    fwd = -cam / cam.norm()
+    right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0])); right = right / right.norm()
+    down = torch.linalg.cross(fwd, right)
+    c2w = torch.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, cam
+    c2w = c2w.to(dev)
+    d, dx, dy = ru.get_ray_directions_Ks(H, W, K[None])
+    unit = d / d.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        ro, rd, rad = ru.get_rays(unit, c2w, directions=d, dx=dx, dy=dy, keepdim=True)
+        rays = torch.cat((ro[0], torch.nn.functional.normalize(rd[0], dim=-1), rad[0]), -1).reshape(-1, 7)
+        rgb, _, acc, _, _, _ = model(rays, white_bg=False)
+    assert 0.15 < float((acc > 0.5).float().mean()) < 0.95                 # the object covers part of the frame
+    rgba = torch.cat((rgb, (acc > 0.5).float()[:, None]), -1).reshape(H, W, 4).cpu().numpy()
+    start = c2w.clone()
+    start[:3, 3] += torch.tensor([0.07, -0.06, 0.05], device=dev)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    import time
+    t0 = time.time()
+    loss, refined, trace = pose_estimation(start, rgba, K, model, sampling_strategy="random", batch_size=512, n_iters=250,
+                                           lrate=0.01, color_bkgd_aug="random", dice_loss=True, print_progress=False, device=dev)
+    print(f"iNeRF loop: {250 / (time.time() - t0):.0f} iterations/s at 512 rays x {model.nSamples} samples")
+    assert refined.shape == (4, 4) and refined.device.type == "cpu" and len(trace) == 250
+    before = float((start[:3, 3] - c2w[:3, 3]).norm())
+    after = float((refined[:3, 3] - c2w[:3, 3].cpu()).norm())
+    print(f"iNeRF refinement: translation error {before:.4f} -> {after:.4f}, final rgb loss {loss:.2e}")
+    assert after < 0.7 * before, (before, after)            # 40 x 40 pixels leave a translation / rotation trade-off
+    with pytest.raises(RuntimeError, match="OpenCV"):
+        pose_estimation(start, rgba, K, model, device=dev)

@@ -213,3 +213,38 @@ def test_ref_head_torch_formulation(golden):
         torch.testing.assert_close(mine, ref, rtol=0, atol=2e-5 * float(ref.abs().max()))
     d = dirs.clone().requires_grad_(True)
     assert head(None, d, feat, None)[0].requires_grad
+
+
+def test_inerf_host_pieces(golden):
+    """The host side of the iNeRF loop (inerf/inerf.py:64-92, ray_utils.py:28-100, inerf/dice_loss.py) against values and
+    gradients the reference produced (fixture G13)."""
+    from iffnerf_amd.inerf.inerf import CameraTransfer, vec2ss_matrix
+    from iffnerf_amd.inerf.dice_loss import SoftDiceLossV2
+    from iffnerf_amd import ray_utils as ru
+    t = lambda k: golden.t("g13_inerf_host", k)      # noqa: E731
+    ct = CameraTransfer(t("start"))
+    assert sorted(n for n, _ in ct.named_parameters()) == ["theta", "v", "w"] and float(ct.w.detach().abs().max()) < 1e-4
+    with torch.no_grad():
+        ct.w.copy_(t("cam_w")); ct.v.copy_(t("cam_v")); ct.theta.copy_(t("cam_theta"))
+    T = ct()
+    torch.testing.assert_close(T, t("T"), rtol=0, atol=1e-6)
+    for got, key in zip(torch.autograd.grad((T * t("c")).sum(), (ct.w, ct.v, ct.theta)), ("g_w", "g_v", "g_theta")):
+        torch.testing.assert_close(got, t(key), rtol=0, atol=2e-6)
+    k = vec2ss_matrix(torch.tensor([1.0, 2.0, 3.0]))
+    assert torch.equal(k, -k.T) and float(k[0, 1]) == -3.0 and float(k[0, 2]) == 2.0 and float(k[1, 2]) == -1.0
+    d, dx, dy = ru.get_ray_directions_Ks(24, 32, t("K"), use_pixel_centers=True)
+    for got, key in ((d, "dirs"), (dx, "dx"), (dy, "dy")):
+        torch.testing.assert_close(got, t(key), rtol=0, atol=1e-6)
+    unit = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+    ro, rd, rad = ru.get_rays(unit, t("T"), directions=d, dx=dx, dy=dy, keepdim=True)
+    for got, key in ((ro, "rays_o"), (rd, "rays_d"), (rad, "radii")):
+        torch.testing.assert_close(got, t(key), rtol=0, atol=1e-6)
+    flat = ru.get_rays(unit, t("T"))                     # keepdim=False, no radii
+    assert flat[0].shape == (24 * 32, 3) and torch.allclose(flat[1], rd.reshape(-1, 3))
+    logits = t("dice_logits").clone().requires_grad_(True)
+    loss = SoftDiceLossV2()(logits[..., None], t("dice_labels"))
+    torch.testing.assert_close(loss.detach(), t("dice_loss"), rtol=0, atol=1e-6)
+    torch.testing.assert_close(torch.autograd.grad(loss[0], logits)[0], t("dice_grad"), rtol=0, atol=1e-7)
+    from iffnerf_amd.inerf.estimate_pose_inerf import pose_estimation
+    with pytest.raises(RuntimeError, match="OpenCV"):
+        pose_estimation(torch.eye(4), np.zeros((4, 4, 4), np.float32), torch.eye(3), None, device="cpu")
