@@ -298,11 +298,17 @@ __global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance(FieldDev f, Mar
         }
         // basis_mat on the weighted sums: quarter c contributes a 12-term fmaf chain to each of the APP outputs; the
         // quarters are then added across the group by xor butterfly (fixed order: deterministic)
-        const float* basis_tile = s_basis;
-        asm volatile("" : "+v"(basis_tile));   // opaque per tile: keeps LLVM from hoisting the 324 weight reads out of the tile loop
+        // an opaque zero offset per tile keeps LLVM from hoisting the 324 weight reads out of the tile loop; the pointer stays
+        // LDS-typed so that they are ds_read_b128 (an opaque POINTER loses its address space: flat loads, which queue in the
+        // vector-memory pipe this kernel is bound by -- they were 23 % of its vector-memory instructions)
+        int opaque0 = 0;
+        asm volatile("" : "+v"(opaque0));
+        const lds_cfloat_p basis_tile = (lds_cfloat_p)s_basis + opaque0;
 #pragma unroll 1
         for (int oo = 0; oo < APP; ++oo) {
-            const float* bl = basis_tile + (oo * NL + c0) * 12;
+            const lds_cfloat4_p bq = (lds_cfloat4_p)(basis_tile + (oo * NL + c0) * 12);
+            const f32q b0 = bq[0], b1 = bq[1], b2 = bq[2];
+            const float bl[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
             float v = 0.0f;
 #pragma unroll
             for (int kk = 0; kk < 12; ++kk) v = fmaf(bl[kk], accp[kk], v);

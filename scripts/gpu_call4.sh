@@ -1,5 +1,9 @@
 #!/bin/bash
-# dev: ray-gradient checks
+# dev: K4b epilogue check
 mkdir -p gpurun_out
-python -m pytest tests/test_hip_dropin.py -m gpu -q -x -s -k "ray_gradients or pose_refinement" > gpurun_out/grad_tests.log 2>&1
-tail -40 gpurun_out/grad_tests.log
+python -m pytest tests/test_hip_field.py tests/test_hip_dropin.py tests/test_hip_fullsize.py -m gpu -q -x > gpurun_out/k4b_tests.log 2>&1 || { tail -40 gpurun_out/k4b_tests.log; exit 1; }
+tail -3 gpurun_out/k4b_tests.log
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/k4b_bench.log 2>&1
+tail -1 gpurun_out/k4b_bench.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'], {k:v.get('avg_launch_ms') for k,v in d['roofline']['other_kernels'].items()}, d['roofline']['avg_launch_ms'])"
