@@ -4,6 +4,7 @@
 #include "iff_device.h"
 #include "iff_launch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -81,6 +82,12 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     FieldDev& v = f->dev;
     memset(&v, 0, sizeof(v));
     const int G[3] = {d->grid[0], d->grid[1], d->grid[2]};
+    for (int i = 0; i < 3; ++i) {
+        // the gathers address a table by a 32-bit byte offset from its base (iff_device.h ld4_at)
+        const uint64_t texels = (uint64_t)G[mat_a(i)] * (uint64_t)G[mat_b(i)];
+        IFF_REQUIRE(texels * (uint64_t)std::max(d->n_density, d->n_app) * 4u < (1ull << 32),
+                    "VM plane %d has %llu texels: tables of 4 GiB and more are not addressable", i, (unsigned long long)texels);
+    }
     const HeadOff ho = head_offsets(d->app_dim, d->feature_c);
     // slab layout
     size_t off = 0, o_dp[3], o_dl[3], o_ap[3], o_al[3];

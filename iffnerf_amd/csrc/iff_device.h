@@ -178,9 +178,15 @@ __device__ inline void make_taps(const FieldDev& f, const float xn[3], int i, Ta
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// 16 B at a 32-bit BYTE offset from a table base: the base stays in scalar registers and the load takes the offset as is
+// (global_load ... v_off, s[base]) instead of two 64-bit vector adds per address.  Tables are < 4 GiB (checked at create).
+__device__ inline float4 ld4_at(const float* tab, int elem) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + ((unsigned)elem << 2));
+}
+
 __device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int ch) {
-    float4 nw = ld4(tab + (size_t)t.p_off[0] * C + ch), ne = ld4(tab + (size_t)t.p_off[1] * C + ch);
-    float4 sw = ld4(tab + (size_t)t.p_off[2] * C + ch), se = ld4(tab + (size_t)t.p_off[3] * C + ch);
+    float4 nw = ld4_at(tab, t.p_off[0] * C + ch), ne = ld4_at(tab, t.p_off[1] * C + ch);
+    float4 sw = ld4_at(tab, t.p_off[2] * C + ch), se = ld4_at(tab, t.p_off[3] * C + ch);
     float4 r;
     r.x = nw.x * t.p_w[0] + ne.x * t.p_w[1] + sw.x * t.p_w[2] + se.x * t.p_w[3];
     r.y = nw.y * t.p_w[0] + ne.y * t.p_w[1] + sw.y * t.p_w[2] + se.y * t.p_w[3];
@@ -190,7 +196,7 @@ __device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int
 }
 
 __device__ inline float4 lerp_line4(const float* tab, int C, const Taps& t, int ch) {
-    float4 lo = ld4(tab + (size_t)t.l_off[0] * C + ch), hi = ld4(tab + (size_t)t.l_off[1] * C + ch);
+    float4 lo = ld4_at(tab, t.l_off[0] * C + ch), hi = ld4_at(tab, t.l_off[1] * C + ch);
     float4 r;
     r.x = lo.x * t.l_w[0] + hi.x * t.l_w[1];
     r.y = lo.y * t.l_w[0] + hi.y * t.l_w[1];

@@ -222,25 +222,30 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
 #ifndef K4B_WAVES
 #define K4B_WAVES 4
 #endif
-template <int APP, bool SHORT>
-__global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance(FieldDev f, MarchArgs a, int64_t n_tiles) {
+template <int APP, bool SHORT, int RB>
+__global__ void __launch_bounds__((RB * 16 + 63) / 64 * 64, K4B_WAVES) k4b_appearance(FieldDev f, MarchArgs a, int64_t n_tiles) {
     extern __shared__ __align__(16) float smem[];
     constexpr int NL = 12;                         // n_app / 4 texel quarters = active lanes per group
     constexpr int G = 16;                          // lanes per ray group
-    constexpr int RB = 256 / G;                    // rays per workgroup tile
+    constexpr int NT = (RB * 16 + 63) / 64 * 64;   // threads: RB rays per workgroup tile, 16 lanes each
     constexpr int NW = (32 + G - 1) / G;           // weight registers per lane for S <= 32
     constexpr int LD = (APP + 3) & ~3;
     float* s_basis = smem;                         // [APP][NL][12]
     const int tid = threadIdx.x;
-    for (int i = tid; i < APP * NL * 12; i += 256) s_basis[i] = f.basis_l12[i];
+    for (int i = tid; i < APP * NL * 12; i += NT) s_basis[i] = f.basis_l12[i];
     __syncthreads();
     const int S = a.S;
     const int ray_l = tid / G, lg = tid % G;
     const int c0 = lg < NL ? lg : NL - 1;          // idle lanes shadow the last active lane's addresses (coalesced away)
     const float lane_on = lg < NL ? 1.0f : 0.0f;
+#ifdef K4B_CHUNK
+    const int64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    for (int64_t tile = blockIdx.x * per; tile < n_tiles && tile < (blockIdx.x + 1) * per; ++tile) {
+#else
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#endif
         const int64_t r = tile * RB + ray_l;
-        const bool live = r < a.R;
+        const bool live = r < a.R && ray_l < RB;
         float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
         if (live) {
             const float* rp = a.rays + r * a.ray_cols;
@@ -355,9 +360,16 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
+#ifdef K4B_FAN
+    const int64_t tiles_b = (R + 26) / 27;
+    grid = tiles_b < 256 * 8 ? tiles_b : 256 * 8;
+    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true, 27>), dim3((unsigned)grid), dim3(448), lds, s, f, a, tiles_b);
+    else hipLaunchKernelGGL((k4b_appearance<27, false, 27>), dim3((unsigned)grid), dim3(448), lds, s, f, a, tiles_b);
+#else
     grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
-    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
-    else hipLaunchKernelGGL((k4b_appearance<27, false>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
+    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
+    else hipLaunchKernelGGL((k4b_appearance<27, false, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
+#endif
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);

@@ -1,8 +1,8 @@
 #!/bin/bash
-# dev: K4b epilogue check
+# dev: full GPU suite + default bench
 mkdir -p gpurun_out
-python -m pytest tests/test_hip_field.py tests/test_hip_dropin.py tests/test_hip_fullsize.py -m gpu -q -x > gpurun_out/k4b_tests.log 2>&1 || { tail -40 gpurun_out/k4b_tests.log; exit 1; }
-tail -3 gpurun_out/k4b_tests.log
+python -m pytest tests -m gpu -q -x > gpurun_out/all_tests.log 2>&1 || { tail -40 gpurun_out/all_tests.log; exit 1; }
+tail -3 gpurun_out/all_tests.log
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/k4b_bench.log 2>&1
 tail -1 gpurun_out/k4b_bench.log | python -c "
 import json,sys
