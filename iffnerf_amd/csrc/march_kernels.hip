@@ -238,12 +238,7 @@ __global__ void __launch_bounds__((RB * 16 + 63) / 64 * 64, K4B_WAVES) k4b_appea
     const int ray_l = tid / G, lg = tid % G;
     const int c0 = lg < NL ? lg : NL - 1;          // idle lanes shadow the last active lane's addresses (coalesced away)
     const float lane_on = lg < NL ? 1.0f : 0.0f;
-#ifdef K4B_CHUNK
-    const int64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-    for (int64_t tile = blockIdx.x * per; tile < n_tiles && tile < (blockIdx.x + 1) * per; ++tile) {
-#else
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-#endif
         const int64_t r = tile * RB + ray_l;
         const bool live = r < a.R && ray_l < RB;
         float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
@@ -360,16 +355,9 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
-#ifdef K4B_FAN
-    const int64_t tiles_b = (R + 26) / 27;
-    grid = tiles_b < 256 * 8 ? tiles_b : 256 * 8;
-    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true, 27>), dim3((unsigned)grid), dim3(448), lds, s, f, a, tiles_b);
-    else hipLaunchKernelGGL((k4b_appearance<27, false, 27>), dim3((unsigned)grid), dim3(448), lds, s, f, a, tiles_b);
-#else
     grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
     if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
     else hipLaunchKernelGGL((k4b_appearance<27, false, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
-#endif
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);
