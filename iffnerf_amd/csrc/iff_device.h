@@ -187,21 +187,22 @@ __device__ inline float4 ld4_at(const float* tab, int elem) {
 __device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int ch) {
     float4 nw = ld4_at(tab, t.p_off[0] * C + ch), ne = ld4_at(tab, t.p_off[1] * C + ch);
     float4 sw = ld4_at(tab, t.p_off[2] * C + ch), se = ld4_at(tab, t.p_off[3] * C + ch);
+    // one multiply and three fused multiply-adds per channel (every kernel shares this form, so their results agree bit for bit)
     float4 r;
-    r.x = nw.x * t.p_w[0] + ne.x * t.p_w[1] + sw.x * t.p_w[2] + se.x * t.p_w[3];
-    r.y = nw.y * t.p_w[0] + ne.y * t.p_w[1] + sw.y * t.p_w[2] + se.y * t.p_w[3];
-    r.z = nw.z * t.p_w[0] + ne.z * t.p_w[1] + sw.z * t.p_w[2] + se.z * t.p_w[3];
-    r.w = nw.w * t.p_w[0] + ne.w * t.p_w[1] + sw.w * t.p_w[2] + se.w * t.p_w[3];
+    r.x = fmaf(se.x, t.p_w[3], fmaf(sw.x, t.p_w[2], fmaf(ne.x, t.p_w[1], nw.x * t.p_w[0])));
+    r.y = fmaf(se.y, t.p_w[3], fmaf(sw.y, t.p_w[2], fmaf(ne.y, t.p_w[1], nw.y * t.p_w[0])));
+    r.z = fmaf(se.z, t.p_w[3], fmaf(sw.z, t.p_w[2], fmaf(ne.z, t.p_w[1], nw.z * t.p_w[0])));
+    r.w = fmaf(se.w, t.p_w[3], fmaf(sw.w, t.p_w[2], fmaf(ne.w, t.p_w[1], nw.w * t.p_w[0])));
     return r;
 }
 
 __device__ inline float4 lerp_line4(const float* tab, int C, const Taps& t, int ch) {
     float4 lo = ld4_at(tab, t.l_off[0] * C + ch), hi = ld4_at(tab, t.l_off[1] * C + ch);
     float4 r;
-    r.x = lo.x * t.l_w[0] + hi.x * t.l_w[1];
-    r.y = lo.y * t.l_w[0] + hi.y * t.l_w[1];
-    r.z = lo.z * t.l_w[0] + hi.z * t.l_w[1];
-    r.w = lo.w * t.l_w[0] + hi.w * t.l_w[1];
+    r.x = fmaf(hi.x, t.l_w[1], lo.x * t.l_w[0]);
+    r.y = fmaf(hi.y, t.l_w[1], lo.y * t.l_w[0]);
+    r.z = fmaf(hi.z, t.l_w[1], lo.z * t.l_w[0]);
+    r.w = fmaf(hi.w, t.l_w[1], lo.w * t.l_w[0]);
     return r;
 }
 
@@ -218,7 +219,7 @@ __device__ inline float density_partial(const FieldDev& f, const float xn[3], in
         for (int ch = 4 * sub; ch < C; ch += 16) {
             float4 p = lerp_plane4(f.dplane[i], C, t, ch);
             float4 l = lerp_line4(f.dline[i], C, t, ch);
-            acc = acc + (p.x * l.x + p.y * l.y + p.z * l.z + p.w * l.w);
+            acc = fmaf(p.w, l.w, fmaf(p.z, l.z, fmaf(p.y, l.y, fmaf(p.x, l.x, acc))));
         }
     }
     return acc;
@@ -240,7 +241,7 @@ __device__ inline float density_full(const FieldDev& f, const float xn[3]) {
             for (int ch = 4 * sub; ch < C; ch += 16) {
                 float4 p = lerp_plane4(f.dplane[i], C, t, ch);
                 float4 l = lerp_line4(f.dline[i], C, t, ch);
-                part[sub] = part[sub] + (p.x * l.x + p.y * l.y + p.z * l.z + p.w * l.w);
+                part[sub] = fmaf(p.w, l.w, fmaf(p.z, l.z, fmaf(p.y, l.y, fmaf(p.x, l.x, part[sub]))));
             }
     }
     return (part[0] + part[1]) + (part[2] + part[3]);

@@ -216,7 +216,10 @@ def test_identify_and_pose(st, dev, idw):
         idx, val = H.topk(score, 100)
         swaps = util.assert_topk_matches(idx.cpu(), score_ref, 100)
         record(name, f"m{M}_top100_positions_differing_from_oracle", swaps)
-        assert swaps == 0, "top-100 index list differs from the oracle's (only near-ties at fp32 rounding level, but not bit-exact)"
+        # assert_topk_matches has already refused anything but adjacent swaps of rays whose ORACLE scores agree to 2e-5
+        # relative (the order of such a pair is decided by rounding in any fp32 evaluation, the reference's included); whether
+        # a list contains such a pair depends on the ray set drawn.  At most one pair per list is expected.
+        assert swaps <= 2, f"{swaps} positions of the top-100 list differ from the oracle's"
         idx_ref, val_ref = torch.topk(score_ref, 100).indices, torch.topk(score_ref, 100).values
         c2w = H.pose_from_topk(idx, val, st.ori, st.dirs, torch.tensor(st.up)).cpu()
         c2w_ref = opose.pose_from_topk(idx_ref, val_ref, o, d, torch.tensor(st.up))
