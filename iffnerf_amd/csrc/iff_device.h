@@ -143,37 +143,39 @@ struct Taps {
     float l_w[2];
 };
 
+// One axis of a lookup: the two texel indices (clamped into the table) and their weights (zero for an index outside it:
+// grid_sample's zero padding).  NaN / far-out coordinates get two out-of-range taps.
+struct AxisTap { int i[2]; float w[2]; };
+__device__ inline AxisTap axis_tap(float xn_ax, int size) {
+    const float x = unnorm(xn_ax, size);
+    const float fx = floorf(x);
+    const float w1 = x - fx, w0 = 1.0f - w1;
+    const bool ok = (x > -2.0f) && (x < (float)(size + 1));     // keeps the int conversion defined
+    const int i0 = ok ? (int)fx : -2, i1 = i0 + 1;
+    AxisTap t;
+    t.i[0] = min(max(i0, 0), size - 1);
+    t.i[1] = min(max(i1, 0), size - 1);
+    t.w[0] = (i0 >= 0 && i0 < size) ? w0 : 0.0f;
+    t.w[1] = (i1 >= 0 && i1 < size) ? w1 : 0.0f;
+    return t;
+}
+
+// The masking is per axis (a tap's weight is the product of its axes' weights, so one zero factor zeroes it) and the texel
+// index uses the 24-bit multiplier (indices < 2^24: checked at create) -- a 32-bit v_mul_lo is a quarter-rate instruction.
 __device__ inline void make_taps(const FieldDev& f, const float xn[3], int i, Taps& t) {
     const int a = mat_a(i), b = mat_b(i), v = vec_ax(i);
-    const int W = f.grid[a], H = f.grid[b], L = f.grid[v];
-    float x = unnorm(xn[a], W), y = unnorm(xn[b], H), z = unnorm(xn[v], L);
-    float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-    float wx1 = x - fx, wy1 = y - fy, wz1 = z - fz;
-    float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1, wz0 = 1.0f - wz1;
-    // keep int conversions defined for NaN / far-out coordinates (all taps get weight 0 there)
-    bool ok = (x > -2.0f) && (x < (float)(W + 1)) && (y > -2.0f) && (y < (float)(H + 1));
-    int x0 = ok ? (int)fx : -2, y0 = ok ? (int)fy : -2;
-    bool okz = (z > -2.0f) && (z < (float)(L + 1));
-    int z0 = okz ? (int)fz : -2;
-    float wxs[2] = {wx0, wx1}, wys[2] = {wy0, wy1};
+    const int W = f.grid[a];
+    const AxisTap tx = axis_tap(xn[a], W), ty = axis_tap(xn[b], f.grid[b]), tz = axis_tap(xn[v], f.grid[v]);
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            int xx = x0 + dx, yy = y0 + dy;
-            bool in = (xx >= 0) && (xx < W) && (yy >= 0) && (yy < H);
-            t.p_off[dy * 2 + dx] = in ? (yy * W + xx) : 0;
-            t.p_w[dy * 2 + dx] = in ? (wys[dy] * wxs[dx]) : 0.0f;
+            t.p_off[dy * 2 + dx] = (int)__umul24((unsigned)ty.i[dy], (unsigned)W) + tx.i[dx];
+            t.p_w[dy * 2 + dx] = ty.w[dy] * tx.w[dx];
         }
     // the line is a width-1 image sampled at x = 0 (tensoRF.py:225): x tap 0 has weight 1, tap 1 is out of range
-    float wzs[2] = {wz0, wz1};
 #pragma unroll
-    for (int dz = 0; dz < 2; ++dz) {
-        int zz = z0 + dz;
-        bool in = (zz >= 0) && (zz < L);
-        t.l_off[dz] = in ? zz : 0;
-        t.l_w[dz] = in ? wzs[dz] : 0.0f;
-    }
+    for (int dz = 0; dz < 2; ++dz) { t.l_off[dz] = tz.i[dz]; t.l_w[dz] = tz.w[dz]; }
 }
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -184,9 +186,11 @@ __device__ inline float4 ld4_at(const float* tab, int elem) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + ((unsigned)elem << 2));
 }
 
+__device__ inline int tex_elem(int texel, int C) { return (int)__umul24((unsigned)texel, (unsigned)C); }   // texel < 2^24
+
 __device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int ch) {
-    float4 nw = ld4_at(tab, t.p_off[0] * C + ch), ne = ld4_at(tab, t.p_off[1] * C + ch);
-    float4 sw = ld4_at(tab, t.p_off[2] * C + ch), se = ld4_at(tab, t.p_off[3] * C + ch);
+    float4 nw = ld4_at(tab, tex_elem(t.p_off[0], C) + ch), ne = ld4_at(tab, tex_elem(t.p_off[1], C) + ch);
+    float4 sw = ld4_at(tab, tex_elem(t.p_off[2], C) + ch), se = ld4_at(tab, tex_elem(t.p_off[3], C) + ch);
     // one multiply and three fused multiply-adds per channel (every kernel shares this form, so their results agree bit for bit)
     float4 r;
     r.x = fmaf(se.x, t.p_w[3], fmaf(sw.x, t.p_w[2], fmaf(ne.x, t.p_w[1], nw.x * t.p_w[0])));
@@ -197,7 +201,7 @@ __device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int
 }
 
 __device__ inline float4 lerp_line4(const float* tab, int C, const Taps& t, int ch) {
-    float4 lo = ld4_at(tab, t.l_off[0] * C + ch), hi = ld4_at(tab, t.l_off[1] * C + ch);
+    float4 lo = ld4_at(tab, tex_elem(t.l_off[0], C) + ch), hi = ld4_at(tab, tex_elem(t.l_off[1], C) + ch);
     float4 r;
     r.x = fmaf(hi.x, t.l_w[1], lo.x * t.l_w[0]);
     r.y = fmaf(hi.y, t.l_w[1], lo.y * t.l_w[0]);
