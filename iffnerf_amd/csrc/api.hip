@@ -83,7 +83,7 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     memset(&v, 0, sizeof(v));
     const int G[3] = {d->grid[0], d->grid[1], d->grid[2]};
     for (int i = 0; i < 3; ++i) {
-        // the gathers address a table by a 32-bit byte offset from its base (iff_device.h ld4_at)
+        // the gathers address a table by a 32-bit byte offset from its base (iff_device.h ld4_tex)
         const uint64_t texels = (uint64_t)G[mat_a(i)] * (uint64_t)G[mat_b(i)];
         IFF_REQUIRE(texels < (1ull << 24) && texels * (uint64_t)std::max(d->n_density, d->n_app) * 4u < (1ull << 32),
                     "VM plane %d has %llu texels: 2^24 texels / 4 GiB per table and more are not addressable", i,

@@ -146,6 +146,13 @@ struct Taps {
 // One axis of a lookup: the two texel indices (clamped into the table) and their weights (zero for an index outside it:
 // grid_sample's zero padding).  NaN / far-out coordinates get two out-of-range taps.
 struct AxisTap { int i[2]; float w[2]; };
+// a * b + c with the 24-bit multiplier (full rate; a 32-bit v_mul_lo is quarter rate and LLVM turns __umul24 by a scalar
+// back into one).  a, b in [0, 2^24), b wave-uniform.
+__device__ inline int mad24_uniform(int a, int b, int c) {
+    int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 __device__ inline AxisTap axis_tap(float xn_ax, int size) {
     const float x = unnorm(xn_ax, size);
     const float fx = floorf(x);
@@ -170,7 +177,7 @@ __device__ inline void make_taps(const FieldDev& f, const float xn[3], int i, Ta
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            t.p_off[dy * 2 + dx] = (int)__umul24((unsigned)ty.i[dy], (unsigned)W) + tx.i[dx];
+            t.p_off[dy * 2 + dx] = mad24_uniform(ty.i[dy], W, tx.i[dx]);
             t.p_w[dy * 2 + dx] = ty.w[dy] * tx.w[dx];
         }
     // the line is a width-1 image sampled at x = 0 (tensoRF.py:225): x tap 0 has weight 1, tap 1 is out of range
@@ -180,17 +187,17 @@ __device__ inline void make_taps(const FieldDev& f, const float xn[3], int i, Ta
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// 16 B at a 32-bit BYTE offset from a table base: the base stays in scalar registers and the load takes the offset as is
-// (global_load ... v_off, s[base]) instead of two 64-bit vector adds per address.  Tables are < 4 GiB (checked at create).
-__device__ inline float4 ld4_at(const float* tab, int elem) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + ((unsigned)elem << 2));
+// channels [ch, ch + 4) of texel `texel` of a channels-last table with C channels: the 32-bit byte offset texel * 4C + 4ch
+// in one 24-bit multiply-add (texel < 2^24, table < 4 GiB: checked at create); the table base stays in scalar registers
+// (global_load ... v_off, s[base]) -- no 64-bit vector address arithmetic
+__device__ inline float4 ld4_tex(const float* tab, int texel, int C, int ch) {
+    const unsigned off = (unsigned)mad24_uniform(texel, 4 * C, 4 * ch);
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + off);
 }
 
-__device__ inline int tex_elem(int texel, int C) { return (int)__umul24((unsigned)texel, (unsigned)C); }   // texel < 2^24
-
 __device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int ch) {
-    float4 nw = ld4_at(tab, tex_elem(t.p_off[0], C) + ch), ne = ld4_at(tab, tex_elem(t.p_off[1], C) + ch);
-    float4 sw = ld4_at(tab, tex_elem(t.p_off[2], C) + ch), se = ld4_at(tab, tex_elem(t.p_off[3], C) + ch);
+    float4 nw = ld4_tex(tab, t.p_off[0], C, ch), ne = ld4_tex(tab, t.p_off[1], C, ch);
+    float4 sw = ld4_tex(tab, t.p_off[2], C, ch), se = ld4_tex(tab, t.p_off[3], C, ch);
     // one multiply and three fused multiply-adds per channel (every kernel shares this form, so their results agree bit for bit)
     float4 r;
     r.x = fmaf(se.x, t.p_w[3], fmaf(sw.x, t.p_w[2], fmaf(ne.x, t.p_w[1], nw.x * t.p_w[0])));
@@ -201,7 +208,7 @@ __device__ inline float4 lerp_plane4(const float* tab, int C, const Taps& t, int
 }
 
 __device__ inline float4 lerp_line4(const float* tab, int C, const Taps& t, int ch) {
-    float4 lo = ld4_at(tab, tex_elem(t.l_off[0], C) + ch), hi = ld4_at(tab, tex_elem(t.l_off[1], C) + ch);
+    float4 lo = ld4_tex(tab, t.l_off[0], C, ch), hi = ld4_tex(tab, t.l_off[1], C, ch);
     float4 r;
     r.x = fmaf(hi.x, t.l_w[1], lo.x * t.l_w[0]);
     r.y = fmaf(hi.y, t.l_w[1], lo.y * t.l_w[0]);
