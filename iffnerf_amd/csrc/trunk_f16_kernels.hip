@@ -134,7 +134,14 @@ __device__ inline void trunk_load_w_h(WFragH<FG>& w, const uint4* __restrict__ W
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int fg = 0; fg < FG; ++fg) {
-            uint4 v = Wf[(((size_t)ks * 2 + pl) * 8 + FG * wave + fg) * 64 + lane];
+            // uniform base (scalar registers, advanced by scalar adds) + one 32-bit lane offset: no vector address arithmetic
+            typedef const __attribute__((address_space(1))) char* gchar_p;          // stays a GLOBAL pointer through the asm
+            typedef unsigned u32q __attribute__((ext_vector_type(4)));              // (HIP's uint4 class cannot be read through it)
+            typedef const __attribute__((address_space(1))) u32q* guint4_p;
+            gchar_p base = (gchar_p)(Wf + ((size_t)ks * 2 + pl) * 8 * 64);
+            asm("" : "+s"(base));          // pinned in scalar registers: LLVM would re-associate the constant onto the lane part
+            const unsigned voff = (unsigned)(((FG * wave + fg) * 64 + lane) * 16);
+            u32q v = *(guint4_p)(base + voff);
             w.p[fg][pl] = *reinterpret_cast<f16x8*>(&v);
         }
 }
