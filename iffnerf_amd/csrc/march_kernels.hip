@@ -321,6 +321,87 @@ __global__ void __launch_bounds__((RB * 16 + 63) / 64 * 64, K4B_WAVES) k4b_appea
     }
 }
 
+// ---- K4b for short rays (S <= 32: the point-centred sampler), FIVE rays per wave: a ray is served by 12 consecutive lanes (one
+// per 16-B quarter of the 192-B texels), so a wave-level gather returns 960 of its 1024 bytes instead of 768 -- the kernel is
+// bound by the number of vector-memory instructions (each returns 64 lanes x 16 B at 64 B/clk: 16 cycles of the CU's texture
+// path whatever its mask), and five rays per instruction are 20 % fewer of them per ray.  Same arithmetic per ray as
+// k4b_appearance; the 12 partial sums of basis_mat are added in a fixed tree (6 + 6, 3 + 3, then the three).
+template <int APP>
+__global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance12(FieldDev f, MarchArgs a, int64_t n_tiles) {
+    extern __shared__ __align__(16) float smem[];
+    constexpr int NL = 12, RW = 5, RB = 4 * RW, NW = 3, LD = (APP + 3) & ~3;
+    float* s_basis = smem;                         // [APP][NL][12]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < APP * NL * 12; i += 256) s_basis[i] = f.basis_l12[i];
+    __syncthreads();
+    const int S = a.S;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int g = lane / NL;                       // ray of the wave; 5 = the four spare lanes
+    const bool grp_on = g < RW;
+    const int c0 = grp_on ? lane - g * NL : 0;     // spare lanes shadow lane 0's addresses
+    const int g0 = grp_on ? g * NL : 0;            // first lane of this ray's group
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r = tile * RB + wave * RW + g;
+        const bool live = grp_on && r < a.R;
+        float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
+        if (live) {
+            const float* rp = a.rays + r * a.ray_cols;
+            o[0] = rp[0]; o[1] = rp[1]; o[2] = rp[2]; d[0] = rp[3]; d[1] = rp[4]; d[2] = rp[5];
+        }
+        float accp[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) accp[i] = 0.0f;
+        // lane c of a ray holds the weights of samples c, c + 12, c + 24; ballots give every ray its mask of shaded samples
+        float wreg[NW];
+        unsigned long long mask = 0ull;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int sj = c0 + NL * j;
+            wreg[j] = (live && sj < S) ? a.weights[r * S + sj] : 0.0f;
+            const unsigned long long bj = __ballot(wreg[j] > f.weight_thres);              // tensorBase.py:851
+            mask |= ((bj >> g0) & 0xfffull) << (NL * j);
+        }
+        if (!grp_on) mask = 0ull;
+        const bool any = mask != 0ull;
+        while (mask) {
+            const int sidx = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const int j = sidx >= 2 * NL ? 2 : (sidx >= NL ? 1 : 0);
+            const int src = g0 + (sidx - NL * j);
+            float w = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < NW; ++jj) {
+                const float vj = __shfl(wreg[jj], src, 64);
+                w = (j == jj) ? vj : w;
+            }
+            const float z = z_of(f, 0, S, 0.0f, sidx);
+            float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z}, xn[3];
+            field_normalize(f, p, xn);
+            float prod[12];
+            app_products_lane(f, xn, c0, prod);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) accp[i] = fmaf(w, prod[i], accp[i]);
+        }
+        int opaque0 = 0;
+        asm volatile("" : "+v"(opaque0));          // see k4b_appearance
+        const lds_cfloat_p basis_tile = (lds_cfloat_p)s_basis + opaque0;
+#pragma unroll 1
+        for (int oo = 0; oo < APP; ++oo) {
+            const lds_cfloat4_p bq = (lds_cfloat4_p)(basis_tile + (oo * NL + c0) * 12);
+            const f32q b0 = bq[0], b1 = bq[1], b2 = bq[2];
+            const float bl[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+            float v = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk) v = fmaf(bl[kk], accp[kk], v);
+            v += __shfl_down(v, 6, 64);             // lanes 0..5 of the group: quarters c and c + 6
+            v += __shfl_down(v, 3, 64);             // lanes 0..2
+            const float v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64);
+            if (c0 == 0 && live) a.feat[r * LD + oo] = (v + v1) + v2;
+        }
+        if (c0 == 0 && live) a.feat[r * LD + APP] = any ? 1.0f : 0.0f;
+    }
+}
+
 // ---- K4c (Ref head on the per-ray features, background blend, clamp) is k_ref_shade<APP, true> in field_kernels.hip.
 
 // workspace = compositing weights [R][S] followed by the per-ray features [R][28]
@@ -355,9 +436,15 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
-    grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
-    if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
-    else hipLaunchKernelGGL((k4b_appearance<27, false, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
+    if (mode == 0 && S <= 32) {
+        const int64_t tiles12 = (R + 19) / 20;
+        grid = tiles12 < 256 * 8 ? tiles12 : 256 * 8;
+        hipLaunchKernelGGL((k4b_appearance12<27>), dim3((unsigned)grid), dim3(256), lds, s, f, a, tiles12);
+    } else {
+        grid = a.n_tiles < 256 * 8 ? a.n_tiles : 256 * 8;
+        if (S <= 32) hipLaunchKernelGGL((k4b_appearance<27, true, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
+        else hipLaunchKernelGGL((k4b_appearance<27, false, 16>), dim3((unsigned)grid), dim3(256), lds, s, f, a, a.n_tiles);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);
