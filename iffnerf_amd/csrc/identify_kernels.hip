@@ -1197,48 +1197,44 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
 __global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int M, int64_t N, const float* __restrict__ row_max,
                                                  const float* __restrict__ row_sumexp, int write_attention,
                                                  float* __restrict__ score) {
-    extern __shared__ float s_stats[];   // [2][M] then [4][64] partials
-    float* s_part = s_stats + 2 * M;
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    // 256 ray columns per workgroup, 64 per wave, every wave over ALL token rows: the four waves read four adjacent 256-B
+    // pieces of the same rows (1 KiB of a row per workgroup at a time -- the logits stream from HBM, and a row is N floats
+    // long); a lane keeps four partial sums (rows i mod 4) and adds them pairwise at the end.
+    extern __shared__ float s_stats[];   // [2][M]
+    const int tid = threadIdx.x;
     {   // blockIdx.y = query of a batch: logits [Q][M][N], statistics [Q][M], score [Q][N]
         const int64_t qb = blockIdx.y;
         logits += qb * M * N; row_max += qb * M; row_sumexp += qb * M; score += qb * N;
     }
     for (int i = tid; i < M; i += 256) { s_stats[i] = row_max[i]; s_stats[M + i] = row_sumexp[i]; }
     __syncthreads();
-    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
-    const int per = (M + 3) / 4;
-    const int r0 = g * per, r1 = min(M, r0 + per);
-    float acc = 0.0f;
-    if (j < N) {
-        // 16 rows requested before the first is used: with one wave per SIMD the loop is latency-bound otherwise
-        int i = r0;
-        for (; i + 16 <= r1; i += 16) {
-            float x[16];
+    const int64_t j = (int64_t)blockIdx.x * 256 + tid;
+    if (j >= N) return;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int i = 0;
+    for (; i + 16 <= M; i += 16) {           // 16 rows requested before the first is used
+        float x[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = logits[(int64_t)(i + u) * N + j];
+        for (int u = 0; u < 16; ++u) x[u] = logits[(int64_t)(i + u) * N + j];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                float a = expf(x[u] - s_stats[i + u]) / s_stats[M + i + u];
-                if (write_attention) logits[(int64_t)(i + u) * N + j] = a;
-                acc += a;
-            }
-        }
-        for (; i < r1; ++i) {
-            float a = expf(logits[(int64_t)i * N + j] - s_stats[i]) / s_stats[M + i];
-            if (write_attention) logits[(int64_t)i * N + j] = a;
-            acc += a;
+        for (int u = 0; u < 16; ++u) {
+            const float a = expf(x[u] - s_stats[i + u]) / s_stats[M + i + u];
+            if (write_attention) logits[(int64_t)(i + u) * N + j] = a;
+            acc[u & 3] += a;
         }
     }
-    s_part[g * 64 + lane] = acc;
-    __syncthreads();
-    if (g == 0 && j < N) score[j] = (s_part[lane] + s_part[64 + lane]) + (s_part[128 + lane] + s_part[192 + lane]);
+    for (; i < M; ++i) {
+        const float a = expf(logits[(int64_t)i * N + j] - s_stats[i]) / s_stats[M + i];
+        if (write_attention) logits[(int64_t)i * N + j] = a;
+        acc[i & 3] += a;
+    }
+    score[j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 hipError_t launch_attn_colsum(float* logits, int Q, int M, int64_t N, const float* row_max, const float* row_sumexp,
                               int write_attention, float* score, hipStream_t s) {
     if (N == 0 || Q == 0) return hipSuccess;
-    hipLaunchKernelGGL(k6_colsum, dim3((unsigned)((N + 63) / 64), (unsigned)Q), dim3(256), (2 * (size_t)M + 256) * sizeof(float), s, logits,
+    hipLaunchKernelGGL(k6_colsum, dim3((unsigned)((N + 255) / 256), (unsigned)Q), dim3(256), 2 * (size_t)M * sizeof(float), s, logits,
                        M, N, row_max, row_sumexp, write_attention, score);
     return hipGetLastError();
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
-# dev: march tests + two bench repeats
+# dev: identify/sharded tests + two bench repeats
 mkdir -p gpurun_out
-python -m pytest tests/test_hip_field.py tests/test_hip_dropin.py tests/test_hip_fullsize.py tests/test_hip_sharded.py -m gpu -q -x > gpurun_out/all_tests.log 2>&1 || { tail -40 gpurun_out/all_tests.log; exit 1; }
+python -m pytest tests/test_hip_identify.py tests/test_hip_fullsize.py tests/test_hip_sharded.py tests/test_hip_dropin.py -m gpu -q -x > gpurun_out/all_tests.log 2>&1 || { tail -40 gpurun_out/all_tests.log; exit 1; }
 tail -2 gpurun_out/all_tests.log
 for i in 1 2; do
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/k4b_bench.log 2>&1
