@@ -373,9 +373,9 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                            "correction), same kernel sources" if fresh else
                            "null: profiles/r02_hbm_traffic.json was measured on other kernel sources or another --config (stale)"),
         "other_kernels": {
-            "k4b_appearance (appearance gather of TensorBase.forward)": {
+            "k4b_appearance12 (appearance gather of TensorBase.forward)": {
                 "bound": "hbm", "achieved": round(gbs_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs_b / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance<27, true>"),
+                "frac": round(gbs_b / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance12<27>", "k4b_appearance<27, true, 16>"),
                 "algorithmic_bytes_per_launch": round(bytes_b), "avg_launch_ms": round(march_launch_ms[1], 4),
                 "note": "algorithmic bytes = 3456 B per shaded sample (SURVEY 8d) x the kernel's own shaded-sample counter.  "
                         "frac > 1 against HBM means the gathers are served on chip (tables in L2 / Infinity Cache; `traffic` is "
