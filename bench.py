@@ -200,7 +200,8 @@ def main():
         launch = "3 hipGraph segments + 2 all_gathers per step (one emitted ray set, %d query images)" % B
     elif sharded:
         graphs = [pipe.capture_query_batch_sharded(tokens.shape, gen_points, seed=s, k=TOPK) for s in seeds]
-        launch = "4 hipGraph segments + 3 RCCL all_gathers per step (%d cold queries per rank, every ray set sharded over the ranks)" % B
+        launch = ("4 hipGraph segments + 3 RCCL all_gathers per step (%d cold queries per rank, every ray set sharded over the "
+                  "ranks), steps issued skewed by one segment") % B
     elif B > 1:
         graphs = [pipe.capture_query_batch(tokens.shape, gen_points, seed=s, k=TOPK) for s in seeds]
         launch = "one hipGraph replay per step (%d cold queries, each with its own ray set)" % B
@@ -215,12 +216,26 @@ def main():
         with torch.cuda.stream(streams[i % in_flight]):
             return graphs[i % in_flight].replay()
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, count):
+        """`count` whole steps.  Sharded batches are issued skewed by one segment (CapturedShardedBatch.replay_head): the head
+        of step i + 1 goes out before the tail of step i, every rank in the same order."""
+        if not (sharded and not shared and in_flight >= 2):
+            for i in range(first, first + count):
+                step(i)
+            return
+        def part(i, head):
+            with torch.cuda.stream(streams[i % in_flight]):
+                graphs[i % in_flight].replay_head() if head else graphs[i % in_flight].replay_tail()
+        part(first, True)
+        for i in range(first, first + count):
+            if i + 1 < first + count:
+                part(i + 1, True)
+            part(i, False)
+
+    run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run_steps(args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if sharded:

@@ -493,18 +493,29 @@ class CapturedShardedBatch:
     def check(self) -> None:
         check_sampler_stats(self.sampler_stats)
 
-    def replay(self, tokens: Optional[torch.Tensor] = None):
+    def replay_head(self, tokens: Optional[torch.Tensor] = None) -> None:
+        """Segment 1 (surface points of this rank's queries, folded queries) and its all_gather.  A serving loop issues the
+        head of step i + 1 BEFORE the tail of step i (each on its own stream and slot): the collectives of one process group
+        execute in issue order, so this puts step i + 1's first exchange ahead of step i's last two and lets its heavy
+        segment start under step i's latency-bound tail (small kernels + two exchanges) instead of after it."""
         from . import distributed as D
         if tokens is not None:
             self.tokens.copy_(tokens, non_blocking=True)
         self.g1.replay()
         D.all_gather_into(self.msg_all, self.msg, self.group)
+
+    def replay_tail(self):
+        from . import distributed as D
         self.g2.replay()
         D.all_gather_into(self.stats_all, self.stats, self.group)
         self.g3.replay()
         D.all_gather_into(self.cand_all, self.cand, self.group)
         self.g4.replay()
         return self.poses
+
+    def replay(self, tokens: Optional[torch.Tensor] = None):
+        self.replay_head(tokens)
+        return self.replay_tail()
 
 
 class CapturedImageQuery:

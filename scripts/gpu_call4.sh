@@ -1,12 +1,9 @@
 #!/bin/bash
-# dev: in-flight / batch sweep of the cold path
+# dev: sharded path at world size 1 (RCCL group of one) vs the single-GPU path
 mkdir -p gpurun_out
-: > gpurun_out/sweep.log
-for nf in 3 4 6; do
-  for b in 8 16 24; do
-    python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-instrument --in-flight $nf --batch $b 2>/dev/null | python -c "
+for extra in "" "--force-sharded"; do
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-instrument $extra > gpurun_out/k4b_bench.log 2>&1 || { tail -20 gpurun_out/k4b_bench.log; exit 1; }
+tail -1 gpurun_out/k4b_bench.log | python -c "
 import json,sys
-d=json.loads(sys.stdin.readlines()[-1]); print('in_flight $nf batch $b', d['value'], d['ms_per_step'])" >> gpurun_out/sweep.log || exit 1
-  done
+d=json.loads(sys.stdin.read()); print('$extra', d['value'], d['ms_per_step'], d['config']['launch'][:60])"
 done
-cat gpurun_out/sweep.log

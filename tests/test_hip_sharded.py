@@ -214,6 +214,22 @@ cq.tokens.copy_(mine)
 for rep in (1, 2):
     cq.replay(); torch.cuda.synchronize(); cq.check()
     out[f"replay{rep}"] = [cq.poses.cpu().clone(), cq.val.cpu().clone(), cq.idx.cpu().clone()]
+# two slots issued skewed by one segment, the way bench.py drives them: head(i + 1) before tail(i), each slot on its own stream
+cq2 = pipe.capture_query_batch_sharded(mine.shape, P, seed=1234, k=k)
+cq2.tokens.copy_(mine)
+slots, streams = [cq, cq2], [torch.cuda.Stream(), torch.cuda.Stream()]
+torch.cuda.synchronize()
+def part(i, head):
+    with torch.cuda.stream(streams[i % 2]):
+        slots[i % 2].replay_head() if head else slots[i % 2].replay_tail()
+part(0, True)
+for i in range(4):
+    if i + 1 < 4:
+        part(i + 1, True)
+    part(i, False)
+torch.cuda.synchronize(); cq.check(); cq2.check()
+out["skew_slot0"] = [cq.poses.cpu().clone(), cq.val.cpu().clone(), cq.idx.cpu().clone()]        # its 4th replay (counter 4)
+out["skew_slot1"] = [cq2.poses.cpu().clone(), cq2.val.cpu().clone(), cq2.idx.cpu().clone()]     # its 2nd replay (counter 2)
 # the shared-ray-set form (BASELINE configs[3]) through the same transport
 out["shared"] = [t.cpu() for t in pipe.query_sharded(tok_all, P, seed=55, k=k)]
 if rank == 0:
@@ -222,6 +238,9 @@ if rank == 0:
     for rep in (1, 2):
         ctr += 1
         want[f"replay{rep}"] = pipe.query_batch(tok_all, P, seed=1234, k=k, seed_offset=ctr)
+    want["skew_slot1"] = want["replay2"]
+    ctr += 2
+    want["skew_slot0"] = pipe.query_batch(tok_all, P, seed=1234, k=k, seed_offset=ctr)
     out["want"] = {key: [t.cpu() for t in v] for key, v in want.items()}
     out["want_shared"] = [torch.stack([pipe.query(tok_all[q], P, seed=55, k=k)[j] for q in range(2 * B)]).cpu() for j in range(3)]
 torch.save(out, sys.argv[4])
@@ -245,7 +264,7 @@ def test_two_real_ranks_on_one_gpu_over_gloo(tmp_path):
         assert p.returncode == 0 and "GLOO_2RANKS_OK" in so, so[-2000:] + se[-4000:]
     r = [torch.load(tmp_path / f"r{i}.pt") for i in range(2)]
     B = 2
-    for key in ("eager", "replay1", "replay2"):
+    for key in ("eager", "replay1", "replay2", "skew_slot0", "skew_slot1"):
         c2w, idx, val = r[0]["want"][key]
         for rank in range(2):
             poses, v, i = r[rank][key]
