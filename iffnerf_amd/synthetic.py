@@ -217,7 +217,7 @@ WORKLOADS = {
         field=dict(grid=(640, 640, 640), aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), mask_res=(256, 256, 256), seed=777,
                    step_ratio=0.5, peak=20.0, near_far=(0.01, 1.4), contraction_type="unisphere", density_shift=0.0,
                    density_offset=-10.0, blob_sigma=0.30, mask_radius=0.62),
-        gen_points=2371, queries=16, shared_rays=False,
+        gen_points=2371, queries=8, shared_rays=False,      # 8 x 47 sampler workgroups: two steps' samplers fit the device together
         describe="bicycle-shaped TensorVMSplit 640^3, unisphere contraction, density_shift 0, gen_points=2371 -> 64017 rays"),
     # configs[3]: "lego, batch of 64 query images, rays sharded across the GPUs": one emitted ray set per step
     "lego_b64": dict(
