@@ -360,6 +360,23 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                 return pmc["kernels"][key].get("hbm_bytes_per_launch")
         return None
 
+    def binding(ms, *keys):
+        """What bounds a gather kernel, from the counters of profiles/ and this run's launch time: the share of the HBM peak the
+        counter bytes make, and the busy shares of the two per-CU resources its instructions occupy (MI355X: 256 CUs x 4 SIMDs
+        at 2.4 GHz; a dwordx4 wave-load holds a CU's texture path for 16 cycles, a wave64 VALU instruction a SIMD for 4)."""
+        if not fresh or ms <= 0:
+            return None
+        for key in keys:
+            e = pmc.get("kernels", {}).get(key)
+            if e and "vmem_rd_wave_insts" in e:
+                cyc = ms * 1e-3 * 2.4e9
+                return {"hbm_frac_from_counters": round(e.get("hbm_bytes_per_launch", 0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "texture_path_busy": round(e["vmem_rd_wave_insts"] * 16.0 / 256.0 / cyc, 3),
+                        "valu_busy": round(e["valu_wave_insts"] * 4.0 / 1024.0 / cyc, 3),
+                        "l1_hit_rate": e.get("l1_hit_rate"), "l2_hit_rate": e.get("l2_hit_rate"),
+                        "wave_loads_per_launch": e["vmem_rd_wave_insts"], "valu_wave_insts_per_launch": e["valu_wave_insts"]}
+        return None
+
     rays_per_launch = ori.shape[0]
     pairs = rays_per_launch * (QT if shared else 1)          # (ray, query) pairs the launch scores
     t_ms = sum(trunk_ms) / max(len(trunk_ms), 1)
@@ -392,14 +409,16 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                 "bound": "hbm", "achieved": round(gbs_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs_b / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance12<27>", "k4b_appearance<27, true, 16>"),
                 "algorithmic_bytes_per_launch": round(bytes_b), "avg_launch_ms": round(march_launch_ms[1], 4),
+                "binding": binding(march_launch_ms[1], "k4b_appearance12<27>", "k4b_appearance<27, true, 16>"),
                 "note": "algorithmic bytes = 3456 B per shaded sample (SURVEY 8d) x the kernel's own shaded-sample counter.  "
                         "frac > 1 against HBM means the gathers are served on chip (tables in L2 / Infinity Cache; `traffic` is "
-                        "what crosses the L2's memory side); the binding resource and its counters are in DESIGN.md section 4 "
-                        "and profiles/"},
+                        "what crosses the L2's memory side, `binding.hbm_frac_from_counters` its share of the HBM peak).  The "
+                        "binding resource is the CU's texture path (`binding.texture_path_busy`: wave-level gathers x 16 cycles) "
+                        "together with the vector ALU (`binding.valu_busy`); DESIGN.md section 4"},
             "k4a_density_composite": {
                 "bound": "hbm", "achieved": round(gbs_a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs_a / HBM_PEAK_GBS, 4), "traffic": traffic("k4a_density_composite<1>"),
-                "algorithmic_bytes_per_launch": round(bytes_a), "avg_launch_ms": round(march_launch_ms[0], 4)},
+                "algorithmic_bytes_per_launch": round(bytes_a), "avg_launch_ms": round(march_launch_ms[0], 4), "binding": binding(march_launch_ms[0], "k4a_density_composite<1>", "k4a_density_composite<4>")},
             "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>")}}}
     if world_size == 1 and not shared:
         # warm path (rays resident: the reference's eval semantics, train_eval_pose_est.py:131-149): stage C only, 16 query

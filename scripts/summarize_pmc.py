@@ -16,6 +16,9 @@ SQ_BUSY_CYCLES; ratios of like units only):
   issue_stall_share   = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES            ... stalled at issue
   mfma_busy_share     = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMDs per CU ...)  reported raw, see profiles/README.md
   l2_hit_rate         = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
+  l1_hit_rate         = 1 - TCP_TCC_READ_REQ_sum / TCP_TOTAL_CACHE_ACCESSES_sum
+  vmem_rd_wave_insts, valu_wave_insts, mfma_wave_insts, lds_wave_insts = SQ_INSTS_* per launch (bench.py prices the gather
+                        kernels with them: 16 cycles of a CU's texture path per dwordx4 wave-load, 4 cycles of a SIMD per VALU)
 """
 import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
@@ -67,6 +70,12 @@ def main():
                             ("lds_active_share", "SQ_ACTIVE_INST_LDS"), ("vmem_active_share", "SQ_ACTIVE_INST_VMEM")):
                 if c in m:
                     e[name] = round(m[c] / wc, 4)
+        for name, c in (("vmem_rd_wave_insts", "SQ_INSTS_VMEM_RD"), ("valu_wave_insts", "SQ_INSTS_VALU"),
+                        ("mfma_wave_insts", "SQ_INSTS_MFMA"), ("lds_wave_insts", "SQ_INSTS_LDS")):
+            if c in m:
+                e[name] = int(m[c])
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in m and "TCP_TCC_READ_REQ_sum" in m and m["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
+            e["l1_hit_rate"] = round(1.0 - m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
         if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
             e["l2_hit_rate"] = round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"] > 0:
