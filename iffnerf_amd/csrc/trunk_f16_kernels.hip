@@ -382,9 +382,13 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
             write_planes(acc3, a.b3, a.inv3, a.s3);           // h3 planes
             __syncthreads();
         }
+        // gridDim.z workgroups share a ray tile's token blocks (many query images against one ray set: without the split a
+        // 16 011-ray set is 251 workgroups -- half the chip's workgroup slots -- however many images it serves)
         const int n_tb = a.Mpad / 256;
+        const int tb_per = (n_tb + (int)gridDim.z - 1) / (int)gridDim.z;
+        const int tb0 = (int)blockIdx.z * tb_per, tb1 = min(n_tb, tb0 + tb_per);
         const float divisor = a.divisor, inv_div = 1.0f / divisor;
-        for (int tb = 0; tb < n_tb; ++tb) {
+        for (int tb = tb0; tb < tb1; ++tb) {
             zero(acc);
             phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, yes_t{}, acc,
                   a.Qf + (size_t)tb * (KH * 2 * 8 * 64), acc, a.Qf);
@@ -470,6 +474,21 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
 //          2 -> 8 waves x 32 features, 128 rays (half the weight stream per ray)
 int trunk_h_rays_per_wg(int variant) { return variant == 2 ? 128 : 64; }
 
+// workgroups per ray tile for the token blocks of a logits launch: enough that tiles x ray sets x split fills the chip's
+// workgroup slots about twice (2 per CU), never more than the blocks there are; `recompute`: every split workgroup of the
+// fused launch runs the encoder again (300 of its 300 + 96 n MFMAs per wave), so it is split only while that stays < 25 %
+static unsigned token_split(int64_t tiles, int B, int n_tb, bool recompute) {
+    int64_t want = (1024 + tiles * B - 1) / (tiles * B);
+    if (want > n_tb) want = n_tb;
+    if (recompute) {
+        const int64_t cap = n_tb / 8;            // >= 8 blocks per workgroup: encoder share 300 / (300 + 96 * 8) = 28 %
+        if (want > cap) want = cap;
+    }
+    if (want < 1) want = 1;
+    const int64_t per = (n_tb + want - 1) / want;          // blocks per workgroup; no workgroup without a block
+    return (unsigned)((n_tb + per - 1) / per);
+}
+
 static TrunkHArgs base_args(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N) {
     TrunkHArgs a;
     a.ray_o = o; a.ray_d = d; a.ray_c = rgb; a.N = N;
@@ -513,7 +532,8 @@ hipError_t launch_trunk_h_logits(const IdNetDev& n, const float* o, const float*
     a.Qf = (const uint4*)Qf; a.qscale = qscale; a.rowc = qf + HC; a.rowc_ld = n.qf_ld; a.M = M; a.divisor = divisor;
     a.logits = logits; a.part = part; a.Mpad = Mpad;
     const int TR = trunk_h_rays_per_wg(n.trunk_variant);
-    return launch_variant<1>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
+    const int64_t tiles = (N + TR - 1) / TR;
+    return launch_variant<1>(n.trunk_variant, dim3((unsigned)tiles, (unsigned)B, token_split(tiles, B, n_tb, true)), a, s);
 }
 
 // The per-model cache: the encoder's last hidden activation as fp16 hi/lo planes [2][N][256] (1 KB per ray),
@@ -537,5 +557,6 @@ hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, i
     a.Qf = (const uint4*)Qf; a.qscale = qscale; a.rowc = qf + HC; a.rowc_ld = n.qf_ld; a.M = M; a.divisor = divisor;
     a.logits = logits; a.part = part; a.Mpad = Mpad;
     const int TR = trunk_h_rays_per_wg(n.trunk_variant);
-    return launch_variant<3>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), 1u), a, s);
+    const int64_t tiles = (N + TR - 1) / TR;
+    return launch_variant<3>(n.trunk_variant, dim3((unsigned)tiles, 1u, token_split(tiles, 1, n_tb, false)), a, s);
 }

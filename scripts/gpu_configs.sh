@@ -20,10 +20,9 @@ except Exception as e:
     print('  parse failed', e)
 PY
 }
-timeout -k 10 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
 run lego16k --steps 100 --warmup 10 --no-cpu-baseline
-
-
-
-
-
+run truck32k --config truck32k --steps 40 --warmup 5 --no-cpu-baseline
+run bicycle64k --config bicycle64k --steps 30 --warmup 5 --no-cpu-baseline
+run lego_b64 --config lego_b64 --steps 60 --warmup 10 --no-cpu-baseline
+run lego16k_sharded_ws1 --steps 100 --warmup 10 --no-cpu-baseline --no-instrument --force-sharded
+run lego_b64_sharded_ws1 --config lego_b64 --steps 60 --warmup 10 --no-cpu-baseline --no-instrument --force-sharded
