@@ -2,7 +2,7 @@
 of a random pixel batch rendered through the field.
 
 Per iteration the reference builds all H*W rays and indexes the batch (:151-163); here only the batch's pixels are
-transformed (same values).  ``model(rays_chunk, bg_color=..., is_train=False)`` is the HIP slab march with its HIP backward
+transformed (same values), and from the fourth iteration on an iteration is one hipGraph replay.  ``model(rays_chunk, bg_color=..., is_train=False)`` is the HIP slab march with its HIP backward
 (``TensorBase._forward_ray_grad``); everything around it is a handful of small torch ops on the GPU.
 """
 import time
@@ -14,6 +14,12 @@ import torch.nn.functional as F
 from ..ray_utils import get_ray_directions_Ks, get_rays
 from .dice_loss import SoftDiceLossV2
 from .inerf import CameraTransfer, img2mse
+
+
+# Iterations after the first CAPTURE_AFTER run as replays of ONE captured hipGraph (gather of the pixel batch, rays, HIP march
+# forward, Ref head, losses, autograd with the HIP march backward, Adam): the eager loop is ~150 kernel launches per
+# iteration and launch-bound.  Set to None to keep every iteration eager (same arithmetic, same random streams).
+CAPTURE_AFTER = 3
 
 
 def pose_estimation(start_pose: torch.Tensor, obs_img: np.ndarray, cam_K: torch.Tensor, model,
@@ -29,30 +35,30 @@ def pose_estimation(start_pose: torch.Tensor, obs_img: np.ndarray, cam_K: torch.
     H, W = obs_img.shape[0], obs_img.shape[1]
     if batch_size > H * W:
         raise RuntimeError(f"batch_size {batch_size} exceeds the image's {H * W} pixels")
-    start_pose = torch.as_tensor(start_pose, device=device)
-    cam_transf = CameraTransfer(start_pose).to(device)
+    dev = torch.device(device)
+    start_pose = torch.as_tensor(start_pose, device=dev)
+    cam_transf = CameraTransfer(start_pose).to(dev)
     opt_cls = torch.optim.Adam if optimizer_type == "adam" else torch.optim.AdamW
-    optimizer = opt_cls(params=cam_transf.parameters(), lr=lrate, betas=(0.9, 0.999))
+    on_gpu = dev.type == "cuda"
+    lr_t = torch.tensor(float(lrate), device=dev)                     # a tensor: the captured step reads it from memory
+    optimizer = opt_cls(params=cam_transf.parameters(), lr=lr_t, betas=(0.9, 0.999), capturable=on_gpu)
     dice = SoftDiceLossV2()
-    K = torch.as_tensor(cam_K, dtype=torch.float32, device=device)
+    K = torch.as_tensor(cam_K, dtype=torch.float32, device=dev)
     K = K[None] if K.dim() == 2 else K
     raw_dirs, dx, dy = get_ray_directions_Ks(H, W, K, use_pixel_centers=True)
     unit_dirs = raw_dirs / torch.linalg.norm(raw_dirs, dim=-1, keepdim=True)
-    obs = torch.from_numpy(np.ascontiguousarray(obs_img)).to(device)
-    poses, rgb_loss = [], torch.zeros(())
-    start = time.time()
-    for k in range(n_iters):
-        optimizer.zero_grad()
-        pick = np.random.choice(H * W, size=batch_size, replace=False)                  # :108-112
-        py, px = torch.from_numpy(pick // W).to(device), torch.from_numpy(pick % W).to(device)
+    obs = torch.from_numpy(np.ascontiguousarray(obs_img)).to(dev)
+    # static inputs / outputs of one iteration
+    py = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+    px = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+    bkgd = torch.zeros(3, dtype=obs.dtype, device=dev)
+    out_loss = torch.zeros((), dtype=torch.float32, device=dev)
+    out_pose = torch.zeros(4, 4, dtype=start_pose.dtype, device=dev)
+
+    def iteration():
+        optimizer.zero_grad(set_to_none=True)
         target = obs[py, px]
         rgb_t, alpha_t = target[..., :3], target[..., 3:4]
-        if color_bkgd_aug == "white":
-            bkgd = torch.ones(3, dtype=target.dtype, device=device)
-        elif color_bkgd_aug == "random":
-            bkgd = torch.rand(3, dtype=target.dtype, device=device)
-        else:
-            bkgd = torch.zeros(3, dtype=target.dtype, device=device)
         target_rgb = rgb_t * alpha_t + bkgd * (1.0 - alpha_t)
         pose = cam_transf()
         rays_o, rays_d, radii = get_rays(unit_dirs[0, py, px], pose, directions=raw_dirs[0, py, px], dx=dx[0, py, px],
@@ -65,11 +71,40 @@ def pose_estimation(start_pose: torch.Tensor, obs_img: np.ndarray, cam_K: torch.
             loss = loss + dice(torch.clamp(opacity, 1.0e-3, 1.0 - 1.0e-3)[..., None], alpha_t)[0]
         loss.backward()
         optimizer.step()
-        poses.append(cam_transf().detach().to(device="cpu", non_blocking=True))
-        for group in optimizer.param_groups:
-            group["lr"] = lrate * (0.8 ** ((k + 1) / 100))
+        out_loss.copy_(rgb_loss.detach())
+        with torch.no_grad():
+            out_pose.copy_(cam_transf())
+
+    trace = torch.zeros(max(n_iters, 1), 4, 4, dtype=start_pose.dtype)
+    if on_gpu:
+        trace = trace.pin_memory()
+    graph = None
+    start = time.time()
+    for k in range(n_iters):
+        pick = np.random.choice(H * W, size=batch_size, replace=False)                  # :108-112
+        py.copy_(torch.from_numpy(pick // W), non_blocking=True)
+        px.copy_(torch.from_numpy(pick % W), non_blocking=True)
+        if color_bkgd_aug == "white":
+            bkgd.fill_(1.0)
+        elif color_bkgd_aug == "random":
+            bkgd.copy_(torch.rand(3, dtype=obs.dtype, device=dev))
+        else:
+            bkgd.zero_()
+        if on_gpu and CAPTURE_AFTER is not None and k == CAPTURE_AFTER and graph is None:
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                iteration()
+        if graph is not None:
+            graph.replay()
+        else:
+            iteration()
+        trace[k].copy_(out_pose, non_blocking=True)
+        lr_t.fill_(lrate * (0.8 ** ((k + 1) / 100)))
         if ((k + 1) % 20 == 0 or k == 0) and print_progress:
-            print(f"[{k}] Loss: {rgb_loss.item()}")
+            print(f"[{k}] Loss: {out_loss.item()}")
+    if on_gpu:
+        torch.cuda.synchronize(dev)
     if print_progress:
         print(f"Total optimization time: {time.time() - start:.02f} s")
-    return rgb_loss.item(), cam_transf().detach().cpu(), poses
+    return out_loss.item(), out_pose.detach().cpu(), [trace[k].clone() for k in range(n_iters)]

@@ -37,7 +37,7 @@ class CameraTransfer(torch.nn.Module):
         rot = eye + s * K + (1 - c) * K2
         trans = (eye * self.theta + (1 - c) * K + (self.theta - s) * K2) @ self.v.to(dt)
         top = torch.cat((rot, trans[:, None]), dim=1)
-        bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=dt, device=dev)
+        bottom = torch.cat((torch.zeros(1, 3, dtype=dt, device=dev), torch.ones(1, 1, dtype=dt, device=dev)), dim=1)   # no host copy: capturable
         return torch.cat((top, bottom), dim=0) @ self.start_pose
 
 

@@ -47,6 +47,7 @@ class Ref(torch.nn.Module):
             raise RuntimeError("Ref: only the configuration the reference instantiates (deg_view=4, predicted normals, "
                                "no rgb premultiplier/bias; models/tensorBase.py:339-342) is built")
         self.dir_enc_fn = IntegratedDirEnc(deg_view)
+        self.deg_view = deg_view
         self.rgb_padding = 0.001
         self.in_mlpC = (3 + 2 * viewpe * 3) + in_channels
         self.viewpe = viewpe
@@ -100,7 +101,7 @@ class Ref(torch.nn.Module):
         ml, mat = self.dir_enc_fn.ml_array, self.dir_enc_fn.mat                                # [2,19] (m, l), [9,19]
         x, y, z = refl[..., 0:1], refl[..., 1:2], refl[..., 2:3]
         re, im, zp = [torch.ones_like(x)], [torch.zeros_like(x)], [torch.ones_like(z)]
-        for _ in range(int(ml[0].max())):
+        for _ in range(2 ** (self.deg_view - 1)):        # largest m of the (m, l) table: l = 1, 2, .., 2^(deg_view-1), m <= l (no host read)
             re, im = re + [re[-1] * x - im[-1] * y], im + [re[-1] * y + im[-1] * x]
         for _ in range(mat.shape[0] - 1):
             zp.append(zp[-1] * z)

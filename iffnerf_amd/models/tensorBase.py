@@ -282,10 +282,10 @@ class TensorBase(torch.nn.Module):
         S = int(N_samples) if N_samples > 0 else (20 if point else h.n_samples_default)
         feat28, depth, acc = _MarchFeatures.apply(rays_chunk, h, mode, S)
         d = rays_chunk[:, 3:6]
-        rows = torch.nonzero(feat28[:, 27] > 0)[:, 0]                                          # rays_to_consider, :887
-        rgb = torch.zeros(rays_chunk.shape[0], 3, dtype=acc.dtype, device=acc.device)
-        if rows.numel():
-            rgb = rgb.index_put((rows,), self.renderModule.forward_autograd(d[rows], feat28[rows, :27]))
+        # rays_to_consider (:887) as a mask instead of an index list: no host synchronisation, so the whole iNeRF iteration
+        # can be captured in a hipGraph; the head of an unshaded ray (F = 0) is finite and its gradient is masked out
+        considered = (feat28[:, 27] > 0)[:, None]
+        rgb = torch.where(considered, self.renderModule.forward_autograd(d, feat28[:, :27]), torch.zeros((), device=acc.device))
         if bg_color is None:
             bg_color = torch.ones(3, device=rgb.device) if white_bg else torch.zeros(3, device=rgb.device)
         rgb = (rgb * acc[..., None] + torch.as_tensor(bg_color, device=rgb.device) * (1.0 - acc[..., None])).clamp(0, 1)
