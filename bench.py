@@ -475,6 +475,23 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                 igraphs[i % 4].replay()
         torch.cuda.synchronize(device)
         result["image_to_pose_per_s"] = round(n_i * WQ / (time.perf_counter() - ti), 2)
+        # the same with the backbone's matrix products in bf16 (torch.autocast): a throughput option of the third-party model
+        del igraphs
+        fe16 = ImageFrontEnd(net, grid, backbone_autocast=torch.bfloat16)
+        igraphs = [CapturedImageQuery(pipe, fe16, imgs.shape, resident, TOPK) for _ in range(4)]
+        for g in igraphs:
+            g.imgs.copy_(imgs), g.masks.copy_(masks)
+        torch.cuda.synchronize(device)
+        for i in range(8):
+            with torch.cuda.stream(wstreams[i % 4]):
+                igraphs[i % 4].replay()
+        torch.cuda.synchronize(device)
+        ti = time.perf_counter()
+        for i in range(n_i):
+            with torch.cuda.stream(wstreams[i % 4]):
+                igraphs[i % 4].replay()
+        torch.cuda.synchronize(device)
+        result["image_to_pose_per_s_bf16_backbone"] = round(n_i * WQ / (time.perf_counter() - ti), 2)
         result["image_to_pose_note"] = ("16 synthetic 800x800 RGBA queries per captured graph: bicubic resize / crop / normalise + ViT-S/14 "
                                         "stand-in (seeded random weights, DINOv2's architecture, fp32 torch module) + token assembly kernel "
                                         "+ stage C on resident rays with the cached encoder; 4 graphs in flight; never part of `value`")

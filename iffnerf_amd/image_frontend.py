@@ -60,8 +60,13 @@ def mask_token_rows(keep: torch.Tensor, row_max: torch.Tensor, row_sumexp: torch
 class ImageFrontEnd:
     """Resize / crop / normalise + backbone + token assembly for a batch of query images, all on the device."""
 
-    def __init__(self, backbone: torch.nn.Module, grid=(16, 16), resize_size: int = 256, crop_size: int = 224):
+    def __init__(self, backbone: torch.nn.Module, grid=(16, 16), resize_size: int = 256, crop_size: int = 224,
+                 backbone_autocast: Optional[torch.dtype] = None):
+        """``backbone_autocast``: None runs the backbone as it is (fp32: the reference's arithmetic); ``torch.bfloat16`` /
+        ``torch.float16`` runs its matrix products under ``torch.autocast`` -- a throughput option of the third-party model, not
+        parity-equivalent (token features move by ~1e-2 relative)."""
         self.backbone, self.grid, self.resize_size, self.crop_size = backbone, (int(grid[0]), int(grid[1])), resize_size, crop_size
+        self.backbone_autocast = backbone_autocast
         self._norm = {}      # device -> (mean, std): made once, outside any capture (a host->device copy cannot be captured)
 
     def _mean_std(self, x):
@@ -77,7 +82,11 @@ class ImageFrontEnd:
         The same arithmetic as identification_module.py:130-160 (``transformations`` / ``mask_transformations`` of the mirror)."""
         x = _center_crop(_resize_short_edge(imgs.permute(0, 3, 1, 2), self.resize_size, "bicubic"), self.crop_size)
         mean, std = self._mean_std(x)
-        feats = self.backbone.forward_features((x - mean) / std)["x_norm_patchtokens"]
+        if self.backbone_autocast is None:
+            feats = self.backbone.forward_features((x - mean) / std)["x_norm_patchtokens"]
+        else:
+            with torch.autocast(device_type="cuda", dtype=self.backbone_autocast):
+                feats = self.backbone.forward_features((x - mean) / std)["x_norm_patchtokens"]
         mg = None
         if masks is not None:
             m = _center_crop(_resize_short_edge(masks[:, None] * 1.0, self.resize_size, "bilinear"), self.crop_size)

@@ -131,3 +131,14 @@ def test_image_in_pose_out_capture(dev, monkeypatch):
         cq.replay(imgs, masks)
         torch.cuda.synchronize()
         assert torch.equal(cq.idx, idx) and torch.equal(cq.val, val) and torch.equal(cq.c2w, c2w)
+    # the bf16-autocast option of the backbone: same masks, token features within bf16's reach of the fp32 ones, and a
+    # capturable graph of its own (a throughput option: it is not parity-equivalent and nothing else uses it)
+    fe16 = ImageFrontEnd(net, grid, backbone_autocast=torch.bfloat16)
+    tok16, keep16 = fe16.tokens(imgs, masks)
+    assert tok16.dtype == torch.float32 and torch.equal(keep16, keep) and torch.equal(tok16[..., 384:], tokens[..., 384:])
+    rel = (tok16[..., :384] - tokens[..., :384]).norm() / tokens[..., :384].norm()
+    assert 0 < float(rel) < 3e-2, float(rel)
+    cq16 = CapturedImageQuery(pipe, fe16, imgs.shape, rays, 100)
+    cq16.replay(imgs, masks)
+    torch.cuda.synchronize()
+    assert torch.isfinite(cq16.c2w).all() and cq16.idx.shape == idx.shape
