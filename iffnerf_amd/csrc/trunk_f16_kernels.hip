@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
     // prefetch, the other waves of the SIMD cover the latency instead
     constexpr bool LEAN = (FG == 1 && RG == 2);
     constexpr int DEPTH_DUAL = LEAN ? 2 : 3, DEPTH_ONE = LEAN ? 3 : 4;
+    constexpr int DEPTH_LOGITS = LEAN ? 6 : 4;       // acc3 is dead by then: its 32 registers hold query fragments further ahead
 
     if (MODE != 3) {
         // layer 1 and the x-part of layer 3, one pass over x
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
         const float divisor = a.divisor, inv_div = 1.0f / divisor;
         for (int tb = tb0; tb < tb1; ++tb) {
             zero(acc);
-            phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, yes_t{}, acc,
+            phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_LOGITS>{}, no_t{}, yes_t{}, acc,
                   a.Qf + (size_t)tb * (KH * 2 * 8 * 64), acc, a.Qf);
             // tile: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 32 FG wave + 32 tg + lr
 #pragma unroll
