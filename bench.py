@@ -219,6 +219,8 @@ def main():
     def run_steps(first, count):
         """`count` whole steps.  Sharded batches are issued skewed by one segment (CapturedShardedBatch.replay_head): the head
         of step i + 1 goes out before the tail of step i, every rank in the same order."""
+        if count <= 0:
+            return
         if not (sharded and not shared and in_flight >= 2):
             for i in range(first, first + count):
                 step(i)
