@@ -933,12 +933,10 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
 // once and read by the four waves (row half x column half), instead of every 16 x 16 output tile streaming its own 51 KB
 // of operands from L2 as k_gemm_small does -- that kernel stays for a single image's <= 256 rows, where it has 4x the
 // workgroups.  NTW = 16-column tiles per wave (ceil(Nout / 32)).
-template <int NTW, int BK>
+template <int NTW>
 __global__ void __launch_bounds__(256) k_gemm_tokens(const float* __restrict__ A, int K, int K_pad, const float* __restrict__ Wt,
                                                      int Nout, const float* __restrict__ bias, float* __restrict__ Y, int M) {
-    // BK = k depth of a staged tile: the loop is a chain of (L2 latency -> LDS -> barrier -> a few MFMAs) per tile with one
-    // workgroup per CU, so fewer, deeper tiles shorten it (32: 13 trips for K = 400 instead of 25)
-    constexpr int A_LD = 33, NA = BK / 8, NB = 7 * BK / 16;
+    constexpr int BK = 16, A_LD = 33;
     extern __shared__ float smem_tok[];
     float* As = smem_tok;                        // [BK][A_LD]   (k-major: As[k][row])
     float* Bs = smem_tok + BK * A_LD;            // [BK][Nout]
@@ -953,26 +951,25 @@ __global__ void __launch_bounds__(256) k_gemm_tokens(const float* __restrict__ A
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int n4 = Nout / 4, nb4 = BK * n4;      // float4s of one Wt k-tile
-    // staging registers: A 32 rows x BK k -> NA per thread; Wt k-tile: ceil(nb4 / 256) float4 per thread (<= NB)
-    const int arow = tid >> 3, ak = (tid & 7) * NA;
-    float a_reg[NA];
-    float4 b_reg[NB];
+    // staging registers: A 32 rows x 16 k = 512 floats -> 2 per thread; Wt k-tile: ceil(nb4 / 256) float4 per thread (<= 7)
+    const int arow = tid >> 3, ak = (tid & 7) * 2;
+    float a_reg[2];
+    float4 b_reg[7];
     auto load_tile = [&](int k0) {
         const int gr = m0 + arow;
 #pragma unroll
-        for (int e = 0; e < NA; ++e) a_reg[e] = (gr < M && k0 + ak + e < K) ? A[(size_t)gr * K + k0 + ak + e] : 0.0f;
+        for (int e = 0; e < 2; ++e) a_reg[e] = (gr < M && k0 + ak + e < K) ? A[(size_t)gr * K + k0 + ak + e] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
+        for (int u = 0; u < 7; ++u) {
             const int f = tid + u * 256;
-            const bool ok = f < nb4 && k0 + f / n4 < K_pad;
-            b_reg[u] = ok ? *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + f / n4) * Nout + 4 * (f % n4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b_reg[u] = f < nb4 ? *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + f / n4) * Nout + 4 * (f % n4)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_tile = [&]() {
+        As[(ak + 0) * A_LD + arow] = a_reg[0];
+        As[(ak + 1) * A_LD + arow] = a_reg[1];
 #pragma unroll
-        for (int e = 0; e < NA; ++e) As[(ak + e) * A_LD + arow] = a_reg[e];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
+        for (int u = 0; u < 7; ++u) {
             const int f = tid + u * 256;
             if (f < nb4) *reinterpret_cast<float4*>(Bs + (size_t)(f / n4) * Nout + 4 * (f % n4)) = b_reg[u];
         }
@@ -985,7 +982,6 @@ __global__ void __launch_bounds__(256) k_gemm_tokens(const float* __restrict__ A
         if (k0 + BK < K_pad) load_tile(k0 + BK);      // in flight while this tile is multiplied
 #pragma unroll
         for (int k4 = 0; k4 < BK; k4 += 4) {
-            if (k0 + k4 >= K_pad) break;                       // K_pad is a multiple of 16: the last deep tile may be half full
             const float av = As[(k4 + kk) * A_LD + rh * 16 + r];
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
@@ -1012,11 +1008,10 @@ static hipError_t gemm_tokens(const float* A, int K, int K_pad, const float* Wt,
     // many rows: the LDS-tiled form; few rows (one image): one wave per 16 x 16 tile fills the chip better
     const int NT = Nout / 16;
     if (M > 512 && Nout % 16 == 0 && Nout / 4 * 16 <= 7 * 256 && (NT + 1) / 2 <= 12) {
-        constexpr int BK = 32;
-        const size_t lds = (size_t)(BK * 33 + BK * Nout) * sizeof(float);
+        const size_t lds = (size_t)(16 * 33 + 16 * Nout) * sizeof(float);
         dim3 grid((unsigned)((M + 31) / 32));
-        if ((NT + 1) / 2 <= 9) hipLaunchKernelGGL((k_gemm_tokens<9, BK>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
-        else hipLaunchKernelGGL((k_gemm_tokens<12, BK>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+        if ((NT + 1) / 2 <= 9) hipLaunchKernelGGL((k_gemm_tokens<9>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+        else hipLaunchKernelGGL((k_gemm_tokens<12>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
         return hipGetLastError();
     }
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((Nout + 63) / 64));
