@@ -1,0 +1,68 @@
+"""bench.py's host-side contract, without a GPU: the self-launch of N ranks, the kernel-source fingerprint the traffic figure
+is keyed on, and the workload table."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` outside torch.distributed.run starts N ranks as child processes under torch.distributed.run on
+    127.0.0.1 with its own arguments passed through, and returns their exit code -- before anything touches the GPU."""
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--config", "lego_b64"])
+    args = bench.parse_args()
+    assert args.gpus == 4 and args.config == "lego_b64"
+    assert bench.relaunch_as_ranks(args) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "5", "--config", "lego_b64"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_defaults_and_workloads():
+    import bench
+    from iffnerf_amd import synthetic
+    old = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        a = bench.parse_args()
+    finally:
+        sys.argv = old
+    assert (a.gpus, a.config, a.in_flight) == (1, "lego16k", 4) and a.steps >= 100 and a.warmup >= 10
+    assert set(synthetic.WORKLOADS) == {"lego16k", "truck32k", "bicycle64k", "lego_b64"}
+    assert synthetic.WORKLOADS["lego16k"]["gen_points"] * 27 == 16011
+    assert synthetic.WORKLOADS["truck32k"]["gen_points"] * 27 == 32022
+    assert synthetic.WORKLOADS["bicycle64k"]["gen_points"] * 27 == 64017
+    assert synthetic.WORKLOADS["lego_b64"]["queries"] == 64 and synthetic.WORKLOADS["lego_b64"]["shared_rays"]
+
+
+def test_traffic_figure_is_keyed_on_the_kernel_sources():
+    """profiles/r02_hbm_traffic.json carries the fingerprint of the sources it was measured on; bench.py and the summariser
+    compute it the same way (bench.py reports `roofline.traffic` only while they agree)."""
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import summarize_pmc
+    fp = bench.source_fingerprint()
+    assert fp == summarize_pmc.source_fingerprint() and len(fp) == 16
+    j = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
+    assert j["config"] == "lego16k" and len(j["source_sha16"]) == 16
+    for k in ("k5_trunk_h<1, 1, 2>", "k4b_appearance12<27>", "k4a_density_composite<1>"):
+        assert j["kernels"][k]["hbm_bytes_per_launch"] > 0 and j["kernels"][k]["vmem_rd_wave_insts"] > 0
