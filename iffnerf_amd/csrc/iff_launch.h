@@ -27,6 +27,10 @@ size_t march_workspace_bytes(int64_t R, int S);
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
                         float* rgb, float* depth, float* acc, float* alpha, int* counts, float* feat_out, void* ws,
                         size_t ws_bytes, float* stage_ms_host, hipStream_t s);
+// fan_march_kernels.hip (the fused form of the point-centred march for 27-ray fans; MarchArgs: march_common.h)
+struct MarchArgs;
+bool fan_march_eligible(const FieldDev& f, int mode, int S);
+hipError_t launch_fan_march(const FieldDev& f, const MarchArgs& a, int variant, hipStream_t s);
 size_t march_grad_workspace_bytes(int64_t R, int S);
 hipError_t launch_march_grad(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S,
                              const float* g_feat, int g_feat_ld, const float* g_acc, float* g_rays, void* ws, size_t ws_bytes,

@@ -17,6 +17,8 @@
 // ~1000-sample slab sampler share the code.
 #include "iff_device.h"
 #include "iff_launch.h"
+#include "march_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------ K3
 // 27 iso-cell directions (pose_estimation/isocell.py:6-68, N0=3, isrand=-1) are passed in by the host mirror, which
@@ -79,39 +81,6 @@ hipError_t launch_isocell_emit(const float* cells27x3_host, const float* pts, co
 // ------------------------------------------------------------------------------------------------ K4
 constexpr int RPB = 16;   // rays per workgroup tile (256 threads / 16 lanes per ray in phases 3-4)
 constexpr int CH = 32;    // samples per chunk held in LDS
-
-struct MarchArgs {
-    const float* rays;
-    int ray_cols;
-    int64_t R;
-    int mode;        // 0 point-centred, 1 slab
-    int S;           // samples per ray
-    float bg[3];
-    float* rgb; float* depth; float* acc;
-    float* alpha;    // nullable [R,S]
-    int* counts;     // nullable [R,2]
-    float* weights;  // [R,S] compositing weights, written by K4a and read by K4b (caller's workspace)
-    float* feat;     // [R,28] per-ray weighted features + shaded flag, written by K4b and read by K4c (workspace)
-    int64_t n_tiles;
-};
-
-// tensorBase.py:499-502: slab entry parameter, clamped to [near, far]
-__device__ inline float slab_entry(const FieldDev& f, const float o[3], const float d[3]) {
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        float v = (d[ax] == 0.0f) ? 1e-6f : d[ax];
-        float ra = (f.aabb_hi[ax] - o[ax]) / v, rb = (f.aabb_lo[ax] - o[ax]) / v;
-        tmax = fmaxf(tmax, fminf(ra, rb));
-    }
-    return fminf(fmaxf(tmax, f.near), f.far);
-}
-
-// sample position parameter z_s (tensorBase.py:628-631 / :504-529), float ops in the reference's order
-__device__ inline float z_of(const FieldDev& f, int mode, int S, float t0, int s) {
-    if (mode == 0) return f.step_size * (float)(s - S / 2);
-    return t0 + f.step_size * (float)s;
-}
 
 // ---- K4a: density gather + alpha compositing.  Writes the per-sample weights for K4b.
 // LPS = lanes per sample: 4 (each lane one 16-B quarter of every 64-B texel, 16-ray tiles) or 1 (one lane gathers all 16
@@ -426,17 +395,28 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     a.feat = feat_out ? feat_out : (float*)((char*)ws + march_feat_offset(R, S));
     a.n_tiles = (R + RPB - 1) / RPB;
     if (a.n_tiles == 0) return hipSuccess;
-    // one lane per sample when the density texel is one 64-B line (n_density = 16, every reference config)
-    const bool one_lane = f.n_density == 16 && f.density_lanes != 4;
-    const int64_t tiles_a = one_lane ? (R + 63) / 64 : a.n_tiles;
-    int64_t grid = tiles_a < 256 * 8 ? tiles_a : 256 * 8;
-    if (one_lane) hipLaunchKernelGGL((k4a_density_composite<1>), dim3((unsigned)grid), dim3(256), 0, s, f, a, tiles_a);
-    else hipLaunchKernelGGL((k4a_density_composite<4>), dim3((unsigned)grid), dim3(256), 0, s, f, a, tiles_a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    // IFF_MARCH_FAN (tuning / A-B aid): 2 = the fused fan kernel where eligible, 1 = K4a + the fan kernel's appearance
+    // half, 0 = the general kernels (default while the fan kernel is being tuned).  iff_field_desc.density_lanes != 0 also keeps the general kernels (it names one of them).
+    static const int fan_knob = [] { const char* e = getenv("IFF_MARCH_FAN"); return e ? atoi(e) : 0; }();
+    const int fan = (fan_knob > 0 && f.density_lanes == 0 && fan_march_eligible(f, mode, S)) ? fan_knob : 0;
+    hipError_t e = hipSuccess;
+    int64_t grid;
+    if (fan != 2) {
+        // one lane per sample when the density texel is one 64-B line (n_density = 16, every reference config)
+        const bool one_lane = f.n_density == 16 && f.density_lanes != 4;
+        const int64_t tiles_a = one_lane ? (R + 63) / 64 : a.n_tiles;
+        grid = tiles_a < 256 * 8 ? tiles_a : 256 * 8;
+        if (one_lane) hipLaunchKernelGGL((k4a_density_composite<1>), dim3((unsigned)grid), dim3(256), 0, s, f, a, tiles_a);
+        else hipLaunchKernelGGL((k4a_density_composite<4>), dim3((unsigned)grid), dim3(256), 0, s, f, a, tiles_a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
-    if (mode == 0 && S <= 32) {
+    if (fan) {
+        e = launch_fan_march(f, a, fan, s);
+        if (e != hipSuccess) return e;
+    } else if (mode == 0 && S <= 32) {
         const int64_t tiles12 = (R + 19) / 20;
         grid = tiles12 < 256 * 8 ? tiles12 : 256 * 8;
         hipLaunchKernelGGL((k4b_appearance12<27>), dim3((unsigned)grid), dim3(256), lds, s, f, a, tiles12);

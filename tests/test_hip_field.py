@@ -174,3 +174,40 @@ def test_one_lane_density_gather_is_bit_identical_to_the_four_lane_form(dev):
             b = four.march(r, mode, S, want_alpha=True, want_counts=True)
             for x, y in zip(a[:5], b[:5]):
                 assert torch.equal(x, y), (P, mode)
+
+
+def test_fan_march_equals_the_general_kernels(dev):
+    """The fused fan kernel (k4f_fan_march: LDS-staged table patches per 27-ray tile, or its in-kernel gather path when a tile's
+    samples do not fit one patch) against the general kernels K4a / K4b (iff_field_desc.density_lanes = 1 keeps those): the
+    per-sample arithmetic is shared, so alpha, acc, depth and the (valid, shaded) counters must be EQUAL; the colours differ
+    only by the order in which the twelve quarter sums of basis_mat are added."""
+    from iffnerf_amd import synthetic
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    from iffnerf_amd.pipeline import PosePipeline
+    g = torch.Generator().manual_seed(31)
+    import os
+    if os.environ.get("IFF_MARCH_FAN", "0") == "0":
+        pytest.skip("the fan kernel is off (IFF_MARCH_FAN=0)")
+    for which, over in (("small", {}), ("tiny", {}), ("small", dict(grid=(300, 280, 260), mask_res=(60, 56, 52)))):
+        ck = util.ckpt(which, **over)
+        pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev)
+        fan, gen = field_handle_from_ckpt(ck, dev), field_handle_from_ckpt(ck, dev, density_lanes=1)
+        cases = []
+        for P in (75, 9, 1):                                                   # fans: the staged path
+            ori, dirs, _ = pipe.emit(P, seed=17 + P)
+            cases.append(torch.cat((ori, dirs), -1).contiguous())
+        cases.append(cases[0][:27 * 3 + 11].contiguous())                      # a ragged last tile
+        for R in (540, 37):                                                    # arbitrary rays: the gather path
+            o = (torch.rand(R, 3, generator=g) - 0.5) * 2.0
+            cases.append(torch.cat((o, torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)), -1).to(dev))
+        mixed = torch.cat((cases[0][:54], cases[4][:27], cases[0][54:108]))    # staged and gathered tiles in one launch
+        cases.append(mixed.contiguous())
+        for rays in cases:
+            a = fan.march(rays, 0, 20, want_alpha=True, want_counts=True)
+            b = gen.march(rays, 0, 20, want_alpha=True, want_counts=True)
+            for x, y, what in zip(a[1:5], b[1:5], ("depth", "acc", "alpha", "counts")):
+                assert torch.equal(x, y), (which, over, tuple(rays.shape), what)
+            close(a[0], b[0].cpu(), 2e-6, what=f"rgb {which} {tuple(rays.shape)}")
+            fa, fb = fan.march_features(rays, 0, 20)[0], gen.march_features(rays, 0, 20)[0]
+            close(fa, fb.cpu(), 2e-5, 2e-6, what="weighted features")
+            assert torch.equal(fa[:, 27], fb[:, 27])
