@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- poses/sec of the IFFNeRF per-query hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--config lego16k|truck32k|bicycle64k|lego_b64] --gpus N --steps K --warmup W
+    python bench.py [--config lego16k|truck32k|bicycle64k|lego_b64|lego540k] --gpus N --steps K --warmup W
 
 N = 1 runs in this process.  N > 1 started plainly (no WORLD_SIZE in the environment) re-launches itself as N child ranks
 under ``python -m torch.distributed.run`` BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the
@@ -12,6 +12,7 @@ Workloads (iffnerf_amd/synthetic.py:WORKLOADS, one per BASELINE.json config; syn
   truck32k (configs[2])                         27e6 voxels over a non-cubic T&T box, near_far [0.01, 6], 32 022 rays
   bicycle64k (configs[4])                       640^3, unisphere contraction, density_shift 0, 64 017 rays
   lego_b64 (configs[3])                         64 query images per step against ONE emitted ray set
+  lego540k (the reference's default size)       explore_model(gen_points=20000): 540 000 rays per query, 2 queries per step
 
 Step = one pass of the hot path over one batch of synthetic queries, COLD: stage A (device-side surface sampler + normals +
 27-ray fans), stage B (20-sample VM march + Ref shading of every ray) and stage C (ray encoder + folded q/k projections,
@@ -47,6 +48,9 @@ sys.path.insert(0, ROOT)
 M_TOKENS = 256
 TOPK = 100
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_GHZ = 2.4                  # MI355X_MICROARCH.md: maximum clock
+L1_PEAK_GBS = 256 * 64 * CLOCK_GHZ      # 256 CUs x 64 B/clk of the vector L1 / texture path = 39.3 TB/s
+LDS_PEAK_GBS = 256 * 256 * CLOCK_GHZ    # 256 CUs x 256 B/clk (ds_read_b128, MI355X_MICROARCH.md section LDS) = 157 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16
 # march: algorithmic bytes per sample = valid*1184 (8 mask corners x 4 B + density taps) + shaded*3456 (appearance taps)
 B_VALID, B_APP = 32 + 1152, 3456
@@ -57,7 +61,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="lego16k", choices=("lego16k", "truck32k", "bicycle64k", "lego_b64"),
+    ap.add_argument("--config", default="lego16k", choices=("lego16k", "truck32k", "bicycle64k", "lego_b64", "lego540k"),
                     help="BASELINE.json workload (default: configs[1], the one the metric is quoted on)")
     ap.add_argument("--in-flight", type=int, default=4, help="steps kept in flight on separate streams")
     ap.add_argument("--batch", type=int, default=0, help="queries per step and rank (default: the workload's: 16, bicycle64k: 8, lego_b64: 64)")
@@ -341,43 +345,52 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
         R = rays.shape[0]
         bytes_a += (R * (24 + 8 + 20 * 4) + counts[0].item() * B_VALID) / n_rep           # rays in, acc/depth + weights out
         bytes_b += (R * (24 + 20 * 4 + 28 * 4) + counts[1].item() * B_APP) / n_rep          # rays + weights in, features out
-    # ---- roofline of the dominant kernel (largest share of GPU time in profiles/): k5_trunk<true>, the fused ray
-    # encoder + attention logits, bound by the matrix cores.  `frac` follows SURVEY.md 8(d): the ALGORITHMIC flops of
-    # the reference's chain (per ray and query: ray MLP + k_proj + QK^T + softmax) over the launch duration over the dense
-    # bf16/fp16 peak; `mfma_issue_frac` is the share of the matrix cores' issue slots the launch fills with what it
-    # actually issues (folded heads, `products` MFMA products per fp32-accurate product).
-    pmc = {}
+    # ---- roofline: the longest kernel of a step by THIS run's event timings is the headline object, the others follow in
+    # `other_kernels`.  Roofs (MI355X_MICROARCH.md; 256 CUs at the 2.4 GHz maximum clock, stated in `peak_basis`):
+    #   mfma        dense bf16 / fp16 MFMA, 2.5 PFLOP/s                 -- the fused ray encoder + logits launch
+    #   lds-gather  256 CUs x 256 B/clk (ds_read_b128) = 157 TB/s       -- the fused fan march: every tap is served from LDS patches
+    #   l1-gather   256 CUs x 64 B/clk of the vector L1s = 39.3 TB/s    -- the general march kernels: taps gathered through the L1s
+    # `achieved` = ALGORITHMIC flops / bytes of SURVEY.md section 8(d) over the launch time; `traffic` = HBM-side bytes per launch
+    # from the rocprofv3 PMC passes of profiles/ (only while they were collected on these kernel sources and this --config),
+    # `hbm_frac_from_counters` = that over the launch time over the 8 TB/s HBM peak.
+    pmc, pmc_name = {}, "profiles/r03_hbm_traffic_%s.json" % args.config
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as fh:
+        with open(os.path.join(ROOT, pmc_name)) as fh:
             pmc = json.load(fh)
     except (OSError, ValueError):
         pass
     fresh = pmc.get("source_sha16") == source_fingerprint() and pmc.get("config") == args.config
+    traffic_source = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2x FETCH correction), same kernel sources"
+                      % pmc_name if fresh else "null: %s is absent or was measured on other kernel sources (stale)" % pmc_name)
+
+    def entry(*keys):
+        if fresh:
+            for key in keys:
+                if key in pmc.get("kernels", {}):
+                    return pmc["kernels"][key]
+        return None
 
     def traffic(*keys):
-        if not fresh:
-            return None
-        for key in keys:
-            if key in pmc.get("kernels", {}):
-                return pmc["kernels"][key].get("hbm_bytes_per_launch")
-        return None
+        e = entry(*keys)
+        return e.get("hbm_bytes_per_launch") if e else None
 
     def binding(ms, *keys):
-        """What bounds a gather kernel, from the counters of profiles/ and this run's launch time: the share of the HBM peak the
-        counter bytes make, and the busy shares of the two per-CU resources its instructions occupy (MI355X: 256 CUs x 4 SIMDs
-        at 2.4 GHz; a dwordx4 wave-load holds a CU's texture path for 16 cycles, a wave64 VALU instruction a SIMD for 4)."""
-        if not fresh or ms <= 0:
+        """Busy shares of the per-CU resources a gather kernel occupies, from the counters of profiles/ and this run's launch time
+        (256 CUs x 4 SIMDs at 2.4 GHz; a dwordx4 wave-load holds a CU's texture path for 16 cycles, a wave64 VALU instruction a SIMD
+        for 4, SQ_LDS_IDX_ACTIVE counts the cycles the LDS arrays are busy)."""
+        e = entry(*keys)
+        if not e or ms <= 0 or "valu_wave_insts" not in e:
             return None
-        for key in keys:
-            e = pmc.get("kernels", {}).get(key)
-            if e and "vmem_rd_wave_insts" in e:
-                cyc = ms * 1e-3 * 2.4e9
-                return {"hbm_frac_from_counters": round(e.get("hbm_bytes_per_launch", 0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "texture_path_busy": round(e["vmem_rd_wave_insts"] * 16.0 / 256.0 / cyc, 3),
-                        "valu_busy": round(e["valu_wave_insts"] * 4.0 / 1024.0 / cyc, 3),
-                        "l1_hit_rate": e.get("l1_hit_rate"), "l2_hit_rate": e.get("l2_hit_rate"),
-                        "wave_loads_per_launch": e["vmem_rd_wave_insts"], "valu_wave_insts_per_launch": e["valu_wave_insts"]}
-        return None
+        cyc = ms * 1e-3 * CLOCK_GHZ * 1e9
+        out = {"hbm_frac_from_counters": round(e.get("hbm_bytes_per_launch", 0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "texture_path_busy": round(e.get("vmem_rd_wave_insts", 0) * 16.0 / 256.0 / cyc, 3),
+               "valu_busy": round(e["valu_wave_insts"] * 4.0 / 1024.0 / cyc, 3),
+               "l1_hit_rate": e.get("l1_hit_rate"), "l2_hit_rate": e.get("l2_hit_rate"),
+               "wave_loads_per_launch": e.get("vmem_rd_wave_insts"), "valu_wave_insts_per_launch": e["valu_wave_insts"]}
+        if "lds_active_cycles" in e:
+            out["lds_busy"] = round(e["lds_active_cycles"] / 256.0 / cyc, 3)
+            out["lds_bank_conflict_share"] = round(e.get("lds_bank_conflict_cycles", 0) / max(e["lds_active_cycles"], 1), 3)
+        return out
 
     rays_per_launch = ori.shape[0]
     pairs = rays_per_launch * (QT if shared else 1)          # (ray, query) pairs the launch scores
@@ -388,11 +401,9 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     issued = rays_per_launch * products * 2.0 * 256.0 * 800 + pairs * products * 2.0 * 256.0 * 256 * ((M_TOKENS + 255) // 256)
     tf_algo = algo / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
     tf_issued = issued / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-    gbs_b = bytes_b / (march_launch_ms[1] * 1e-3) / 1e9
-    gbs_a = bytes_a / (march_launch_ms[0] * 1e-3) / 1e9
     tname = pipe.idnet.trunk_kernel_name()
-    result["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
-    result["roofline"] = {
+    peak_basis = "256 CUs at the %.1f GHz maximum clock (MI355X_MICROARCH.md)" % CLOCK_GHZ
+    kernels = [{
         "kernel": tname + " (ray encoder + attention logits + softmax partials, one launch)",
         "queries_per_launch": QT, "rays_per_launch": rays_per_launch,
         "bound": "mfma", "achieved": round(tf_algo, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -402,26 +413,42 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
         "note": "achieved = SURVEY 8(d) algorithmic flops (898 048 per ray for the encoder + k_proj, (2*384 + 4)*M per "
                 "(ray, query) pair) / launch time; peak = dense bf16/fp16 MFMA.  The kernel issues the folded chain "
                 "(2 x 256 x 1056 flops per ray and 256-token block) as %d MFMA products per fp32-accurate product: "
-                "mfma_issue_frac is that over the same peak" % products,
-        "traffic_source": ("profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2x FETCH "
-                           "correction), same kernel sources" if fresh else
-                           "null: profiles/r02_hbm_traffic.json was measured on other kernel sources or another --config (stale)"),
-        "other_kernels": {
-            "k4b_appearance12 (appearance gather of TensorBase.forward)": {
-                "bound": "hbm", "achieved": round(gbs_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs_b / HBM_PEAK_GBS, 4), "traffic": traffic("k4b_appearance12<27>", "k4b_appearance<27, true, 16>"),
-                "algorithmic_bytes_per_launch": round(bytes_b), "avg_launch_ms": round(march_launch_ms[1], 4),
-                "binding": binding(march_launch_ms[1], "k4b_appearance12<27>", "k4b_appearance<27, true, 16>"),
-                "note": "algorithmic bytes = 3456 B per shaded sample (SURVEY 8d) x the kernel's own shaded-sample counter.  "
-                        "frac > 1 against HBM means the gathers are served on chip (tables in L2 / Infinity Cache; `traffic` is "
-                        "what crosses the L2's memory side, `binding.hbm_frac_from_counters` its share of the HBM peak).  The "
-                        "binding resource is the CU's texture path (`binding.texture_path_busy`: wave-level gathers x 16 cycles) "
-                        "together with the vector ALU (`binding.valu_busy`); DESIGN.md section 4"},
-            "k4a_density_composite": {
-                "bound": "hbm", "achieved": round(gbs_a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs_a / HBM_PEAK_GBS, 4), "traffic": traffic("k4a_density_composite<1>"),
-                "algorithmic_bytes_per_launch": round(bytes_a), "avg_launch_ms": round(march_launch_ms[0], 4), "binding": binding(march_launch_ms[0], "k4a_density_composite<1>", "k4a_density_composite<4>")},
-            "k_ref_shade": {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>")}}}
+                "mfma_issue_frac is that over the same peak" % products}]
+
+    def gather_kernel(name, keys, bound, peak, nbytes, ms, note):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": name, "rays_per_launch": rays_per_launch, "bound": bound, "achieved": round(gbs, 1), "peak": round(peak, 1),
+                "unit": "GB/s", "frac": round(gbs / peak, 4), "traffic": traffic(*keys), "avg_launch_ms": round(ms, 4),
+                "algorithmic_bytes_per_launch": round(nbytes), "peak_basis": peak_basis, "binding": binding(ms, *keys), "note": note}
+
+    if pipe.field.march_plan(0, 20) == 2:
+        kernels.append(gather_kernel(
+            "k4f_fan_march<2> (TensorBase.forward up to the Ref head, fused per 27-ray fan: density, compositing, appearance, basis_mat)",
+            ("(anonymous namespace)::k4f_fan_march<2>",), "lds-gather", LDS_PEAK_GBS, bytes_a + bytes_b - rays_per_launch * 2 * 20 * 4,
+            march_launch_ms[1],
+            "algorithmic bytes = 1184 B per valid sample + 3456 B per shaded sample (SURVEY 8d) x the kernel's own sample counters + "
+            "rays in / features out.  The table patches a fan touches are staged once in LDS (coalesced row segments: `traffic` is "
+            "what crosses the L2's memory side) and every tap is an LDS read, so the roof is the LDS read rate, 256 B/clk per CU; the "
+            "kernel is co-limited by the vector ALU (`binding.valu_busy`); DESIGN.md section 4"))
+    else:
+        kernels.append(gather_kernel(
+            "k4b_appearance12<27> (appearance gather of TensorBase.forward)", ("k4b_appearance12<27>", "k4b_appearance<27, true, 16>"),
+            "l1-gather", L1_PEAK_GBS, bytes_b, march_launch_ms[1],
+            "algorithmic bytes = 3456 B per shaded sample (SURVEY 8d) x the kernel's own shaded-sample counter; the taps are served by "
+            "the CUs' vector L1s (64 B/clk each), `traffic` is what crosses the L2's memory side; DESIGN.md section 4"))
+        kernels.append(gather_kernel(
+            "k4a_density_composite (density gather + compositing of TensorBase.forward)", ("k4a_density_composite<1>", "k4a_density_composite<4>"),
+            "l1-gather", L1_PEAK_GBS, bytes_a, march_launch_ms[0],
+            "algorithmic bytes = 1184 B per valid sample (SURVEY 8d) x the kernel's own valid-sample counter + rays in, weights out"))
+    kernels.sort(key=lambda k: -k["avg_launch_ms"])
+    result["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+    result["roofline"] = dict(kernels[0])
+    result["roofline"]["traffic_source"] = traffic_source
+    result["roofline"]["selected_as"] = "the longest launch of a step by this run's hipEvent timings"
+    others = {k["kernel"].split(" ")[0]: k for k in kernels[1:]}
+    others["k_ref_shade<27, true>"] = {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>"),
+                                       "note": "Ref head per ray (ref.py:103-152): vector ALU from LDS-staged weights, no roofline"}
+    result["roofline"]["other_kernels"] = others
     if world_size == 1 and not shared:
         # warm path (rays resident: the reference's eval semantics, train_eval_pose_est.py:131-149): stage C only, 16 query
         # images per graph against one resident ray set whose encoder output is cached per model (SURVEY 8f-2:

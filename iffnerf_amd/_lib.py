@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
 _lib = None
-ABI_VERSION = 7          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 8          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "iff_isocell_emit": (C.c_int, [c_float_p, _VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     "iff_march_workspace": (_SZ, [_VP, _I64, _I32, _I32]),
     "iff_march_default_samples": (_I32, [_VP, _I32]),
+    "iff_march_plan": (_I32, [_VP, _I32, _I32]),
     "iff_march_shade": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, c_float_p, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_march_features": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_march_grad_workspace": (_SZ, [_VP, _I64, _I32, _I32]),

@@ -253,6 +253,11 @@ static int march_samples(const iff_field* f, int32_t mode, int32_t n_samples) {
 
 extern "C" int32_t iff_march_default_samples(const iff_field* f, int32_t mode) { return f ? march_samples(f, mode, 0) : 0; }
 
+extern "C" int32_t iff_march_plan(const iff_field* f, int32_t mode, int32_t n_samples) {
+    if (!f) return IFF_MARCH_PLAN_GENERAL;
+    return march_plan(f->dev, mode, march_samples(f, mode, n_samples));
+}
+
 extern "C" size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples) {
     if (!f || R <= 0) return 0;
     return march_workspace_bytes(R, march_samples(f, mode, n_samples));

@@ -8,18 +8,19 @@
 //   phase 0   bounding box of the tile's samples in texel indices (ray end points; positions are monotone along a ray)
 //   phase A   one record per sample: occupancy, clamped tap indices relative to the box, zero-padded tap weights -- the tap
 //             arithmetic of a sample is done once, not once per lane and plane
-//   phase B   density: the three 12 x 12 x 64-B plane patches + lines in LDS, four lanes per ray (one 16-B quarter of the
-//             density texel each), sigma / alpha, then the transmittance product of the ray (tensorBase.py:23-35)
-//   phase C   appearance, plane by plane: a 12 x 12 x 192-B patch + its line in LDS, four lanes per ray (three 16-B quarters of
-//             the 192-B texel each), samples with weight > rayMarch_weight_thres only (tensorBase.py:851), weight-summed
-//             plane*line products in registers
-//   phase D   basis_mat (tensoRF.py:158) once per ray on the weighted sums, from an LDS copy
+//   phase B   density: the three 12 x 12 x 64-B plane patches + lines in LDS; a ray is served by EIGHT lanes = two sub-groups of
+//             four (one 16-B quarter of the density texel each), sub-group h takes the samples s = h mod 2; sigma / alpha,
+//             then the transmittance product of the ray (tensorBase.py:23-35)
+//   phase C   appearance, plane by plane: a 12 x 12 x 192-B patch + its line in LDS, each lane three 16-B quarters of the
+//             192-B texel, sub-group h the samples s = h mod 2 with weight > rayMarch_weight_thres (tensorBase.py:851),
+//             weight-summed plane*line products in registers, the two sub-groups' sums added at the end
+//   phase D   basis_mat (tensoRF.py:158) once per ray on the weighted sums, from an LDS copy (sub-group h: outputs h mod 2)
 //
 // The next patch is fetched into registers while the current phase computes.  A tile is ANY 27 consecutive rays: when its box
 // does not fit the patch (arbitrary rays, unisphere contraction) the same workgroup gathers from global memory with the lookup
 // functions of iff_device.h -- same arithmetic, same bits, no LDS staging.  Every per-sample operation is the one the general
-// kernels perform (shared lerp order, per-ray sequential accumulation), so alpha / acc / depth / counters are bit-identical to
-// theirs; the 12 quarter sums of basis_mat are added in this kernel's own fixed tree.
+// kernels perform (shared lerp order), so alpha / acc / depth / counters are bit-identical to theirs; the weighted feature
+// sums are added in this kernel's own fixed order (even samples, odd samples, then the 12 quarter sums of basis_mat).
 #include "iff_device.h"
 #include "iff_launch.h"
 #include "march_common.h"
@@ -29,7 +30,7 @@ namespace {
 constexpr int FR = 27;          // rays per tile = one iso-cell fan (pose_estimation/isocell.py:6-68)
 constexpr int FS = 20;          // samples per ray (pose_estimation/sampling.py:247)
 constexpr int FP = 12;          // patch side, texels
-constexpr int NT = 128;         // threads: 32 groups of 4 lanes; group g serves ray g of the tile
+constexpr int NT = 256;         // threads: 32 groups of 8 lanes (two sub-groups of 4); group g serves ray g of the tile
 constexpr int REC = 8;          // dwords per sample record
 constexpr int PLANE16 = FP * FP * 16, LINE16 = FP * 16;      // density patch (floats)
 constexpr int PLANE48 = FP * FP * 48, LINE48 = FP * 48;      // appearance patch (floats)
@@ -38,9 +39,33 @@ constexpr int BASIS_FLOATS = 27 * 12 * 12;
 static_assert(3 * (PLANE16 + LINE16) == PATCH_FLOATS, "the density patches fill the appearance patch exactly");
 static_assert(BASIS_FLOATS <= PATCH_FLOATS, "basis_mat is staged in the patch buffer");
 
+#ifndef FAN_WAVES
+#define FAN_WAVES 3            // waves per SIMD the register budget is set for (three 256-thread workgroups per CU)
+#endif
 typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+// FAN_STAMPS (diagnostic build only): wave w of a tile stores the low word of s_memtime after each phase into the tile's
+// slice of the optional alpha output ([R,20] floats: slot 16 w + k), which then carries no alphas.
+#ifdef FAN_STAMPS
+#define STAMP(k) do { if (a.alpha && lane == 0 && n_live == FR) reinterpret_cast<uint32_t*>(a.alpha)[ray0 * FS + 16 * wave + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ f32q splat(float v) { return (f32q)(v); }
+// cross-lane moves as DPP modifiers of vector-ALU instructions (__shfl_xor compiles to ds_bpermute_b32: a round trip through
+// the LDS crossbar per call)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 4 lanes of a quad, in the order of sum4 (iff_device.h): (v + xor1) then (+ xor2)
+__device__ __forceinline__ float sum4_dpp(float v) {
+    v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
+    return v;
+}
+// the value of lane (i xor 4): reverse inside the quad (quad_perm [3,2,1,0]), then mirror the 8-lane half row (row_half_mirror)
+__device__ __forceinline__ float xor4_dpp(float v) { return dpp_mov<0x141>(dpp_mov<0x1B>(v)); }
 // bilinear / linear combination in the operation order of lerp_plane4 / lerp_line4 (iff_device.h)
 __device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
     f32q r = nw * splat(pw[0]);
@@ -54,68 +79,36 @@ __device__ __forceinline__ f32q lerp_line_q(f32q lo, f32q hi, const float lw[2])
     return __builtin_elementwise_fma(hi, splat(lw[1]), r);
 }
 
-// ---- coalesced patch fetch: chunk = one 16-B piece; a patch row (12 texels) is one contiguous run of the table
-// plane patch of a C-channel table into registers: rows lob.., columns loa..; `fast` = the patch lies inside the table
-template <int C, int ROUNDS>
-__device__ __forceinline__ void fetch_plane(const float* __restrict__ tab, int Ga, int Gb, int loa, int lob, bool fast, int tid,
-                                            f32q (&reg)[ROUNDS]) {
-    constexpr int CPT = C / 4, CPR = FP * CPT, NCH = FP * CPR;
-    static_assert(ROUNDS * NT >= NCH, "rounds");
+// ---- coalesced patch fetch: chunk = one 16-B piece; a patch row (12 texels) is one contiguous run of the table.
+// `fast` = the patch lies inside the table (no clamping).  Byte offset of chunk `chunk` of a C-channel plane patch:
+template <int C>
+__device__ __forceinline__ const f32q* plane_chunk(const float* __restrict__ tab, int Ga, int Gb, int loa, int lob, bool fast, int chunk) {
+    constexpr int CPT = C / 4, CPR = FP * CPT;
     if (fast) {
         const char* base = reinterpret_cast<const char*>(tab + ((size_t)lob * Ga + loa) * C);
-        const int row_skip = (Ga - FP) * C * 4;                 // bytes between the end of a patch row and the next one
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int chunk = tid + NT * r;
-            if (chunk < NCH) {
-                const int ry = chunk / CPR;
-                reg[r] = *reinterpret_cast<const f32q*>(base + (unsigned)(ry * row_skip + chunk * 16));
-            }
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int chunk = tid + NT * r;
-            if (chunk < NCH) {
-                const int texel = chunk / CPT, q = chunk - texel * CPT;
-                const int ry = texel / FP, rx = texel - ry * FP;
-                const int row = min(lob + ry, Gb - 1), col = min(loa + rx, Ga - 1);
-                reg[r] = *reinterpret_cast<const f32q*>(tab + ((size_t)row * Ga + col) * C + 4 * q);
-            }
-        }
+        const int ry = chunk / CPR;
+        return reinterpret_cast<const f32q*>(base + (unsigned)(ry * ((Ga - FP) * C * 4) + chunk * 16));
     }
+    const int texel = chunk / CPT, q = chunk - texel * CPT;
+    const int ry = texel / FP, rx = texel - ry * FP;
+    const int row = min(lob + ry, Gb - 1), col = min(loa + rx, Ga - 1);
+    return reinterpret_cast<const f32q*>(tab + ((size_t)row * Ga + col) * C + 4 * q);
 }
-template <int C, int ROUNDS>
-__device__ __forceinline__ void fetch_line(const float* __restrict__ tab, int Gv, int lov, bool fast, int tid, f32q (&reg)[ROUNDS]) {
-    constexpr int CPT = C / 4, NCH = FP * CPT;
-    static_assert(ROUNDS * NT >= NCH, "rounds");
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int chunk = tid + NT * r;
-        if (chunk < NCH) {
-            const int rz = chunk / CPT, q = chunk - rz * CPT;
-            const int row = fast ? lov + rz : min(lov + rz, Gv - 1);
-            reg[r] = *reinterpret_cast<const f32q*>(tab + (size_t)row * C + 4 * q);
-        }
-    }
-}
-template <int NCH, int ROUNDS>
-__device__ __forceinline__ void stash(float* dst, int tid, const f32q (&reg)[ROUNDS]) {
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int chunk = tid + NT * r;
-        if (chunk < NCH) *reinterpret_cast<f32q*>(dst + 4 * chunk) = reg[r];
-    }
+template <int C>
+__device__ __forceinline__ const f32q* line_chunk(const float* __restrict__ tab, int Gv, int lov, bool fast, int chunk) {
+    constexpr int CPT = C / 4;
+    const int rz = chunk / CPT, q = chunk - rz * CPT;
+    const int row = fast ? lov + rz : min(lov + rz, Gv - 1);
+    return reinterpret_cast<const f32q*>(tab + (size_t)row * C + 4 * q);
 }
 
-struct RecView {           // one sample record, unpacked (all four lanes of a group read the same record)
+struct RecView {           // one sample record, unpacked (all lanes of a sub-group read the same record)
     float w;               // compositing weight (after phase B)
     bool valid;
     int r[3], d[3];        // tap index relative to the box, and 1 when the high tap is a different texel
     float wt[3][2];        // zero-padded tap weights per axis
 };
-__device__ __forceinline__ RecView read_rec(const uint32_t* rec) {
-    const u32q a = *reinterpret_cast<const u32q*>(rec), b = *reinterpret_cast<const u32q*>(rec + 4);
+__device__ __forceinline__ RecView unpack_rec(const u32q a, const u32q b) {
     RecView v;
     v.w = __uint_as_float(a.x);
     v.valid = (a.y >> 15) & 1u;
@@ -126,343 +119,417 @@ __device__ __forceinline__ RecView read_rec(const uint32_t* rec) {
     v.wt[2][0] = __uint_as_float(b.z); v.wt[2][1] = __uint_as_float(b.w);
     return v;
 }
+__device__ __forceinline__ RecView read_rec(const uint32_t* rec) {
+    return unpack_rec(*reinterpret_cast<const u32q*>(rec), *reinterpret_cast<const u32q*>(rec + 4));
+}
 
 // MODE 2: the whole march of a tile (density, compositing, appearance, basis_mat).  MODE 1: appearance + basis_mat only, the
 // compositing weights come from K4a's workspace (A/B aid).
 template <int MODE>
-__global__ void __launch_bounds__(NT, 2) k4f_fan_march(FieldDev f, MarchArgs a, int64_t n_tiles) {
+__global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, MarchArgs a, int64_t n_tiles) {
     __shared__ __align__(16) float s_patch[PATCH_FLOATS];
     __shared__ __align__(16) uint32_t s_rec[FR * FS * REC];
     __shared__ __align__(16) float s_feat[FR * 28];
     __shared__ float s_ray[FR * 8];
     __shared__ int s_box[8];
     const int tid = threadIdx.x;
-    const int g = tid >> 2, c = tid & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int g = tid >> 3, h = (tid >> 2) & 1, c = tid & 3;     // ray of the tile, sub-group, texel quarter
     const bool grp_on = g < FR;
-    const int G0 = f.grid[0], G1 = f.grid[1], G2 = f.grid[2];
+    const int gg = grp_on ? g : 0;
 
     // one tile per workgroup (exact grid): inside a persistent tile loop LLVM hoists the per-lane patch offsets and table
     // descriptors out of the loop and spills them
-    {
-        const int64_t tile = blockIdx.x;
-        const int64_t ray0 = tile * FR;
-        const int n_live = (int)min((int64_t)FR, a.R - ray0);
-        if (tid < FR) {
-            float* sr = s_ray + tid * 8;
-            if (tid < n_live) {
-                const float* rp = a.rays + (ray0 + tid) * a.ray_cols;
-                sr[0] = rp[0]; sr[1] = rp[1]; sr[2] = rp[2]; sr[3] = rp[3]; sr[4] = rp[4]; sr[5] = rp[5];
-                sr[6] = 0.0f; sr[7] = rp[a.ray_cols - 1];
-            } else {
-                sr[0] = sr[1] = sr[2] = 0.0f; sr[3] = sr[4] = 0.0f; sr[5] = 1.0f; sr[6] = sr[7] = 0.0f;
+    const int64_t ray0 = (int64_t)blockIdx.x * FR;
+    const int n_live = (int)min((int64_t)FR, a.R - ray0);
+    if (tid < FR) {
+        float* sr = s_ray + tid * 8;
+        if (tid < n_live) {
+            const float* rp = a.rays + (ray0 + tid) * a.ray_cols;
+            sr[0] = rp[0]; sr[1] = rp[1]; sr[2] = rp[2]; sr[3] = rp[3]; sr[4] = rp[4]; sr[5] = rp[5];
+            sr[6] = 0.0f; sr[7] = rp[a.ray_cols - 1];
+        } else {
+            sr[0] = sr[1] = sr[2] = 0.0f; sr[3] = sr[4] = 0.0f; sr[5] = 1.0f; sr[6] = sr[7] = 0.0f;
+        }
+    }
+    STAMP(0);
+    __syncthreads();
+    // ---------------------------------------------------------------------------------------------------- phase 0: the box
+    // x(s) is monotone in s along a ray (every operation of the position / normalisation chain is monotone and so is its
+    // rounding), hence the taps of a ray's samples lie between the taps of its two end points.  The 54 end points sit in
+    // wave 0: reduced across the wave by xor butterfly (same-address LDS atomics would serialise lane by lane).
+    if (wave == 0) {
+        int blo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, bhi[3] = {-1, -1, -1};
+        const int rl = tid % FR;
+        if (tid < 2 * FR && rl < n_live) {
+            const float* sr = s_ray + rl * 8;
+            const float z = z_of(f, 0, FS, 0.0f, tid < FR ? 0 : FS - 1);
+            const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
+            float xn[3];
+            field_normalize(f, p, xn);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const int G = f.grid[ax];
+                const float x = unnorm(xn[ax], G);
+                blo[ax] = 0; bhi[ax] = G - 1;          // NaN: the whole axis (forces the gather path)
+                if (x == x) {
+                    const int fl = (int)floorf(fminf(fmaxf(x, -1.0f), (float)G));
+                    blo[ax] = min(max(fl, 0), G - 1);
+                    bhi[ax] = min(max(fl + 1, 0), G - 1);
+                }
             }
         }
-        if (tid < 6) s_box[tid] = tid < 3 ? 0x7fffffff : -1;
-        __syncthreads();
-        // ------------------------------------------------------------------------------------------------ phase 0: the box
-        // x(s) is monotone in s along a ray (every operation of the position / normalisation chain is monotone and so is its
-        // rounding), hence the taps of a ray's samples lie between the taps of its two end points
-        if (tid < 2 * FR) {
-            const int rl = tid % FR;
-            if (rl < n_live) {
-                const float* sr = s_ray + rl * 8;
-                const float z = z_of(f, 0, FS, 0.0f, tid < FR ? 0 : FS - 1);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                blo[ax] = min(blo[ax], __shfl_xor(blo[ax], off, 64));
+                bhi[ax] = max(bhi[ax], __shfl_xor(bhi[ax], off, 64));
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { s_box[ax] = blo[ax]; s_box[3 + ax] = bhi[ax]; }
+        }
+    }
+    __syncthreads();
+    int lo[3];
+    bool fits = !f.unisphere, inner = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        lo[ax] = __builtin_amdgcn_readfirstlane(s_box[ax]);
+        const int hi = __builtin_amdgcn_readfirstlane(s_box[3 + ax]);
+        fits = fits && (hi - lo[ax] + 1 <= FP);
+        inner = inner && (lo[ax] + FP <= f.grid[ax]);
+    }
+    // ---------------------------------------------------------------------------------------------------- prefetch for phase B
+    // density patches: 3 x 576 plane chunks = two full rounds per plane + one round in which wave w takes the last 64 chunks of
+    // plane w; the three lines (48 chunks each) likewise by waves 0..2 in one round
+    f32q pre[8];
+    if (MODE == 2 && fits) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pa = mat_a(i), pb = mat_b(i);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) pre[2 * i + r] = *plane_chunk<16>(f.dplane[i], f.grid[pa], f.grid[pb], lo[pa], lo[pb], inner, tid + NT * r);
+        }
+        if (wave < 3) {
+            const int pa = mat_a(wave), pb = mat_b(wave), pv = vec_ax(wave);
+            pre[6] = *plane_chunk<16>(f.dplane[wave], f.grid[pa], f.grid[pb], lo[pa], lo[pb], inner, 2 * NT + lane);
+            if (lane < FP * 4) pre[7] = *line_chunk<16>(f.dline[wave], f.grid[pv], lo[pv], inner, lane);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+    // ---------------------------------------------------------------------------------------------------- phase A: records
+    if (grp_on) {
+        const float* sr = s_ray + g * 8;
+        const bool live = g < n_live;
+        const int l8 = tid & 7;
+        // the occupancy values of the lane's (up to) three samples first: 24 independent byte loads in flight together
+        float mvs[3] = {1.0f, 1.0f, 1.0f};
+        if (f.mask) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int s = min(l8 + 8 * k, FS - 1);
+                const float z = z_of(f, 0, FS, 0.0f, s);
                 const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
+                mvs[k] = (live && inside_aabb(f, p)) ? mask_value(f, p) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int s = l8 + 8 * k;
+            if (s >= FS) break;
+            const float z = z_of(f, 0, FS, 0.0f, s);
+            const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
+            const bool inside = live && inside_aabb(f, p);
+            u32q r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+            if (inside) {
                 float xn[3];
                 field_normalize(f, p, xn);
+                uint32_t packed = (mvs[k] > 0.0f) ? (1u << 15) : 0u;
+                float wt[3][2];
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
-                    const int G = f.grid[ax];
-                    const float x = unnorm(xn[ax], G);
-                    int blo = 0, bhi = G - 1;              // NaN: the whole axis (forces the gather path)
-                    if (x == x) {
-                        const int fl = (int)floorf(fminf(fmaxf(x, -1.0f), (float)G));
-                        blo = min(max(fl, 0), G - 1);
-                        bhi = min(max(fl + 1, 0), G - 1);
-                    }
-                    atomicMin(&s_box[ax], blo);
-                    atomicMax(&s_box[3 + ax], bhi);
+                    const AxisTap t = axis_tap(xn[ax], f.grid[ax]);
+                    packed |= (uint32_t)(((t.i[0] - lo[ax]) & 15) | ((t.i[1] - t.i[0]) << 4)) << (5 * ax);
+                    wt[ax][0] = t.w[0]; wt[ax][1] = t.w[1];
                 }
+                r0.y = packed; r0.z = __float_as_uint(wt[0][0]); r0.w = __float_as_uint(wt[0][1]);
+                r1.x = __float_as_uint(wt[1][0]); r1.y = __float_as_uint(wt[1][1]);
+                r1.z = __float_as_uint(wt[2][0]); r1.w = __float_as_uint(wt[2][1]);
             }
+            if (MODE == 1) r0.x = __float_as_uint(live ? a.weights[(ray0 + g) * FS + s] : 0.0f);
+            uint32_t* rec = s_rec + (g * FS + s) * REC;
+            *reinterpret_cast<u32q*>(rec) = r0;
+            *reinterpret_cast<u32q*>(rec + 4) = r1;
         }
-        __syncthreads();
-        int lo[3];
-        bool fits = !f.unisphere, inner = true;
+    }
+    STAMP(2);
+    if (MODE == 2 && fits) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            lo[ax] = __builtin_amdgcn_readfirstlane(s_box[ax]);
-            const int hi = __builtin_amdgcn_readfirstlane(s_box[3 + ax]);
-            fits = fits && (hi - lo[ax] + 1 <= FP);
-            inner = inner && (lo[ax] + FP <= f.grid[ax]);
-        }
-        // ------------------------------------------------------------------------------------------------ prefetch for phase B
-        f32q pre[16];
-        f32q prel[3];
-        if (MODE == 2 && fits) {
-            // density planes: 5 rounds each (576 chunks), lines: one round each (48 chunks)
-            f32q t0[5], t1[5], t2[5], l0[1], l1[1], l2[1];
-            fetch_plane<16, 5>(f.dplane[0], G0, G1, lo[0], lo[1], inner, tid, t0);
-            fetch_plane<16, 5>(f.dplane[1], G0, G2, lo[0], lo[2], inner, tid, t1);
-            fetch_plane<16, 5>(f.dplane[2], G1, G2, lo[1], lo[2], inner, tid, t2);
-            fetch_line<16, 1>(f.dline[0], G2, lo[2], inner, tid, l0);
-            fetch_line<16, 1>(f.dline[1], G1, lo[1], inner, tid, l1);
-            fetch_line<16, 1>(f.dline[2], G0, lo[0], inner, tid, l2);
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int r = 0; r < 5; ++r) { pre[r] = t0[r]; pre[5 + r] = t1[r]; pre[10 + r] = t2[r]; }
-            prel[0] = l0[0]; prel[1] = l1[0]; prel[2] = l2[0];
+            for (int r = 0; r < 2; ++r) *reinterpret_cast<f32q*>(s_patch + i * PLANE16 + 4 * (tid + NT * r)) = pre[2 * i + r];
+        if (wave < 3) {
+            *reinterpret_cast<f32q*>(s_patch + wave * PLANE16 + 4 * (2 * NT + lane)) = pre[6];
+            if (lane < FP * 4) *reinterpret_cast<f32q*>(s_patch + 3 * PLANE16 + wave * LINE16 + 4 * lane) = pre[7];
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ------------------------------------------------------------------------------------------------ phase A: records
-        if (grp_on) {
-            const float* sr = s_ray + g * 8;
-            const bool live = g < n_live;
+    }
+    __syncthreads();
+    // appearance plane 0 on its way while phase B computes: 1728 plane chunks = 6 full rounds + 192, 144 line chunks
+    auto fetch_app = [&](int i) {
+        const int pa = mat_a(i), pb = mat_b(i), pv = vec_ax(i);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) pre[r] = *plane_chunk<48>(f.aplane[i], f.grid[pa], f.grid[pb], lo[pa], lo[pb], inner, tid + NT * r);
+        if (tid < FP * FP * 12 - 6 * NT) pre[6] = *plane_chunk<48>(f.aplane[i], f.grid[pa], f.grid[pb], lo[pa], lo[pb], inner, tid + NT * 6);
+        if (tid < FP * 12) pre[7] = *line_chunk<48>(f.aline[i], f.grid[pv], lo[pv], inner, tid);
+    };
+    auto fetch_basis = [&]() {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pre[r] = *reinterpret_cast<const f32q*>(f.basis_l12 + 4 * (tid + NT * r));
+        if (tid < BASIS_FLOATS / 4 - 3 * NT) pre[3] = *reinterpret_cast<const f32q*>(f.basis_l12 + 4 * (tid + NT * 3));
+    };
+    if (fits) fetch_app(0);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(3);
+    // ---------------------------------------------------------------------------------------------------- phase B: density
+    const float* sr = s_ray + gg * 8;
+    const int64_t r_glob = ray0 + g;
+    const bool live = grp_on && g < n_live;
+    uint32_t* recs = s_rec + gg * FS * REC;
+    unsigned shmask = 0u;
+    if (MODE == 2) {
+        // the 540 samples of the tile over the 64 four-lane sub-groups of the workgroup: sub-group q takes the samples t = q + 64 it
+        // (t = 20 ray + s: the record index), its four lanes gather a sample together (one 16-B quarter of the density texel each)
+        // and lane c finishes the sample of trip it = 4 k + c; the record of the next sample is read one trip ahead
+        const int q4 = tid >> 2;
+        constexpr int NSMP = FR * FS, TRIPS = (NSMP + 63) / 64;
+        u32q nra = *reinterpret_cast<const u32q*>(s_rec + q4 * REC), nrb = *reinterpret_cast<const u32q*>(s_rec + q4 * REC + 4);
 #pragma unroll 1
-            for (int k = 0; k < FS / 4; ++k) {
-                const int s = c + 4 * k;
-                const float z = z_of(f, 0, FS, 0.0f, s);
-                const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
-                const bool inside = live && inside_aabb(f, p);
-                u32q r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
-                if (inside) {
+        for (int k = 0; k < (TRIPS + 3) / 4; ++k) {
+            float feat_mine = 0.0f;
+            bool valid_mine = false;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int it = 4 * k + j;
+                if (it >= TRIPS) break;
+                const int t = min(q4 + 64 * it, NSMP - 1);
+                const RecView rv = unpack_rec(nra, nrb);
+                {
+                    const uint32_t* rp = s_rec + min(t + 64, NSMP - 1) * REC;
+                    nra = *reinterpret_cast<const u32q*>(rp); nrb = *reinterpret_cast<const u32q*>(rp + 4);
+                }
+                float part = 0.0f;
+                if (fits) {
+                    // all 18 taps of the three planes in flight before the first one is used (left to itself the compiler takes
+                    // them plane by plane: three LDS round trips in a row)
+                    f32q tp[3][6];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
+                        const float* P = s_patch + i * PLANE16 + ((rv.r[ax_b] * FP + rv.r[ax_a]) * 16 + 4 * c);
+                        const int da = rv.d[ax_a] * 16, db = rv.d[ax_b] * (FP * 16);
+                        tp[i][0] = *reinterpret_cast<const f32q*>(P); tp[i][1] = *reinterpret_cast<const f32q*>(P + da);
+                        tp[i][2] = *reinterpret_cast<const f32q*>(P + db); tp[i][3] = *reinterpret_cast<const f32q*>(P + db + da);
+                        const float* L = s_patch + 3 * PLANE16 + i * LINE16 + (rv.r[ax_v] * 16 + 4 * c);
+                        tp[i][4] = *reinterpret_cast<const f32q*>(L); tp[i][5] = *reinterpret_cast<const f32q*>(L + rv.d[ax_v] * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
+                        const float pw[4] = {rv.wt[ax_b][0] * rv.wt[ax_a][0], rv.wt[ax_b][0] * rv.wt[ax_a][1],
+                                             rv.wt[ax_b][1] * rv.wt[ax_a][0], rv.wt[ax_b][1] * rv.wt[ax_a][1]};
+                        const float lw[2] = {rv.wt[ax_v][0], rv.wt[ax_v][1]};
+                        const f32q pq = lerp_plane_q(tp[i][0], tp[i][1], tp[i][2], tp[i][3], pw), lq = lerp_line_q(tp[i][4], tp[i][5], lw);
+                        part = fmaf(pq.w, lq.w, fmaf(pq.z, lq.z, fmaf(pq.y, lq.y, fmaf(pq.x, lq.x, part))));
+                    }
+                } else if (rv.valid) {
+                    const int ry = t / FS, s = t - ry * FS;
+                    const float* srr = s_ray + ry * 8;
+                    const float z = z_of(f, 0, FS, 0.0f, s);
+                    const float p[3] = {srr[0] + srr[3] * z, srr[1] + srr[4] * z, srr[2] + srr[5] * z};
                     float xn[3];
                     field_normalize(f, p, xn);
-                    const float mv = f.mask ? mask_value(f, p) : 1.0f;
-                    uint32_t packed = (mv > 0.0f) ? (1u << 15) : 0u;
-                    float wt[3][2];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        const AxisTap t = axis_tap(xn[ax], f.grid[ax]);
-                        packed |= (uint32_t)(((t.i[0] - lo[ax]) & 15) | ((t.i[1] - t.i[0]) << 4)) << (5 * ax);
-                        wt[ax][0] = t.w[0]; wt[ax][1] = t.w[1];
-                    }
-                    r0.y = packed; r0.z = __float_as_uint(wt[0][0]); r0.w = __float_as_uint(wt[0][1]);
-                    r1.x = __float_as_uint(wt[1][0]); r1.y = __float_as_uint(wt[1][1]);
-                    r1.z = __float_as_uint(wt[2][0]); r1.w = __float_as_uint(wt[2][1]);
+                    part = density_partial(f, xn, c);
                 }
-                if (MODE == 1) r0.x = __float_as_uint(live ? a.weights[(ray0 + g) * FS + s] : 0.0f);
-                uint32_t* rec = s_rec + (g * FS + s) * REC;
-                *reinterpret_cast<u32q*>(rec) = r0;
-                *reinterpret_cast<u32q*>(rec + 4) = r1;
+                const float feat = sum4_dpp(rv.valid ? part : 0.0f);
+                if (j == c) { feat_mine = feat; valid_mine = rv.valid; }
             }
+            // lane c finishes the sample of trip 4k + c: sigma and alpha (tensorBase.py:25,849)
+            const int t = q4 + 64 * (4 * k + c);
+            const int s = t % FS;
+            const float sigma = valid_mine ? feature2density(f, feat_mine) : 0.0f;
+            const float zs = z_of(f, 0, FS, 0.0f, s);
+            const float dist = (s + 1 < FS) ? (z_of(f, 0, FS, 0.0f, s + 1) - zs) : 0.0f;       // tensorBase.py:800-803
+            const float alpha = 1.0f - expf(-sigma * (dist * f.distance_scale));
+            if (4 * k + c < TRIPS && t < NSMP) s_rec[t * REC] = __float_as_uint(alpha);
         }
-        if (MODE == 2 && fits) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                f32q t[5] = {pre[5 * i], pre[5 * i + 1], pre[5 * i + 2], pre[5 * i + 3], pre[5 * i + 4]};
-                stash<FP * FP * 4, 5>(s_patch + i * PLANE16, tid, t);
-                f32q l[1] = {prel[i]};
-                stash<FP * 4, 1>(s_patch + 3 * PLANE16 + i * LINE16, tid, l);
-            }
-        }
+        STAMP(4);
         __syncthreads();
-        // appearance plane 0 on its way while phase B computes
-        f32q prea[2];
-        if (fits) {
-            f32q t[14];
-            fetch_plane<48, 14>(f.aplane[0], G0, G1, lo[0], lo[1], inner, tid, t);
-            fetch_line<48, 2>(f.aline[0], G2, lo[2], inner, tid, prea);
+        // the transmittance product of the ray (tensorBase.py:27-32), all eight lanes alike
+        float run_T = 1.0f, run_acc = 0.0f, run_depth = 0.0f;
+        int run_valid = 0, run_app = 0;
+        const bool writer = live && (tid & 7) == 0;
+        typedef uint32_t u32d __attribute__((ext_vector_type(2)));
+        u32d av[FS];                                   // (alpha, packed) of every sample: all reads in flight before the chain
 #pragma unroll
-            for (int r = 0; r < 14; ++r) pre[r] = t[r];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ------------------------------------------------------------------------------------------------ phase B: density
-        const float* sr = s_ray + (grp_on ? g : 0) * 8;
-        const int64_t r_glob = ray0 + g;
-        const bool live = grp_on && g < n_live;
-        unsigned shmask = 0u;
-        if (MODE == 2) {
-#pragma unroll 1
-            for (int k = 0; k < FS / 4; ++k) {
-                float feat_mine = 0.0f;
-                bool valid_mine = false;
-#pragma unroll 1
-                for (int j = 0; j < 4; ++j) {
-                    const int s = 4 * k + j;
-                    const RecView rv = read_rec(s_rec + ((grp_on ? g : 0) * FS + s) * REC);
-                    float part = 0.0f;
-                    if (fits) {
+        for (int s = 0; s < FS; ++s) av[s] = *reinterpret_cast<const u32d*>(recs + s * REC);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
-                            const float* P = s_patch + i * PLANE16 + ((rv.r[ax_b] * FP + rv.r[ax_a]) * 16 + 4 * c);
-                            const int da = rv.d[ax_a] * 16, db = rv.d[ax_b] * (FP * 16);
-                            const f32q nw = *reinterpret_cast<const f32q*>(P), ne = *reinterpret_cast<const f32q*>(P + da);
-                            const f32q sw = *reinterpret_cast<const f32q*>(P + db), se = *reinterpret_cast<const f32q*>(P + db + da);
-                            const float* L = s_patch + 3 * PLANE16 + i * LINE16 + (rv.r[ax_v] * 16 + 4 * c);
-                            const f32q ll = *reinterpret_cast<const f32q*>(L), lh = *reinterpret_cast<const f32q*>(L + rv.d[ax_v] * 16);
-                            const float pw[4] = {rv.wt[ax_b][0] * rv.wt[ax_a][0], rv.wt[ax_b][0] * rv.wt[ax_a][1],
-                                                 rv.wt[ax_b][1] * rv.wt[ax_a][0], rv.wt[ax_b][1] * rv.wt[ax_a][1]};
-                            const float lw[2] = {rv.wt[ax_v][0], rv.wt[ax_v][1]};
-                            const f32q pq = lerp_plane_q(nw, ne, sw, se, pw), lq = lerp_line_q(ll, lh, lw);
-                            part = fmaf(pq.w, lq.w, fmaf(pq.z, lq.z, fmaf(pq.y, lq.y, fmaf(pq.x, lq.x, part))));
-                        }
-                    } else if (rv.valid) {
-                        const float z = z_of(f, 0, FS, 0.0f, s);
-                        const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
-                        float xn[3];
-                        field_normalize(f, p, xn);
-                        part = density_partial(f, xn, c);
-                    }
-                    const float feat = sum4(rv.valid ? part : 0.0f);
-                    if (j == c) { feat_mine = feat; valid_mine = rv.valid; }
-                }
-                // lane c finishes sample 4k + c: sigma and alpha (tensorBase.py:25,849)
-                const int s = 4 * k + c;
-                const float sigma = valid_mine ? feature2density(f, feat_mine) : 0.0f;
-                const float zs = z_of(f, 0, FS, 0.0f, s);
-                const float dist = (s + 1 < FS) ? (z_of(f, 0, FS, 0.0f, s + 1) - zs) : 0.0f;       // tensorBase.py:800-803
-                const float alpha = 1.0f - expf(-sigma * (dist * f.distance_scale));
-                if (grp_on) s_rec[(g * FS + s) * REC] = __float_as_uint(alpha);
+        for (int s = 0; s < FS; ++s) {
+            const float alpha = __uint_as_float(av[s].x);
+            const bool valid = (av[s].y >> 15) & 1u;
+            const float z = z_of(f, 0, FS, 0.0f, s);
+            const float w = alpha * run_T;
+            run_T = run_T * ((1.0f - alpha) + 1e-10f);
+            run_acc += w;
+            run_depth += w * z;
+            run_valid += valid ? 1 : 0;
+            const bool sh = w > f.weight_thres;                                     // tensorBase.py:851
+            run_app += sh ? 1 : 0;
+            shmask |= (sh ? 1u : 0u) << s;
+            if (writer) {
+                recs[s * REC] = __float_as_uint(w);
+
+#ifndef FAN_STAMPS
+                if (a.alpha) a.alpha[r_glob * FS + s] = alpha;
+#endif
+
             }
+        }
+        if (writer) {
+            a.acc[r_glob] = run_acc;
+            a.depth[r_glob] = run_depth + (1.0f - run_acc) * sr[7];
+            if (a.counts) { a.counts[r_glob * 2] = run_valid; a.counts[r_glob * 2 + 1] = run_app; }
+        }
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < FS; ++s) shmask |= (__uint_as_float(recs[s * REC]) > f.weight_thres ? 1u : 0u) << s;
+    }
+    STAMP(5);
+    if (!live) shmask = 0u;
+    const bool any = shmask != 0u;
+    const unsigned mymask = shmask & (h ? 0xAAAAAu : 0x55555u);       // this sub-group's shaded samples
+    // ---------------------------------------------------------------------------------------------------- phase C: appearance
+    float accp[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) accp[i] = 0.0f;
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            __syncthreads();                              // phase B / the previous plane is done with the patch buffer
+#pragma unroll
+            for (int r = 0; r < 6; ++r) *reinterpret_cast<f32q*>(s_patch + 4 * (tid + NT * r)) = pre[r];
+            if (tid < FP * FP * 12 - 6 * NT) *reinterpret_cast<f32q*>(s_patch + 4 * (tid + NT * 6)) = pre[6];
+            if (tid < FP * 12) *reinterpret_cast<f32q*>(s_patch + PLANE48 + 4 * tid) = pre[7];
             __syncthreads();
-            // the transmittance product of the ray (tensorBase.py:27-32), all four lanes alike
-            float run_T = 1.0f, run_acc = 0.0f, run_depth = 0.0f;
-            int run_valid = 0, run_app = 0;
-            uint32_t* rec = s_rec + (grp_on ? g : 0) * FS * REC;
-#pragma unroll 1
-            for (int s = 0; s < FS; ++s) {
-                const float alpha = __uint_as_float(rec[s * REC]);
-                const bool valid = (rec[s * REC + 1] >> 15) & 1u;
-                const float z = z_of(f, 0, FS, 0.0f, s);
-                const float w = alpha * run_T;
-                run_T = run_T * ((1.0f - alpha) + 1e-10f);
-                run_acc += w;
-                run_depth += w * z;
-                run_valid += valid ? 1 : 0;
-                const bool sh = w > f.weight_thres;                                     // tensorBase.py:851
-                run_app += sh ? 1 : 0;
-                shmask |= (sh ? 1u : 0u) << s;
-                if (c == 0 && live) {
-                    rec[s * REC] = __float_as_uint(w);
-                    if (a.alpha) a.alpha[r_glob * FS + s] = alpha;
-                }
+            if (i < 2) fetch_app(i + 1);                  // the next plane (registers) under this plane's arithmetic
+            else fetch_basis();                           // basis_mat for phase D
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(6 + 2 * i);
+            const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
+            unsigned m = mymask;
+            // the record of the next sample is read one trip ahead
+            u32q na = {0u, 0u, 0u, 0u}, nb = {0u, 0u, 0u, 0u};
+            if (m) {
+                const uint32_t* rp = recs + (__ffs((int)m) - 1) * REC;
+                na = *reinterpret_cast<const u32q*>(rp); nb = *reinterpret_cast<const u32q*>(rp + 4);
             }
-            if (c == 0 && live) {
-                a.acc[r_glob] = run_acc;
-                a.depth[r_glob] = run_depth + (1.0f - run_acc) * sr[7];
-                if (a.counts) { a.counts[r_glob * 2] = run_valid; a.counts[r_glob * 2 + 1] = run_app; }
-            }
-        } else {
-            const uint32_t* rec = s_rec + (grp_on ? g : 0) * FS * REC;
-#pragma unroll 1
-            for (int s = 0; s < FS; ++s) shmask |= (__uint_as_float(rec[s * REC]) > f.weight_thres ? 1u : 0u) << s;
-        }
-        if (!live) shmask = 0u;
-        const bool any = shmask != 0u;
-        // ------------------------------------------------------------------------------------------------ phase C: appearance
-        float accp[36];
-#pragma unroll
-        for (int i = 0; i < 36; ++i) accp[i] = 0.0f;
-        const uint32_t* recs = s_rec + (grp_on ? g : 0) * FS * REC;
-        if (fits) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                __syncthreads();                              // phase B / the previous plane is done with the patch buffer
-                {
-                    f32q t[14];
-#pragma unroll
-                    for (int r = 0; r < 14; ++r) t[r] = pre[r];
-                    stash<FP * FP * 12, 14>(s_patch, tid, t);
-                    stash<FP * 12, 2>(s_patch + PLANE48, tid, prea);
-                }
-                __syncthreads();
-                if (i < 2) {                                  // the next plane (registers) under this plane's arithmetic
-                    const int n = i + 1, na = mat_a(n), nb = mat_b(n), nv = vec_ax(n);
-                    f32q t[14];
-                    fetch_plane<48, 14>(f.aplane[n], f.grid[na], f.grid[nb], lo[na], lo[nb], inner, tid, t);
-                    fetch_line<48, 2>(f.aline[n], f.grid[nv], lo[nv], inner, tid, prea);
-#pragma unroll
-                    for (int r = 0; r < 14; ++r) pre[r] = t[r];
-                } else {                                      // basis_mat for phase D
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int chunk = tid + NT * r;
-                        if (chunk < BASIS_FLOATS / 4) pre[r] = *reinterpret_cast<const f32q*>(f.basis_l12 + 4 * chunk);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
-                unsigned m = shmask;
-                while (m) {
-                    const int s = __ffs((int)m) - 1;
-                    m &= m - 1u;
-                    const RecView rv = read_rec(recs + s * REC);
-                    const float* P = s_patch + ((rv.r[ax_b] * FP + rv.r[ax_a]) * 48 + 4 * c);
-                    const int da = rv.d[ax_a] * 48, db = rv.d[ax_b] * (FP * 48);
-                    const float* L = s_patch + PLANE48 + (rv.r[ax_v] * 48 + 4 * c);
-                    const int dv = rv.d[ax_v] * 48;
-                    const float pw[4] = {rv.wt[ax_b][0] * rv.wt[ax_a][0], rv.wt[ax_b][0] * rv.wt[ax_a][1],
-                                         rv.wt[ax_b][1] * rv.wt[ax_a][0], rv.wt[ax_b][1] * rv.wt[ax_a][1]};
-                    const float lw[2] = {rv.wt[ax_v][0], rv.wt[ax_v][1]};
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {             // quarter c + 4 j of the 192-B texel
-                        const f32q nw = *reinterpret_cast<const f32q*>(P + 16 * j), ne = *reinterpret_cast<const f32q*>(P + 16 * j + da);
-                        const f32q sw = *reinterpret_cast<const f32q*>(P + 16 * j + db), se = *reinterpret_cast<const f32q*>(P + 16 * j + db + da);
-                        const f32q ll = *reinterpret_cast<const f32q*>(L + 16 * j), lh = *reinterpret_cast<const f32q*>(L + 16 * j + dv);
-                        const f32q pr = lerp_plane_q(nw, ne, sw, se, pw) * lerp_line_q(ll, lh, lw);
-                        accp[12 * j + 4 * i + 0] = fmaf(rv.w, pr.x, accp[12 * j + 4 * i + 0]);
-                        accp[12 * j + 4 * i + 1] = fmaf(rv.w, pr.y, accp[12 * j + 4 * i + 1]);
-                        accp[12 * j + 4 * i + 2] = fmaf(rv.w, pr.z, accp[12 * j + 4 * i + 2]);
-                        accp[12 * j + 4 * i + 3] = fmaf(rv.w, pr.w, accp[12 * j + 4 * i + 3]);
-                    }
-                }
-            }
-        } else {
-            // the gather path: a tile whose samples do not fit one patch reads its taps where the general kernels do
-            unsigned m = shmask;
             while (m) {
-                const int s = __ffs((int)m) - 1;
                 m &= m - 1u;
-                const float w = __uint_as_float(recs[s * REC]);
-                const float z = z_of(f, 0, FS, 0.0f, s);
-                const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
-                float xn[3];
-                field_normalize(f, p, xn);
+                const RecView rv = unpack_rec(na, nb);
+                if (m) {
+                    const uint32_t* rp = recs + (__ffs((int)m) - 1) * REC;
+                    na = *reinterpret_cast<const u32q*>(rp); nb = *reinterpret_cast<const u32q*>(rp + 4);
+                }
+                const float* P = s_patch + ((rv.r[ax_b] * FP + rv.r[ax_a]) * 48 + 4 * c);
+                const int da = rv.d[ax_a] * 48, db = rv.d[ax_b] * (FP * 48);
+                const float* L = s_patch + PLANE48 + (rv.r[ax_v] * 48 + 4 * c);
+                const int dv = rv.d[ax_v] * 48;
+                const float pw[4] = {rv.wt[ax_b][0] * rv.wt[ax_a][0], rv.wt[ax_b][0] * rv.wt[ax_a][1],
+                                     rv.wt[ax_b][1] * rv.wt[ax_a][0], rv.wt[ax_b][1] * rv.wt[ax_a][1]};
+                const float lw[2] = {rv.wt[ax_v][0], rv.wt[ax_v][1]};
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float prod[12];
-                    app_products_lane(f, xn, c + 4 * j, prod);
-#pragma unroll
-                    for (int q = 0; q < 12; ++q) accp[12 * j + q] = fmaf(w, prod[q], accp[12 * j + q]);
+                for (int j = 0; j < 3; ++j) {             // quarter c + 4 j of the 192-B texel
+                    const f32q nw = *reinterpret_cast<const f32q*>(P + 16 * j), ne = *reinterpret_cast<const f32q*>(P + 16 * j + da);
+                    const f32q sw = *reinterpret_cast<const f32q*>(P + 16 * j + db), se = *reinterpret_cast<const f32q*>(P + 16 * j + db + da);
+                    const f32q ll = *reinterpret_cast<const f32q*>(L + 16 * j), lh = *reinterpret_cast<const f32q*>(L + 16 * j + dv);
+                    const f32q pr = lerp_plane_q(nw, ne, sw, se, pw) * lerp_line_q(ll, lh, lw);
+                    accp[12 * j + 4 * i + 0] = fmaf(rv.w, pr.x, accp[12 * j + 4 * i + 0]);
+                    accp[12 * j + 4 * i + 1] = fmaf(rv.w, pr.y, accp[12 * j + 4 * i + 1]);
+                    accp[12 * j + 4 * i + 2] = fmaf(rv.w, pr.z, accp[12 * j + 4 * i + 2]);
+                    accp[12 * j + 4 * i + 3] = fmaf(rv.w, pr.w, accp[12 * j + 4 * i + 3]);
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int chunk = tid + NT * r;
-                if (chunk < BASIS_FLOATS / 4) pre[r] = *reinterpret_cast<const f32q*>(f.basis_l12 + 4 * chunk);
-            }
+            STAMP(7 + 2 * i);
         }
-        // ------------------------------------------------------------------------------------------------ phase D: basis_mat
-        __syncthreads();
-        {
-            f32q t[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) t[r] = pre[r];
-            stash<BASIS_FLOATS / 4, 8>(s_patch, tid, t);
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int oo = 0; oo < 27; ++oo) {
-            float v[3];
+    } else {
+        // the gather path: a tile whose samples do not fit one patch reads its taps where the general kernels do
+        unsigned m = mymask;
+        while (m) {
+            const int s = __ffs((int)m) - 1;
+            m &= m - 1u;
+            const float w = __uint_as_float(recs[s * REC]);
+            const float z = z_of(f, 0, FS, 0.0f, s);
+            const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
+            float xn[3];
+            field_normalize(f, p, xn);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float* bq = s_patch + (oo * 12 + c + 4 * j) * 12;
-                const f32q b0 = *reinterpret_cast<const f32q*>(bq), b1 = *reinterpret_cast<const f32q*>(bq + 4),
-                           b2 = *reinterpret_cast<const f32q*>(bq + 8);
-                const float bl[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-                float acc = 0.0f;
+                float prod[12];
+                app_products_lane(f, xn, c + 4 * j, prod);
 #pragma unroll
-                for (int kk = 0; kk < 12; ++kk) acc = fmaf(bl[kk], accp[12 * j + kk], acc);
-                v[j] = acc;
+                for (int q = 0; q < 12; ++q) accp[12 * j + q] = fmaf(w, prod[q], accp[12 * j + q]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const float out = sum4((v[0] + v[1]) + v[2]);         // quarters (c, c+4, c+8), then the four lanes by xor butterfly
-            if (c == 0 && grp_on) s_feat[g * 28 + oo] = out;
         }
-        if (c == 0 && grp_on) s_feat[g * 28 + 27] = any ? 1.0f : 0.0f;
-        __syncthreads();
-        for (int t = tid; t < n_live * 7; t += NT)
-            *reinterpret_cast<f32q*>(a.feat + ray0 * 28 + 4 * t) = *reinterpret_cast<const f32q*>(s_feat + 4 * t);
+        fetch_basis();
     }
+    // ---------------------------------------------------------------------------------------------------- phase D: basis_mat
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) *reinterpret_cast<f32q*>(s_patch + 4 * (tid + NT * r)) = pre[r];
+    if (tid < BASIS_FLOATS / 4 - 3 * NT) *reinterpret_cast<f32q*>(s_patch + 4 * (tid + NT * 3)) = pre[3];
+    // even samples + odd samples: both sub-groups of a ray hold the ray's sums afterwards
+#pragma unroll
+    for (int i = 0; i < 36; ++i) accp[i] = accp[i] + xor4_dpp(accp[i]);
+    __syncthreads();
+    STAMP(12);
+    f32q bn[9];                                        // the basis rows of the next output are read one trip ahead
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bn[3 * j + q] = *reinterpret_cast<const f32q*>(s_patch + (h * 12 + c + 4 * j) * 12 + 4 * q);
+#pragma unroll 1
+    for (int oo = h; oo < 27; oo += 2) {
+        f32q bc[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) bc[q] = bn[q];
+        const int on = min(oo + 2, 26);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bn[3 * j + q] = *reinterpret_cast<const f32q*>(s_patch + (on * 12 + c + 4 * j) * 12 + 4 * q);
+        float v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32q b0 = bc[3 * j], b1 = bc[3 * j + 1], b2 = bc[3 * j + 2];
+            const float bl[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+            float acc = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk) acc = fmaf(bl[kk], accp[12 * j + kk], acc);
+            v[j] = acc;
+        }
+        const float out = sum4_dpp((v[0] + v[1]) + v[2]);         // quarters (c, c+4, c+8), then the four lanes by xor butterfly
+        if (c == 0 && grp_on) s_feat[g * 28 + oo] = out;
+    }
+    if ((tid & 7) == 0 && grp_on) s_feat[g * 28 + 27] = any ? 1.0f : 0.0f;
+    STAMP(13);
+    __syncthreads();
+    if (tid < n_live * 7)
+        *reinterpret_cast<f32q*>(a.feat + ray0 * 28 + 4 * tid) = *reinterpret_cast<const f32q*>(s_feat + 4 * tid);
+    STAMP(14);
 }
 
 }  // namespace

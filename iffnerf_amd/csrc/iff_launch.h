@@ -24,6 +24,7 @@ hipError_t launch_ref_shade(const FieldDev& f, const float* dirs, const float* f
 hipError_t launch_isocell_emit(const float* cells27x3_host, const float* pts, const float* nrm, int64_t P, float* ori,
                                float* dirs, float* rays6, hipStream_t s);
 size_t march_workspace_bytes(int64_t R, int S);
+int march_plan(const FieldDev& f, int mode, int S);
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
                         float* rgb, float* depth, float* acc, float* alpha, int* counts, float* feat_out, void* ws,
                         size_t ws_bytes, float* stage_ms_host, hipStream_t s);

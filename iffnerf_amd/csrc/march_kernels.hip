@@ -377,6 +377,14 @@ __global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance12(FieldDev f, M
 static size_t march_feat_offset(int64_t R, int S) { return ((size_t)R * (size_t)S * sizeof(float) + 255) / 256 * 256; }
 size_t march_workspace_bytes(int64_t R, int S) { return march_feat_offset(R, S) + (size_t)R * 28 * sizeof(float); }
 
+// 0 = the general kernels, 1 = K4a + the fan kernel's appearance half (A/B aid), 2 = the fused fan kernel.
+// IFF_MARCH_FAN (environment, read once; tuning / A-B aid) caps the choice; iff_field_desc.density_lanes != 0 names one of the
+// general kernels and therefore keeps them.
+int march_plan(const FieldDev& f, int mode, int S) {
+    static const int fan_knob = [] { const char* e = getenv("IFF_MARCH_FAN"); return e ? atoi(e) : 2; }();
+    return (fan_knob > 0 && f.density_lanes == 0 && fan_march_eligible(f, mode, S)) ? (fan_knob == 1 ? 1 : 2) : 0;
+}
+
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
                         float* rgb, float* depth, float* acc, float* alpha, int* counts, float* feat_out, void* ws,
                         size_t ws_bytes, float* stage_ms_host, hipStream_t s) {
@@ -395,10 +403,7 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     a.feat = feat_out ? feat_out : (float*)((char*)ws + march_feat_offset(R, S));
     a.n_tiles = (R + RPB - 1) / RPB;
     if (a.n_tiles == 0) return hipSuccess;
-    // IFF_MARCH_FAN (tuning / A-B aid): 2 = the fused fan kernel where eligible, 1 = K4a + the fan kernel's appearance
-    // half, 0 = the general kernels (default while the fan kernel is being tuned).  iff_field_desc.density_lanes != 0 also keeps the general kernels (it names one of them).
-    static const int fan_knob = [] { const char* e = getenv("IFF_MARCH_FAN"); return e ? atoi(e) : 0; }();
-    const int fan = (fan_knob > 0 && f.density_lanes == 0 && fan_march_eligible(f, mode, S)) ? fan_knob : 0;
+    const int fan = march_plan(f, mode, S);
     hipError_t e = hipSuccess;
     int64_t grid;
     if (fan != 2) {

@@ -204,6 +204,10 @@ class FieldHandle:
         return cls._dummy(device, mask_volume=mask_volume, mask_aabb=mask_aabb, unisphere=unisphere)
 
     # ------------------------------------------------------------------ march
+    def march_plan(self, mode: int = MARCH_POINT, n_samples: int = -1) -> int:
+        """``iff_march_plan``: 2 when the fused fan kernel serves this march, 0 for the general kernels."""
+        return int(_lib.lib().iff_march_plan(self._h, int(mode), int(n_samples)))
+
     def march(self, rays: torch.Tensor, mode: int, n_samples: int = -1, bg=(0.0, 0.0, 0.0), want_alpha: bool = True,
               want_counts: bool = False, stage_ms: Optional[list] = None):
         """stage_ms: pass an empty list to run the instrumented (synchronous) variant; it receives the 3 launch times."""

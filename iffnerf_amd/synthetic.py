@@ -219,6 +219,13 @@ WORKLOADS = {
                    density_offset=-10.0, blob_sigma=0.30, mask_radius=0.62),
         gen_points=2371, queries=8, shared_rays=False,      # 8 x 47 sampler workgroups: two steps' samplers fit the device together
         describe="bicycle-shaped TensorVMSplit 640^3, unisphere contraction, density_shift 0, gen_points=2371 -> 64017 rays"),
+    # the reference's DEFAULT operating point: explore_model(model, gen_points=20000) (pose_estimation/model_utils.py:22-24) ->
+    # 540 000 rays on the lego-shaped model; 553 MB of logits per query image (identification_module.py:165)
+    "lego540k": dict(
+        field=dict(grid=(300, 300, 300), aabb=((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5)), mask_res=(180, 180, 180), seed=1234,
+                   step_ratio=0.5, peak=20.0, near_far=(2.0, 6.0)),
+        gen_points=20000, queries=2, shared_rays=False,
+        describe="lego-shaped TensorVMSplit 300^3, the reference's default gen_points=20000 -> 540000 rays"),
     # configs[3]: "lego, batch of 64 query images, rays sharded across the GPUs": one emitted ray set per step
     "lego_b64": dict(
         field=dict(grid=(300, 300, 300), aabb=((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5)), mask_res=(180, 180, 180), seed=1234,

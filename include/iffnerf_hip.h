@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 7
+#define IFF_ABI_VERSION 8
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -155,12 +155,25 @@ size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t 
 /* samples per ray when n_samples <= 0: 20 for the point-centred sampler (pose_estimation/sampling.py:247), the handle's
  * nSamples (models/tensorBase.py:368) for the slab sampler */
 int32_t iff_march_default_samples(const iff_field* f, int32_t mode);
+/* Which kernels serve TensorBase.forward (models/tensorBase.py:775-917) for this (mode, n_samples) on this handle:
+ *   IFF_MARCH_PLAN_GENERAL  three launches: density + compositing per sample from the vector caches, appearance gather, Ref head
+ *   IFF_MARCH_PLAN_FAN      two launches: the fused fan kernel + Ref head.  Rays are taken 27 at a time (one iso-cell fan of
+ *                           pose_estimation/sampling.py:442-488 when they come from iff_isocell_emit); the table patches the 540
+ *                           samples of a tile touch are staged once in LDS and density, compositing, appearance and basis_mat run
+ *                           from there.  Chosen for the point-centred 20-sample march of a field without unisphere contraction
+ *                           whose ten steps span about five texels (every reference config); any rays are accepted -- a tile
+ *                           whose samples do not fit one patch is gathered from global memory by the same kernel, same results.
+ * Both plans produce the same alpha / acc / depth / sample counters bit for bit; colours agree to fp32 summation order. */
+#define IFF_MARCH_PLAN_GENERAL 0
+#define IFF_MARCH_PLAN_FAN     2
+int32_t iff_march_plan(const iff_field* f, int32_t mode, int32_t n_samples);
 int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                     int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
                     float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream);
 /* Same call (models/tensorBase.py:775-917), but SYNCHRONOUS and instrumented: stage_ms_host[3] receives the durations of
- * its three launches (density+compositing, appearance gather, Ref shading) from hipEvents on `stream`.  Measurement
- * aid for bench.py's roofline; not for the timed path. */
+ * its launches from hipEvents on `stream`: (density+compositing, appearance gather, Ref shading) under
+ * IFF_MARCH_PLAN_GENERAL, (0, fused fan kernel, Ref shading) under IFF_MARCH_PLAN_FAN.  Measurement aid for bench.py's
+ * roofline; not for the timed path. */
 int iff_march_shade_timed(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                           int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
                           float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes,

@@ -19,6 +19,7 @@ SQ_BUSY_CYCLES; ratios of like units only):
   l1_hit_rate         = 1 - TCP_TCC_READ_REQ_sum / TCP_TOTAL_CACHE_ACCESSES_sum
   vmem_rd_wave_insts, valu_wave_insts, mfma_wave_insts, lds_wave_insts = SQ_INSTS_* per launch (bench.py prices the gather
                         kernels with them: 16 cycles of a CU's texture path per dwordx4 wave-load, 4 cycles of a SIMD per VALU)
+  lds_active_cycles, lds_bank_conflict_cycles = SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT per launch, summed over the CUs
 """
 import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
@@ -71,7 +72,9 @@ def main():
                 if c in m:
                     e[name] = round(m[c] / wc, 4)
         for name, c in (("vmem_rd_wave_insts", "SQ_INSTS_VMEM_RD"), ("valu_wave_insts", "SQ_INSTS_VALU"),
-                        ("mfma_wave_insts", "SQ_INSTS_MFMA"), ("lds_wave_insts", "SQ_INSTS_LDS")):
+                        ("mfma_wave_insts", "SQ_INSTS_MFMA"), ("lds_wave_insts", "SQ_INSTS_LDS"),
+                        ("lds_active_cycles", "SQ_LDS_IDX_ACTIVE"), ("lds_bank_conflict_cycles", "SQ_LDS_BANK_CONFLICT"),
+                        ("waves", "SQ_WAVES")):
             if c in m:
                 e[name] = int(m[c])
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in m and "TCP_TCC_READ_REQ_sum" in m and m["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
@@ -84,7 +87,7 @@ def main():
             js["kernels"][k] = e
     json.dump(js, open(f"{out}_hbm_traffic.json", "w"), indent=1, sort_keys=True)
     for k in js["kernels"]:
-        if any(t in k for t in ("k4b", "k4a", "k5_trunk", "k_ref_shade", "k6_", "k_surface", "k_score")):
+        if any(t in k for t in ("k4f", "k4b", "k4a", "k5_trunk", "k_ref_shade", "k6_", "k_surface", "k_score")):
             print(k, js["kernels"][k])
 
 

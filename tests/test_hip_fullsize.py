@@ -3,7 +3,8 @@
   lego16k     300^3, 180^3 mask, gen_points 593  -> 16 011 rays          (configs[1], the bench's headline workload)
   truck32k    27e6 voxels over a non-cubic T&T box, near_far [0.01, 6], gen_points 1186 -> 32 022 rays   (configs[2])
   bicycle64k  640^3, contraction_type "unisphere", density_shift 0, gen_points 2371 -> 64 017 rays       (configs[4])
-  lego_b64    64 query images against one ray set sharded over 2 and 3 (emulated) ranks                  (configs[3])
+  lego_b64    64 query images against one ray set sharded over 2, 3 and 8 (emulated) ranks               (configs[3])
+  lego540k    the reference's default explore_model(gen_points=20000): 540 000 rays (model_utils.py:22-24)
 
 The models are the seeded synthetic ones of iffnerf_amd/synthetic.py:WORKLOADS (what bench.py --config runs); the oracle
 (oracle/, the reference's op chain on torch-CPU, pinned bit-for-bit to the reference by tests/golden) is evaluated on the
@@ -83,7 +84,7 @@ class State:
         torch.cuda.synchronize()
 
 
-CONFIGS = ("lego16k", "truck32k", "bicycle64k")
+CONFIGS = ("lego16k", "truck32k", "bicycle64k", "lego540k")
 
 
 @pytest.fixture(scope="module", params=CONFIGS)
@@ -290,7 +291,7 @@ def test_batch_of_64_queries_sharded_over_emulated_ranks(dev, idw):
         if q == 0:                                                        # the restated per-image loop is oid.test_image's arithmetic
             i0, v0, _, _ = oid.test_image(idw, tok[0], o, d, c, k)
             assert torch.equal(i0, top.indices) and torch.equal(v0, top.values)
-    for ws in (2, 3):
+    for ws in (2, 3, 8):                    # 8 = the rank count BASELINE configs[3] / [4] name: 74- and 75-point shards
         seg1 = [pipe.shard_local_logits(tok_d, P, seed, r, ws) for r in range(ws)]
         assert torch.equal(torch.cat([s[0] for s in seg1]), ori) and torch.equal(torch.cat([s[1] for s in seg1]), dirs)
         stats_all = torch.stack([s[3] for s in seg1])
@@ -313,3 +314,33 @@ def test_batch_of_64_queries_sharded_over_emulated_ranks(dev, idw):
         record("lego_b64", f"ranks{ws}_pose_translation_err", e_t)
         record("lego_b64", f"ranks{ws}_pose_rotation_err_rad", e_r)
         assert e_t <= TOL_POSE_UNITS and e_r <= TOL_POSE_RAD
+
+
+def test_top100_exactness_per_arithmetic(dev, idw):
+    """How often is the top-100 list the oracle's, bit for bit, under each matrix-product arithmetic of the library?  64 query
+    images against one full-size ray set (lego16k), the same rays for every mode: IFF_GEMM_F32 (v_mfma_f32_32x32x2_f32, a
+    k-ordered fmaf chain, unfolded heads), IFF_GEMM_BF16X3 (six bf16 products per product block) and IFF_GEMM_F16X2 (three fp16
+    products; the default).  Every list must be the oracle's up to near-tie pairs (assert_topk_matches); the count of identical
+    lists per mode goes to gpurun_out/fullsize_parity.json -> profiles/r03_fullsize_parity.json (identification_module.py:207)."""
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.pipeline import PosePipeline
+    from oracle import identify as oid
+    st = State("lego16k", dev, idw)
+    Q, k = 64, 100
+    tok = torch.stack([synthetic.make_tokens(256, 384, seed=300 + q) for q in range(Q)])
+    o, d, c = st.ori.cpu(), st.dirs.cpu(), st.rgb.cpu()
+    rf = oid.ray_encode(idw, o, d, c)
+    want = [oid.attention_map(idw, tok[q], rf).sum(0) for q in range(Q)]
+    out = {}
+    for name, mode, fold in (("F32_unfolded", H.GEMM_F32, False), ("F32_folded", H.GEMM_F32, True), ("BF16X3", H.GEMM_BF16X3, True),
+                             ("F16X2", H.GEMM_F16X2, True)):
+        pipe = PosePipeline.from_checkpoints(st.ck, idw, dev, model_up=st.up, fold_heads=fold, gemm_mode=mode)
+        identical, worst = 0, 0.0
+        for q0 in range(0, Q, 16):
+            for q in range(q0, q0 + 16):
+                _, idx, _ = pipe.identify(tok[q].to(dev), st.ori, st.dirs, st.rgb, k=k, materialize_map=False)
+                identical += int(util.assert_topk_matches(idx.cpu(), want[q], k, rel_tie=TIE_REL) == 0)
+        out[name] = identical
+        del pipe
+    record("lego16k", "top100_lists_identical_to_oracle_of_64_by_arithmetic", out)
+    assert min(out.values()) >= 56

@@ -50,7 +50,7 @@ def test_two_emulated_ranks_equal_one(pipe, dev):
     tok = _tokens(dev)
     Q, k, P = tok.shape[0], 100, 75
     want_pose, want_val, want_idx = pipe.query_sharded(tok, P, seed=77, k=k)
-    for ws in (2, 3):
+    for ws in (2, 3, 8):                    # 8 ranks: shards of 9 / 10 points = 243 / 270 rays each
         seg1 = [pipe.shard_local_logits(tok, P, 77, r, ws) for r in range(ws)]
         assert sum(s[0].shape[0] for s in seg1) == P * 27
         stats_all = torch.stack([s[3] for s in seg1])
@@ -166,12 +166,12 @@ def test_large_ray_sets_keep_the_invariants(dev):
 
 
 def test_batched_cold_queries_sharded_over_emulated_ranks_equal_one_gpu(pipe, dev):
-    """query_batch_sharded's four segments with G = 2 and 3 ranks emulated on one GPU (the three all_gathers replaced by
+    """query_batch_sharded's four segments with G = 2, 3 and 8 ranks emulated on one GPU (the three all_gathers replaced by
     stacking the per-rank messages): the G*B cold queries are those of query_batch on one GPU -- same random streams, same
     rays, hence the same top-100 lists and poses."""
     from iffnerf_amd import distributed as D
     P, k, M, B = 75, 100, 64, 2
-    for G in (2, 3):
+    for G in (2, 3, 8):                     # 8: shards of 9 / 10 points (243 / 270 rays), candidates padded from 100 per rank
         tok = torch.stack([synthetic.make_tokens(M, 384, seed=40 + q) for q in range(G * B)]).to(dev)
         want_c2w, want_idx, want_val = pipe.query_batch(tok, P, seed=1234, k=k)
         msgs = torch.stack([pipe.batch_shard_draw(tok[r * B:(r + 1) * B].contiguous(), P, 1234, r) for r in range(G)])
