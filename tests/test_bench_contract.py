@@ -47,7 +47,8 @@ def test_defaults_and_workloads():
     finally:
         sys.argv = old
     assert (a.gpus, a.config, a.in_flight) == (1, "lego16k", 4) and a.steps >= 100 and a.warmup >= 10
-    assert set(synthetic.WORKLOADS) == {"lego16k", "truck32k", "bicycle64k", "lego_b64"}
+    assert set(synthetic.WORKLOADS) == {"lego16k", "truck32k", "bicycle64k", "lego_b64", "lego540k"}
+    assert synthetic.WORKLOADS["lego540k"]["gen_points"] == 20000          # the reference's default (model_utils.py:22)
     assert synthetic.WORKLOADS["lego16k"]["gen_points"] * 27 == 16011
     assert synthetic.WORKLOADS["truck32k"]["gen_points"] * 27 == 32022
     assert synthetic.WORKLOADS["bicycle64k"]["gen_points"] * 27 == 64017
