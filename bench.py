@@ -445,7 +445,7 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     result["roofline"] = dict(kernels[0])
     result["roofline"]["traffic_source"] = traffic_source
     result["roofline"]["selected_as"] = "the longest launch of a step by this run's hipEvent timings"
-    others = {k["kernel"].split(" ")[0]: k for k in kernels[1:]}
+    others = {k["kernel"].split(" (")[0]: k for k in kernels[1:]}
     others["k_ref_shade<27, true>"] = {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>"),
                                        "note": "Ref head per ray (ref.py:103-152): vector ALU from LDS-staged weights, no roofline"}
     result["roofline"]["other_kernels"] = others

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <sys/stat.h>
+#include <exception>
 
 static thread_local char g_err[512] = "";
 
@@ -57,54 +59,72 @@ extern "C" size_t iff_field_table_bytes(const iff_field* f) { return f ? f->slab
 
 static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
+// Where every table of a field handle sits in its slab, as a function of the descriptor's dimensions alone: iff_field_create
+// lays the slab out with it and iff_field_load checks a table file against it (a file is accepted only if it is exactly what
+// iff_field_create would have produced for the dimensions it claims).
+struct FieldLayout { size_t dp[3], dl[3], ap[3], al[3], basis, basis_l, basis_l12, head, mask, n_mask, total; };
+static FieldLayout field_layout(const int G[3], int n_density, int n_app, int app_dim, int feature_c, const int mask_dims[3], bool has_mask) {
+    FieldLayout L;
+    size_t off = 0;
+    for (int i = 0; i < 3; ++i) {
+        size_t hw = (size_t)G[mat_a(i)] * G[mat_b(i)], l = (size_t)G[vec_ax(i)];
+        L.dp[i] = off; off = up256(off + hw * n_density * 4);
+        L.dl[i] = off; off = up256(off + l * n_density * 4);
+        L.ap[i] = off; off = up256(off + hw * n_app * 4);
+        L.al[i] = off; off = up256(off + l * n_app * 4);
+    }
+    L.basis = off; off = up256(off + (size_t)app_dim * 3 * n_app * 4);
+    L.basis_l = off; off = up256(off + (size_t)app_dim * 3 * n_app * 4);
+    L.basis_l12 = off; off = up256(off + (size_t)app_dim * 3 * n_app * 4);
+    L.head = off; off = up256(off + (size_t)head_offsets(app_dim, feature_c).total * 4);
+    L.n_mask = has_mask ? (size_t)mask_dims[0] * mask_dims[1] * mask_dims[2] : 0;
+    L.mask = off; off = up256(off + L.n_mask);
+    L.total = off;
+    return L;
+}
+// the range checks iff_field_create applies to a descriptor's dimensions (shared with iff_field_load)
+static int check_field_dims(const int G[3], int n_density, int n_app, int app_dim, int feature_c, int density_lanes, const int mask_dims[3],
+                            bool has_mask) {
+    for (int i = 0; i < 3; ++i) IFF_REQUIRE(G[i] >= 2 && G[i] <= 4096, "gridSize[%d] = %d out of range", i, G[i]);
+    if (n_app != 48 || app_dim != 27)
+        return fail(IFF_ERR_UNSUPPORTED, "only appearance_n_comp = 48 and app_dim = 27 are built (got %d, %d)", n_app, app_dim);
+    IFF_REQUIRE(n_density >= 4 && n_density % 4 == 0 && n_density <= 64, "density_n_comp = %d unsupported", n_density);
+    IFF_REQUIRE(density_lanes == 0 || density_lanes == 4 || (density_lanes == 1 && n_density == 16),
+                "density_lanes = %d: must be 0 (auto), 4, or 1 with density_n_comp = 16", density_lanes);
+    IFF_REQUIRE(feature_c >= 16 && feature_c <= 512 && feature_c % 16 == 0, "featureC = %d unsupported", feature_c);
+    if (has_mask)
+        for (int i = 0; i < 3; ++i) IFF_REQUIRE(mask_dims[i] >= 1 && mask_dims[i] <= 4096, "mask dim %d out of range", i);
+    for (int i = 0; i < 3; ++i) {
+        // the gathers address a table by a 32-bit byte offset from its base (iff_device.h ld4_tex)
+        const uint64_t texels = (uint64_t)G[mat_a(i)] * (uint64_t)G[mat_b(i)];
+        IFF_REQUIRE(texels < (1ull << 24) && texels * (uint64_t)std::max(n_density, n_app) * 4u < (1ull << 32),
+                    "VM plane %d has %llu texels: 2^24 texels / 4 GiB per table and more are not addressable", i,
+                    (unsigned long long)texels);
+    }
+    return 0;
+}
+
 extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field** out) {
     IFF_REQUIRE(d && out, "iff_field_create: null argument");
     *out = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    for (int i = 0; i < 3; ++i) {
-        IFF_REQUIRE(d->grid[i] >= 2 && d->grid[i] <= 4096, "gridSize[%d] = %d out of range", i, d->grid[i]);
+    for (int i = 0; i < 3; ++i)
         IFF_REQUIRE(d->density_plane[i] && d->density_line[i] && d->app_plane[i] && d->app_line[i], "null VM table %d", i);
-    }
-    if (d->n_app != 48 || d->app_dim != 27)
-        return fail(IFF_ERR_UNSUPPORTED, "only appearance_n_comp = 48 and app_dim = 27 are built (got %d, %d)", d->n_app,
-                    d->app_dim);
-    IFF_REQUIRE(d->n_density >= 4 && d->n_density % 4 == 0 && d->n_density <= 64, "density_n_comp = %d unsupported", d->n_density);
-    IFF_REQUIRE(d->density_lanes == 0 || d->density_lanes == 4 || (d->density_lanes == 1 && d->n_density == 16),
-                "density_lanes = %d: must be 0 (auto), 4, or 1 with density_n_comp = 16", d->density_lanes);
-    IFF_REQUIRE(d->feature_c >= 16 && d->feature_c <= 512 && d->feature_c % 16 == 0, "featureC = %d unsupported", d->feature_c);
     IFF_REQUIRE(d->basis && d->normal_w && d->normal_b && d->tint_w && d->tint_b && d->rough_w && d->rough_b && d->diffuse_w &&
                     d->diffuse_b && d->bottleneck_w && d->bottleneck_b && d->specular_w && d->specular_b && d->ide_mat,
                 "null Ref-head / basis tensor");
-    if (d->mask_volume)
-        for (int i = 0; i < 3; ++i) IFF_REQUIRE(d->mask_dims[i] >= 1 && d->mask_dims[i] <= 4096, "mask dim %d out of range", i);
+    const int G[3] = {d->grid[0], d->grid[1], d->grid[2]};
+    if (int rc = check_field_dims(G, d->n_density, d->n_app, d->app_dim, d->feature_c, d->density_lanes, d->mask_dims, d->mask_volume != nullptr))
+        return rc;
 
     iff_field* f = new iff_field();
     FieldDev& v = f->dev;
     memset(&v, 0, sizeof(v));
-    const int G[3] = {d->grid[0], d->grid[1], d->grid[2]};
-    for (int i = 0; i < 3; ++i) {
-        // the gathers address a table by a 32-bit byte offset from its base (iff_device.h ld4_tex)
-        const uint64_t texels = (uint64_t)G[mat_a(i)] * (uint64_t)G[mat_b(i)];
-        IFF_REQUIRE(texels < (1ull << 24) && texels * (uint64_t)std::max(d->n_density, d->n_app) * 4u < (1ull << 32),
-                    "VM plane %d has %llu texels: 2^24 texels / 4 GiB per table and more are not addressable", i,
-                    (unsigned long long)texels);
-    }
     const HeadOff ho = head_offsets(d->app_dim, d->feature_c);
-    // slab layout
-    size_t off = 0, o_dp[3], o_dl[3], o_ap[3], o_al[3];
-    for (int i = 0; i < 3; ++i) {
-        size_t hw = (size_t)G[mat_a(i)] * G[mat_b(i)], l = (size_t)G[vec_ax(i)];
-        o_dp[i] = off; off = up256(off + hw * d->n_density * 4);
-        o_dl[i] = off; off = up256(off + l * d->n_density * 4);
-        o_ap[i] = off; off = up256(off + hw * d->n_app * 4);
-        o_al[i] = off; off = up256(off + l * d->n_app * 4);
-    }
-    size_t o_basis = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
-    size_t o_basis_l = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
-    size_t o_basis_l12 = off; off = up256(off + (size_t)d->app_dim * 3 * d->n_app * 4);
-    size_t o_head = off; off = up256(off + (size_t)ho.total * 4);
-    size_t n_mask = d->mask_volume ? (size_t)d->mask_dims[0] * d->mask_dims[1] * d->mask_dims[2] : 0;
-    size_t o_mask = off; off = up256(off + n_mask);
+    const FieldLayout L = field_layout(G, d->n_density, d->n_app, d->app_dim, d->feature_c, d->mask_dims, d->mask_volume != nullptr);
+    const size_t* o_dp = L.dp; const size_t* o_dl = L.dl; const size_t* o_ap = L.ap; const size_t* o_al = L.al;
+    const size_t o_basis = L.basis, o_basis_l = L.basis_l, o_basis_l12 = L.basis_l12, o_head = L.head, o_mask = L.mask, n_mask = L.n_mask;
+    const size_t off = L.total;
     f->slab_bytes = off;
     hipError_t e = hipMalloc(&f->slab, off);
     if (e != hipSuccess) { delete f; return hip_fail(e, "hipMalloc(field tables)"); }
@@ -480,6 +500,36 @@ extern "C" int32_t iff_idnet_gemm_mode(const iff_idnet* n) {
     return n->dev.gemm_mode == 0 ? IFF_GEMM_F32 : (n->dev.fused_trunk ? IFF_GEMM_BF16X3 : IFF_GEMM_BF16X3_LAYERED);
 }
 
+// Slab layout of an identification-net handle as a function of its widths and of which optional table sets it carries
+// (fused: the fragment-ordered bf16 planes of a 256-wide encoder; f16: the fp16 hi/lo planes of IFF_GEMM_F16X2) -- shared by
+// iff_idnet_create and the table-file check of iff_idnet_load.
+struct IdLayout { size_t w1, b1, w2, b2, w3, b3, w4, b4, wk, bk, wq, bq, p1, p2, p3, p4, pk, wqf, bqf, f1, f2, f3, h1, h2, h3h, h3x, total; };
+static IdLayout idnet_layout(int C, int Fe, int IF, bool fused, bool want_f16) {
+    const int KQ = (IF + 15) / 16 * 16, XW = 160, QLD = C + 16, KXS = (IFF_RAY_INPUT + 15) / 16;
+    IdLayout L;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = up256(off + floats * 4); return o; };
+    // bf16 planes: 3 x out x K_pad halves = 1.5 floats per element
+    auto take_planes = [&](size_t out_f, size_t kpad) { return take((out_f * kpad * 3 + 1) / 2); };
+    L.w1 = take((size_t)XW * C); L.b1 = take(C); L.w2 = take((size_t)C * C); L.b2 = take(C);
+    L.w3 = take((size_t)(C + XW) * C); L.b3 = take(C); L.w4 = take((size_t)C * Fe); L.b4 = take(Fe);
+    L.wk = take((size_t)Fe * Fe); L.bk = take(Fe); L.wq = take((size_t)KQ * Fe); L.bq = take(Fe);
+    L.p1 = take_planes(C, XW); L.p2 = take_planes(C, C); L.p3 = take_planes(C, C + XW); L.p4 = take_planes(Fe, C); L.pk = take_planes(Fe, Fe);
+    L.wqf = take((size_t)KQ * QLD); L.bqf = take(QLD);
+    L.f1 = fused ? take_planes(C, XW) : 0; L.f2 = fused ? take_planes(C, C) : 0; L.f3 = fused ? take_planes(C, C + XW) : 0;
+    // fp16 hi/lo planes in fragment order (IFF_GEMM_F16X2): [k-steps][2][256][16] halves = k-steps * 4096 floats
+    L.h1 = want_f16 ? take((size_t)KXS * 4096) : 0; L.h2 = want_f16 ? take((size_t)(C / 16) * 4096) : 0;
+    L.h3h = want_f16 ? take((size_t)(C / 16) * 4096) : 0; L.h3x = want_f16 ? take((size_t)KXS * 4096) : 0;
+    L.total = off;
+    return L;
+}
+static int check_idnet_dims(int C, int Fe, int IF) {
+    IFF_REQUIRE(C >= 16 && C % 16 == 0 && Fe >= 16 && Fe % 16 == 0 && IF >= 1 && C <= 4096 && Fe <= 4096 && IF <= 4096,
+                "identification net: widths %d/%d/%d unsupported", C, Fe, IF);
+    IFF_REQUIRE(C % 32 == 0 && Fe % 32 == 0, "identification net: widths must be multiples of 32 (got %d, %d)", C, Fe);
+    return 0;
+}
+
 extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet** out) {
     IFF_REQUIRE(d && out, "iff_idnet_create: null argument");
     *out = nullptr;
@@ -487,31 +537,21 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     IFF_REQUIRE(d->l1_w && d->l1_b && d->l2_w && d->l2_b && d->l3_w && d->l3_b && d->l4_w && d->l4_b && d->q_w && d->q_b &&
                     d->k_w && d->k_b, "iff_idnet_create: null weight");
     const int C = d->feature_c, Fe = d->fea, IF = d->img_fea;
-    IFF_REQUIRE(C >= 16 && C % 16 == 0 && Fe >= 16 && Fe % 16 == 0 && IF >= 1, "iff_idnet_create: widths %d/%d/%d unsupported", C, Fe, IF);
-    IFF_REQUIRE(C % 32 == 0 && Fe % 32 == 0, "iff_idnet_create: widths must be multiples of 32 (got %d, %d)", C, Fe);
+    if (int rc = check_idnet_dims(C, Fe, IF)) return rc;
     IFF_REQUIRE(d->gemm_mode >= 0 && d->gemm_mode <= 3, "iff_idnet_create: gemm_mode must be one of IFF_GEMM_* (0..3)");
     IFF_REQUIRE(d->trunk_variant >= 0 && d->trunk_variant <= 3, "iff_idnet_create: trunk_variant must be 0 (choose) or 1..3");
     const int KQ = (IF + 15) / 16 * 16;
     const int XW = 160;                  // encoder input 141 padded to a multiple of 32 (identify_kernels.hip)
-    iff_idnet* n = new iff_idnet();
-    size_t off = 0;
-    auto take = [&](size_t floats) { size_t o = off; off = up256(off + floats * 4); return o; };
-    size_t o_w1 = take((size_t)XW * C), o_b1 = take(C), o_w2 = take((size_t)C * C), o_b2 = take(C),
-           o_w3 = take((size_t)(C + XW) * C), o_b3 = take(C), o_w4 = take((size_t)C * Fe), o_b4 = take(Fe),
-           o_wk = take((size_t)Fe * Fe), o_bk = take(Fe), o_wq = take((size_t)KQ * Fe), o_bq = take(Fe);
-    // bf16 planes: 3 x out x K_pad halves = 1.5 floats per element
-    auto take_planes = [&](size_t out_f, size_t kpad) { return take((out_f * kpad * 3 + 1) / 2); };
-    size_t o_p1 = take_planes(C, XW), o_p2 = take_planes(C, C), o_p3 = take_planes(C, C + XW), o_p4 = take_planes(Fe, C),
-           o_pk = take_planes(Fe, Fe);
     const int QLD = C + 16;
-    size_t o_wqf = take((size_t)KQ * QLD), o_bqf = take(QLD);
-    const bool fused = (C == 256);
-    size_t o_f1 = fused ? take_planes(C, XW) : 0, o_f2 = fused ? take_planes(C, C) : 0, o_f3 = fused ? take_planes(C, C + XW) : 0;
-    // fp16 hi/lo planes in fragment order (IFF_GEMM_F16X2): [k-steps][2][256][16] halves = k-steps * 4096 floats
-    const bool want_f16 = fused && d->gemm_mode == IFF_GEMM_F16X2;
     const int KXS = (IFF_RAY_INPUT + 15) / 16;
-    size_t o_h1 = want_f16 ? take((size_t)KXS * 4096) : 0, o_h2 = want_f16 ? take((size_t)(C / 16) * 4096) : 0,
-           o_h3h = want_f16 ? take((size_t)(C / 16) * 4096) : 0, o_h3x = want_f16 ? take((size_t)KXS * 4096) : 0;
+    const bool fused = (C == 256);
+    const bool want_f16 = fused && d->gemm_mode == IFF_GEMM_F16X2;
+    const IdLayout L = idnet_layout(C, Fe, IF, fused, want_f16);
+    const size_t o_w1 = L.w1, o_b1 = L.b1, o_w2 = L.w2, o_b2 = L.b2, o_w3 = L.w3, o_b3 = L.b3, o_w4 = L.w4, o_b4 = L.b4, o_wk = L.wk,
+                 o_bk = L.bk, o_wq = L.wq, o_bq = L.bq, o_p1 = L.p1, o_p2 = L.p2, o_p3 = L.p3, o_p4 = L.p4, o_pk = L.pk, o_wqf = L.wqf,
+                 o_bqf = L.bqf, o_f1 = L.f1, o_f2 = L.f2, o_f3 = L.f3, o_h1 = L.h1, o_h2 = L.h2, o_h3h = L.h3h, o_h3x = L.h3x;
+    const size_t off = L.total;
+    iff_idnet* n = new iff_idnet();
     n->slab_bytes = off;
     hipError_t e = hipMalloc(&n->slab, off);
     if (e != hipSuccess) { delete n; return hip_fail(e, "hipMalloc(idnet weights)"); }
@@ -925,20 +965,81 @@ static int read_table_file(const char* path, uint32_t kind, void* dev_struct, si
     if (!fh) return fail(IFF_ERR_INVALID_ARGUMENT, "cannot open %s", path);
     TableFileHeader h;
     int rc = 0;
+    struct stat st;
     if (fread(&h, sizeof(h), 1, fh) != 1 || memcmp(h.magic, "IFFTABLE", 8) != 0) rc = fail(IFF_ERR_INVALID_ARGUMENT, "%s is not an IFFTABLE file", path);
     else if (h.version != IFF_TABLE_FILE_VERSION || h.kind != kind || h.struct_bytes != struct_bytes)
         rc = fail(IFF_ERR_UNSUPPORTED, "%s: table file version %u kind %u descriptor %u B; this build reads version %u kind %u descriptor %zu B",
                   path, h.version, h.kind, h.struct_bytes, IFF_TABLE_FILE_VERSION, kind, struct_bytes);
+    else if (h.abi != IFF_ABI_VERSION)
+        rc = fail(IFF_ERR_UNSUPPORTED, "%s was written by ABI version %u of the library; this build is ABI version %d (re-save the tables)",
+                  path, h.abi, IFF_ABI_VERSION);
     else if (h.slab_bytes > ((uint64_t)1 << 40) || h.extra_count > ((uint64_t)1 << 32)) rc = fail(IFF_ERR_INVALID_ARGUMENT, "%s: implausible sizes", path);
+    else if (fstat(fileno(fh), &st) != 0 || (uint64_t)st.st_size != 64 + (uint64_t)struct_bytes + h.slab_bytes + 4 * h.extra_count)
+        rc = fail(IFF_ERR_INVALID_ARGUMENT, "%s is truncated or carries trailing bytes: its header promises %llu bytes", path,
+                  (unsigned long long)(64 + (uint64_t)struct_bytes + h.slab_bytes + 4 * h.extra_count));
     else {
-        slab.resize(h.slab_bytes);
-        extra.resize(h.extra_count);
+        try {
+            slab.resize(h.slab_bytes);
+            extra.resize(h.extra_count);
+        } catch (const std::exception&) {
+            fclose(fh);
+            return fail(IFF_ERR_INVALID_ARGUMENT, "%s: cannot allocate %llu bytes of host memory for its tables", path,
+                        (unsigned long long)(h.slab_bytes + 4 * h.extra_count));
+        }
         bool ok = fread(dev_struct, struct_bytes, 1, fh) == 1 && (h.slab_bytes == 0 || fread(slab.data(), h.slab_bytes, 1, fh) == 1) &&
                   (h.extra_count == 0 || fread(extra.data(), h.extra_count * sizeof(int), 1, fh) == 1);
         if (!ok) rc = fail(IFF_ERR_INVALID_ARGUMENT, "%s is truncated", path);
     }
     fclose(fh);
     return rc;
+}
+
+// a stored pointer is (offset into the slab + 1), 0 = null: does it name exactly the table `want_off` (or null when !present)?
+static bool stored_is(const void* stored, bool present, size_t want_off) {
+    return present ? (uintptr_t)stored == want_off + 1 : stored == nullptr;
+}
+
+// A field descriptor read from a file, pointers still in stored form: every dimension in the range iff_field_create accepts,
+// every table exactly where iff_field_create would have put it, the slab exactly that long, the occupied-voxel list inside the
+// mask -- so no kernel can be sent outside the slab by a corrupted or foreign file.
+static int validate_field_file(const char* path, const FieldDev& v, size_t slab_bytes, const std::vector<int>& occ) {
+    const bool has_mask = v.mask != nullptr;
+    if (int rc = check_field_dims(v.grid, v.n_density, v.n_app, v.app_dim, v.feature_c, v.density_lanes, v.mask_dims, has_mask)) return rc;
+    const FieldLayout L = field_layout(v.grid, v.n_density, v.n_app, v.app_dim, v.feature_c, v.mask_dims, has_mask);
+    bool ok = slab_bytes == L.total;
+    for (int i = 0; i < 3; ++i)
+        ok = ok && stored_is(v.dplane[i], true, L.dp[i]) && stored_is(v.dline[i], true, L.dl[i]) && stored_is(v.aplane[i], true, L.ap[i]) &&
+             stored_is(v.aline[i], true, L.al[i]);
+    ok = ok && stored_is(v.basis, true, L.basis) && stored_is(v.basis_l, true, L.basis_l) && stored_is(v.basis_l12, true, L.basis_l12) &&
+         stored_is(v.head, true, L.head) && stored_is(v.mask, has_mask, L.mask);
+    if (!ok) return fail(IFF_ERR_INVALID_ARGUMENT, "%s: the table offsets / slab size do not match the dimensions the file claims", path);
+    IFF_REQUIRE(v.n_samples >= 1 && (v.softplus == 0 || v.softplus == 1) && (v.unisphere == 0 || v.unisphere == 1) && v.step_size > 0.0f &&
+                    v.step_size < 1e30f, "%s: implausible march parameters", path);
+    IFF_REQUIRE(occ.size() <= L.n_mask, "%s: %zu occupied voxels listed for a mask of %zu", path, occ.size(), L.n_mask);
+    for (int i : occ) IFF_REQUIRE(i >= 0 && (size_t)i < L.n_mask, "%s: occupied-voxel index %d outside the mask", path, i);
+    return 0;
+}
+
+static int validate_idnet_file(const char* path, const IdNetDev& v, size_t slab_bytes) {
+    if (int rc = check_idnet_dims(v.feature_c, v.fea, v.img_fea)) return rc;
+    const bool fused = v.feature_c == 256, f16 = v.h1 != nullptr;
+    IFF_REQUIRE(!f16 || fused, "%s: fp16 planes without a 256-wide encoder", path);
+    const IdLayout L = idnet_layout(v.feature_c, v.fea, v.img_fea, fused, f16);
+    const bool ok = slab_bytes == L.total && stored_is(v.w1, true, L.w1) && stored_is(v.b1, true, L.b1) && stored_is(v.w2, true, L.w2) &&
+                    stored_is(v.b2, true, L.b2) && stored_is(v.w3, true, L.w3) && stored_is(v.b3, true, L.b3) && stored_is(v.w4, true, L.w4) &&
+                    stored_is(v.b4, true, L.b4) && stored_is(v.wk, true, L.wk) && stored_is(v.bk, true, L.bk) && stored_is(v.wq, true, L.wq) &&
+                    stored_is(v.bq, true, L.bq) && stored_is(v.p1, true, L.p1) && stored_is(v.p2, true, L.p2) && stored_is(v.p3, true, L.p3) &&
+                    stored_is(v.p4, true, L.p4) && stored_is(v.pk, true, L.pk) && stored_is(v.wqf, true, L.wqf) && stored_is(v.bqf, true, L.bqf) &&
+                    stored_is(v.f1, fused, L.f1) && stored_is(v.f2, fused, L.f2) && stored_is(v.f3, fused, L.f3) && stored_is(v.h1, f16, L.h1) &&
+                    stored_is(v.h2, f16, L.h2) && stored_is(v.h3h, f16, L.h3h) && stored_is(v.h3x, f16, L.h3x);
+    if (!ok) return fail(IFF_ERR_INVALID_ARGUMENT, "%s: the table offsets / slab size do not match the widths the file claims", path);
+    auto small = [](int e) { return e >= -64 && e <= 64; };
+    IFF_REQUIRE(v.qf_ld == v.feature_c + 16 && (v.gemm_mode == 0 || v.gemm_mode == 1) && (v.trunk_f16 == 0 || v.trunk_f16 == 1) &&
+                    (v.trunk_f16 == 0 || f16) && (v.fused_trunk == 0 || (v.fused_trunk == 1 && fused)) && v.trunk_variant >= 0 &&
+                    v.trunk_variant <= 2 && small(v.e_x) && small(v.e_h1) && small(v.e_h2) && small(v.e_h3) && small(v.e_w1) &&
+                    small(v.e_w2) && small(v.e_w3h) && small(v.e_w3x),
+                "%s: implausible identification-net parameters", path);
+    return 0;
 }
 
 extern "C" int iff_field_save(const iff_field* f, const char* path, void* stream) {
@@ -957,6 +1058,7 @@ extern "C" int iff_field_load(const char* path, void* stream, iff_field** out) {
     std::vector<int> occ;
     int rc = read_table_file(path, 1, &v, sizeof(v), slab, occ);
     if (rc) return rc;
+    if ((rc = validate_field_file(path, v, slab.size(), occ)) != 0) return rc;
     iff_field* f = new iff_field();
     f->slab_bytes = slab.size();
     f->n_occ = (int)occ.size();
@@ -992,6 +1094,7 @@ extern "C" int iff_idnet_load(const char* path, void* stream, iff_idnet** out) {
     std::vector<int> none;
     int rc = read_table_file(path, 2, &v, sizeof(v), slab, none);
     if (rc) return rc;
+    if ((rc = validate_idnet_file(path, v, slab.size())) != 0) return rc;
     iff_idnet* n = new iff_idnet();
     n->slab_bytes = slab.size();
     IFF_NET_HIP(hipMalloc(&n->slab, slab.size()));

@@ -16,6 +16,7 @@ from ._lib import check, dptr, fvec, stream_ptr
 
 GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_LAYERED, GEMM_F16X2 = 0, 1, 2, 3        # include/iffnerf_hip.h IFF_GEMM_*
 GEMM_DEFAULT = GEMM_F16X2        # falls back to BF16X3 by itself when a network does not fit fp16's range
+F16_ORIGIN_BOUND = 64.0          # |ray origin| the F16X2 scale plan covers (csrc/api.hip plan_f16_scales); PosePipeline picks BF16X3 beyond
 
 _KEYS = (("l1", "ray_preprocessor.mlp.0"), ("l2", "ray_preprocessor.mlp.2"), ("l3", "ray_preprocessor.mlp2.0"),
          ("l4", "ray_preprocessor.mlp2.2"), ("q", "attention.q_proj"), ("k", "attention.k_proj"))

@@ -95,6 +95,14 @@ class IdentificationModule(torch.nn.Module):
         if getattr(self, "_net", None) is not None:
             self._net.close()
         self._net = None
+        self._net_key = None
+
+    def _weights_key(self):
+        """Identity + in-place version of every tensor the kernel handle was built from.  ``optimizer.step()`` updates the
+        parameters in place between the validations of pose_estimation/train.py:126,145,188,222 without going through
+        ``_apply`` or ``load_state_dict``: the version counters move, and the handle is rebuilt from the new weights."""
+        ps = list(self.ray_preprocessor.parameters()) + list(self.attention.parameters())
+        return tuple((p.data_ptr(), p._version) for p in ps)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -102,6 +110,9 @@ class IdentificationModule(torch.nn.Module):
         return out
 
     def _idnet(self):
+        key = self._weights_key()
+        if self._net is not None and getattr(self, "_net_key", None) != key:
+            self.invalidate_tables()
         if self._net is None:
             from ..hip_identify import IdNetHandle
             w = {"ray_preprocessor." + k: v for k, v in self.ray_preprocessor.state_dict().items()}
@@ -110,6 +121,7 @@ class IdentificationModule(torch.nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("IdentificationModule is on the CPU: move it to the GPU; libiffnerf_hip has no CPU path")
             self._net = IdNetHandle(w, dev)
+            self._net_key = key
         return self._net
 
     def _training_graph(self, *tensors) -> bool:

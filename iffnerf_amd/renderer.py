@@ -19,7 +19,7 @@ def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray
                                 is_train=False, device="cuda"):
     if ndc_ray or is_train:
         raise RuntimeError("OctreeRender_trilinear_fast: ndc_ray / is_train are outside the inference path")
-    step = max(int(chunk), MAX_RAYS_PER_LAUNCH)
+    step = min(max(int(chunk), 4096), MAX_RAYS_PER_LAUNCH)      # the [R, nSamples] weight workspace stays bounded whatever `chunk` says
     rgbs, depths = [], []
     for lo in range(0, rays.shape[0], step):
         rgb, depth, _, _, _, _ = tensorf.march(rays[lo:lo + step].to(device), point_centred=False, N_samples=N_samples,

@@ -306,7 +306,11 @@ def test_batch_of_64_queries_sharded_over_emulated_ranks(dev, idw):
         # swapped; anything else fails inside assert_topk_matches.  Measured: 62-64 of the 64 lists are identical.
         swapped = [q for q in range(Q) if util.assert_topk_matches(idx[q].cpu(), want_score[q], k, rel_tie=TIE_REL) > 0]
         record("lego_b64", f"ranks{ws}_queries_with_a_near_tie_swap_of_64", len(swapped))
-        assert len(swapped) <= 4
+        # the lists that CAN differ are those in which the oracle itself has a pair of scores within TIE_REL among its best 101
+        # (assert_topk_matches has refused every other difference): the count is a property of the rays drawn, bounded by that
+        tie_lists = sum(1 for q in range(Q) if util.near_tie_pairs(want_score[q], k, TIE_REL) > 0)
+        record("lego_b64", f"ranks{ws}_queries_whose_oracle_top101_has_a_near_tie_pair_of_64", tie_lists)
+        assert len(swapped) <= tie_lists and len(swapped) <= Q // 4
         torch.testing.assert_close(val.cpu(), torch.stack(want_val), atol=1e-7, rtol=5e-4)
         # a swapped pair changes nothing in the pose but the summation order of two nearly equal weights
         e_t = float((poses.cpu()[:, :3, 3] - torch.stack(want_pose)[:, :3, 3]).abs().max())
@@ -342,5 +346,6 @@ def test_top100_exactness_per_arithmetic(dev, idw):
                 identical += int(util.assert_topk_matches(idx.cpu(), want[q], k, rel_tie=TIE_REL) == 0)
         out[name] = identical
         del pipe
+    out["lists_whose_oracle_top101_has_a_near_tie_pair"] = sum(1 for q in range(Q) if util.near_tie_pairs(want[q], k, TIE_REL) > 0)
     record("lego16k", "top100_lists_identical_to_oracle_of_64_by_arithmetic", out)
-    assert min(out.values()) >= 56
+    assert min(v for n, v in out.items() if not n.startswith("lists_")) >= Q - out["lists_whose_oracle_top101_has_a_near_tie_pair"]

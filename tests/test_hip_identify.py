@@ -361,6 +361,13 @@ def test_f16x2_range_guard(dev):
     lb = b.ray_logits_folded(b.q_fold(tok), o.to(dev), d.to(dev), c.to(dev))[0]
     # logits grow with the inputs (|logit| reaches thousands here): the bar is 1e-4 at the golden vectors' scale of 64
     assert torch.isfinite(la).all() and float((la - lb).abs().max()) < TOL_LOGIT * max(1.0, float(lb.abs().max()) / 64.0)
+    # a scene box reaching beyond that bound: the pipeline keeps the range-free 3xBF16 arithmetic by itself
+    from iffnerf_amd.pipeline import PosePipeline
+    from tests import util
+    ck = dict(util.ckpt("tiny"))
+    big = dict(ck, kwargs=dict(ck["kwargs"], aabb=torch.tensor([[-100.0, -120.0, -90.0], [110.0, 100.0, 130.0]])))
+    assert PosePipeline.from_checkpoints(big, w, dev).idnet.gemm_mode == H.GEMM_BF16X3
+    assert PosePipeline.from_checkpoints(ck, w, dev).idnet.gemm_mode == H.GEMM_F16X2
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])

@@ -75,6 +75,38 @@ def test_field_from_file_is_the_same_handle(golden, tmp_path):
         IdNetHandle.from_file(str(tmp_path / "small.ifft"), dev)
     with pytest.raises(RuntimeError):
         FieldHandle.from_file(str(tmp_path / "small.ifft"), "cpu")
+    # refused: a file whose body does not match what its header / descriptor claim (the loader re-derives the slab layout from
+    # the stored dimensions and accepts only exactly that -- no table offset, dimension or list entry is taken on trust)
+    import struct
+
+    def corrupt(name, patches, tail=b""):
+        b = bytearray(data)
+        for off, fmt, val in patches:
+            struct.pack_into(fmt, b, off, val)
+        (tmp_path / name).write_bytes(bytes(b) + tail)
+        return str(tmp_path / name)
+
+    abi, struct_bytes, slab_bytes, n_occ = struct.unpack_from("<IIQQ", data, 16)
+    assert len(data) == 64 + struct_bytes + slab_bytes + 4 * n_occ and n_occ > 0
+    with pytest.raises(RuntimeError, match="ABI version"):
+        FieldHandle.from_file(corrupt("abi.ifft", [(16, "<I", abi + 1)]), dev)
+    with pytest.raises(RuntimeError, match="trailing"):
+        FieldHandle.from_file(corrupt("tail.ifft", [], tail=b"\0" * 8), dev)
+    with pytest.raises(RuntimeError):                                             # a slab size the file cannot hold
+        FieldHandle.from_file(corrupt("huge.ifft", [(24, "<Q", 1 << 39)]), dev)
+    # the descriptor starts with the 12 table pointers (stored as offset + 1), then basis x 3, mask, head, then grid[3]
+    with pytest.raises(RuntimeError, match="do not match"):
+        FieldHandle.from_file(corrupt("ptr.ifft", [(64 + 8, "<Q", slab_bytes + 4096)]), dev)
+    with pytest.raises(RuntimeError, match="do not match"):
+        FieldHandle.from_file(corrupt("ptr2.ifft", [(64, "<Q", 257)]), dev)     # inside the slab, but not where the table is
+    grid_off = 64 + 8 * 17
+    assert struct.unpack_from("<3i", data, grid_off) == tuple(util.SMALL["grid"])
+    with pytest.raises(RuntimeError, match="do not match|out of range"):
+        FieldHandle.from_file(corrupt("grid.ifft", [(grid_off, "<i", util.SMALL["grid"][0] + 1)]), dev)
+    with pytest.raises(RuntimeError, match="out of range"):
+        FieldHandle.from_file(corrupt("grid2.ifft", [(grid_off, "<i", 1 << 20)]), dev)
+    with pytest.raises(RuntimeError, match="outside the mask"):
+        FieldHandle.from_file(corrupt("occ.ifft", [(len(data) - 4, "<i", 1 << 30)]), dev)
 
 
 @pytest.mark.gpu
@@ -96,6 +128,13 @@ def test_idnet_and_pipeline_from_files(golden, tmp_path):
         fa, ka = a.ray_encode(o, d, c, want_features=True, want_k=True)
         fb, kb = b.ray_encode(o, d, c, want_features=True, want_k=True)
         assert torch.equal(fa, fb) and torch.equal(ka, kb) and torch.equal(a.q_proj(tok), b.q_proj(tok))
+    # a corrupted identification-net file is refused too (width, table offset)
+    import struct
+    data = bytearray(open(tmp_path / f"id{H.GEMM_F16X2}.ifft", "rb").read())
+    bad = bytearray(data); struct.pack_into("<Q", bad, 64, 12345)
+    (tmp_path / "idbad.ifft").write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError, match="do not match"):
+        H.IdNetHandle.from_file(str(tmp_path / "idbad.ifft"), dev)
     # the whole path from two files: same poses, same top-100 as the pipeline built from the checkpoints
     ck = util.ckpt("small")
     p1 = PosePipeline.from_checkpoints(ck, w, dev, model_up=(0.1, 0.2, 0.9))

@@ -70,3 +70,10 @@ def assert_topk_matches(idx_got: torch.Tensor, score_ref: torch.Tensor, k: int, 
     sg = s[got]
     assert bool(((sg[1:] - sg[:-1]) <= rel_tie * sg[:-1].abs()).all()), "returned order is not the oracle's score order"
     return sum(int(a != b) for a, b in zip(got, want))
+
+
+def near_tie_pairs(score_ref: torch.Tensor, k: int, rel_tie: float = 2e-5) -> int:
+    """Adjacent pairs among the oracle's k + 1 best scores that agree to ``rel_tie`` relative: the positions of a top-k list whose
+    order (or, for the last pair, membership) fp32 rounding decides in ANY evaluation, the reference's own included."""
+    s = torch.sort(score_ref.double(), descending=True).values[:k + 1]
+    return int(((s[:-1] - s[1:]) <= rel_tie * s[:-1].abs()).sum())
