@@ -164,15 +164,17 @@ def test_reference_module_paths_run_on_the_gpu(golden, dev, tmp_path, monkeypatc
     handle_before = idm._idnet()
     same_tokens()
     (idm.run_attention(img, msk, ro, -rd, rc)[0] * torch.linspace(0.0, 1.0, ro.shape[0], device=dev)).sum().backward()
-    opt = torch.optim.SGD([p_ for p_ in idm.parameters() if p_.requires_grad], lr=0.05)
-    opt.step()
+    with torch.no_grad():                   # what optimizer.step() does: in-place updates (here 1 % of each tensor's scale)
+        for p_ in idm.parameters():
+            if p_.grad is not None:
+                p_.add_(p_.grad, alpha=-0.01 * float(p_.abs().max()) / (float(p_.grad.abs().max()) + 1e-30))
     with torch.no_grad():
         same_tokens()
         s_hip3 = idm.run_attention(img, msk, ro, -rd, rc)[0]
     assert idm._idnet() is not handle_before, "the kernel handle survived an in-place parameter update"
     same_tokens()
     s_torch3 = idm.run_attention(img, msk, ro, -rd, rc)[0]
-    assert float((s_hip3 - s_hip2).abs().max()) > 1e-4                       # the step did move the scores
+    assert float((s_hip3 - s_hip2).abs().max()) > 1e-5                       # the step did move the scores
     torch.testing.assert_close(s_torch3.detach(), s_hip3, atol=1e-7, rtol=3e-4)
     # CPU tensors are refused on the training branch too
     with pytest.raises(RuntimeError, match="no CPU path"):
