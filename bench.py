@@ -478,52 +478,44 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                 wgraphs[i % 4][0].replay()
         torch.cuda.synchronize(device)
         result["warm_poses_per_s"] = round(n_w * WQ / (time.perf_counter() - tw), 2)
-        # image in -> pose out: 800 x 800 query images + alpha masks through resize / crop / normalise, a ViT-S/14
-        # of DINOv2's shape (seeded stand-in: the real weights are not available offline), token assembly and stage C against
-        # the resident rays -- ONE captured graph per batch of 16 images, 4 in flight.  The backbone is a stock fp32 torch module.
+        # image in -> pose out: 800 x 800 query images + alpha masks through resize / crop / normalise, the ViT-S/14
+        # backbone (DINOv2's architecture; seeded stand-in weights -- the real ones are not available offline), token assembly and
+        # stage C against the resident rays -- ONE captured graph per batch of 16 images, 4 in flight.  Headline figure: the backbone
+        # on the matrix cores (iff_vit_forward, bf16 operands, fp32 accumulate); beside it the same module as stock fp32 torch ops.
         from iffnerf_amd.image_frontend import ImageFrontEnd
         from iffnerf_amd.pipeline import CapturedImageQuery
         from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
-        net, grid, _ = create_standin_backbone(seed=0)
-        fe = ImageFrontEnd(net.to(device), grid)
         gen = torch.Generator().manual_seed(11)
         imgs = torch.rand(WQ, 800, 800, 3, generator=gen).to(device)
         masks = (torch.rand(WQ, 800, 800, generator=gen) > 0.2).float().to(device)
-        igraphs = [CapturedImageQuery(pipe, fe, imgs.shape, resident, TOPK) for _ in range(4)]
-        for g in igraphs:
-            g.imgs.copy_(imgs), g.masks.copy_(masks)
-        torch.cuda.synchronize(device)
-        for i in range(8):
-            with torch.cuda.stream(wstreams[i % 4]):
-                igraphs[i % 4].replay()
-        torch.cuda.synchronize(device)
-        ti = time.perf_counter()
         n_i = 40
-        for i in range(n_i):
-            with torch.cuda.stream(wstreams[i % 4]):
-                igraphs[i % 4].replay()
-        torch.cuda.synchronize(device)
-        result["image_to_pose_per_s"] = round(n_i * WQ / (time.perf_counter() - ti), 2)
-        # the same with the backbone's matrix products in bf16 (torch.autocast): a throughput option of the third-party model
-        del igraphs
-        fe16 = ImageFrontEnd(net, grid, backbone_autocast=torch.bfloat16)
-        igraphs = [CapturedImageQuery(pipe, fe16, imgs.shape, resident, TOPK) for _ in range(4)]
-        for g in igraphs:
-            g.imgs.copy_(imgs), g.masks.copy_(masks)
-        torch.cuda.synchronize(device)
-        for i in range(8):
-            with torch.cuda.stream(wstreams[i % 4]):
-                igraphs[i % 4].replay()
-        torch.cuda.synchronize(device)
-        ti = time.perf_counter()
-        for i in range(n_i):
-            with torch.cuda.stream(wstreams[i % 4]):
-                igraphs[i % 4].replay()
-        torch.cuda.synchronize(device)
-        result["image_to_pose_per_s_bf16_backbone"] = round(n_i * WQ / (time.perf_counter() - ti), 2)
+
+        def image_rate(frontend):
+            igraphs = [CapturedImageQuery(pipe, frontend, imgs.shape, resident, TOPK) for _ in range(4)]
+            for g in igraphs:
+                g.imgs.copy_(imgs), g.masks.copy_(masks)
+            torch.cuda.synchronize(device)
+            for i in range(8):
+                with torch.cuda.stream(wstreams[i % 4]):
+                    igraphs[i % 4].replay()
+            torch.cuda.synchronize(device)
+            ti = time.perf_counter()
+            for i in range(n_i):
+                with torch.cuda.stream(wstreams[i % 4]):
+                    igraphs[i % 4].replay()
+            torch.cuda.synchronize(device)
+            return round(n_i * WQ / (time.perf_counter() - ti), 2)
+
+        net, grid, _ = create_standin_backbone(seed=0)
+        net = net.to(device)
+        from iffnerf_amd.hip_vit import NativeViT
+        result["image_to_pose_per_s"] = image_rate(ImageFrontEnd(NativeViT(net, grid), grid))
+        result["image_to_pose_per_s_torch_fp32_backbone"] = image_rate(ImageFrontEnd(net, grid))
         result["image_to_pose_note"] = ("16 synthetic 800x800 RGBA queries per captured graph: bicubic resize / crop / normalise + ViT-S/14 "
-                                        "stand-in (seeded random weights, DINOv2's architecture, fp32 torch module) + token assembly kernel "
-                                        "+ stage C on resident rays with the cached encoder; 4 graphs in flight; never part of `value`")
+                                        "(DINOv2's architecture, seeded stand-in weights) + token assembly kernel + stage C on resident rays "
+                                        "with the cached encoder; 4 graphs in flight; never part of `value`.  image_to_pose_per_s runs the "
+                                        "backbone in libiffnerf_hip (iff_vit_forward: bf16 MFMA, fp32 accumulate), "
+                                        "image_to_pose_per_s_torch_fp32_backbone the same module as stock fp32 torch ops")
         result["warm_note"] = ("rays resident (the reference's eval semantics): 16 query images per graph against one ray set whose "
                                "encoder output is cached per model, 4 graphs in flight; never part of `value`")
 

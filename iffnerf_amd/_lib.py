@@ -44,6 +44,12 @@ class IdNetDesc(C.Structure):
         (n, C.c_void_p) for n in ("l1_w", "l1_b", "l2_w", "l2_b", "l3_w", "l3_b", "l4_w", "l4_b", "q_w", "q_b", "k_w", "k_b")]
 
 
+class VitDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "mlp", "patch", "grid_h", "grid_w")] + [("ln_eps", C.c_float)] + [
+        (n, C.c_void_p) for n in ("patch_w", "patch_b", "cls", "pos", "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
+                                  "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "norm_w", "norm_b")]
+
+
 # name -> (restype, argtypes); must list every function include/iffnerf_hip.h declares (tests/test_abi.py checks)
 _VP, _I32, _I64, _F, _SZ, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 SIGNATURES = {
@@ -97,6 +103,10 @@ SIGNATURES = {
     "iff_ray_logits_folded_batched_workspace": (_SZ, [_VP, _I32, _I64, _I32]),
     "iff_ray_logits_folded_batched": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_ray_logits_folded_timed": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, c_float_p, _VP]),
+    "iff_vit_create": (C.c_int, [C.POINTER(VitDesc), _VP, C.POINTER(_VP)]),
+    "iff_vit_destroy": (None, [_VP]),
+    "iff_vit_workspace": (_SZ, [_VP, _I32]),
+    "iff_vit_forward": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _VP, _SZ, _VP]),
     "iff_token_assemble": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _F, c_float_p, c_float_p, _VP, _VP, _VP]),
     "iff_mask_token_rows": (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
     "iff_ray_cache_bytes": (_SZ, [_VP, _I64]),

@@ -1105,3 +1105,81 @@ extern "C" int iff_idnet_load(const char* path, void* stream, iff_idnet** out) {
     *out = n;
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ image backbone (ViT-S/14)
+struct iff_vit {
+    VitDev dev;
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+};
+
+extern "C" void iff_vit_destroy(iff_vit* v) {
+    if (!v) return;
+    if (v->slab) (void)hipFree(v->slab);
+    delete v;
+}
+
+extern "C" int iff_vit_create(const iff_vit_desc* d, void* stream, iff_vit** out) {
+    IFF_REQUIRE(d && out, "iff_vit_create: null argument");
+    *out = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    IFF_REQUIRE(d->dim == 384 && d->heads == 6, "iff_vit_create: built for ViT-S (dim 384, 6 heads of 64); got dim %d, heads %d", d->dim, d->heads);
+    IFF_REQUIRE(d->depth >= 1 && d->depth <= 64 && d->mlp >= 128 && d->mlp % 128 == 0 && d->mlp <= 8192, "iff_vit_create: depth %d / mlp %d unsupported", d->depth, d->mlp);
+    IFF_REQUIRE(d->patch >= 1 && d->patch <= 32 && d->grid_h >= 1 && d->grid_w >= 1 && 1 + d->grid_h * d->grid_w <= 288,
+                "iff_vit_create: patch %d grid %dx%d unsupported (at most 288 tokens)", d->patch, d->grid_h, d->grid_w);
+    IFF_REQUIRE(d->patch_w && d->patch_b && d->cls && d->pos && d->ln1_w && d->ln1_b && d->qkv_w && d->qkv_b && d->proj_w && d->proj_b &&
+                    d->ls1 && d->ln2_w && d->ln2_b && d->fc1_w && d->fc1_b && d->fc2_w && d->fc2_b && d->ls2 && d->norm_w && d->norm_b,
+                "iff_vit_create: null weight");
+    const size_t D = d->dim, L = d->depth, F = d->mlp, T = 1 + (size_t)d->grid_h * d->grid_w;
+    const size_t kraw = 3 * (size_t)d->patch * d->patch, kp = (kraw + 63) / 64 * 64;
+    iff_vit* v = new iff_vit();
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
+    const size_t o_pw = take(D * kp * 2), o_qkv = take(L * 3 * D * D * 2), o_proj = take(L * D * D * 2), o_fc1 = take(L * F * D * 2),
+                 o_fc2 = take(L * D * F * 2);
+    struct { const float* src; size_t n; size_t off; } vecs[] = {
+        {d->patch_b, D, 0}, {d->cls, D, 0}, {d->pos, T * D, 0}, {d->ln1_w, L * D, 0}, {d->ln1_b, L * D, 0}, {d->ln2_w, L * D, 0},
+        {d->ln2_b, L * D, 0}, {d->qkv_b, L * 3 * D, 0}, {d->proj_b, L * D, 0}, {d->fc1_b, L * F, 0}, {d->fc2_b, L * D, 0}, {d->ls1, L * D, 0},
+        {d->ls2, L * D, 0}, {d->norm_w, D, 0}, {d->norm_b, D, 0}};
+    for (auto& x : vecs) x.off = take(x.n * 4);
+    v->slab_bytes = off;
+    hipError_t e = hipMalloc(&v->slab, off);
+    if (e != hipSuccess) { delete v; return hip_fail(e, "hipMalloc(ViT weights)"); }
+    char* b = (char*)v->slab;
+#define IFF_VIT_HIP(call)                                              \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) { iff_vit_destroy(v); return hip_fail(e__, #call); } \
+    } while (0)
+    IFF_VIT_HIP(launch_vit_pad_rows(d->patch_w, (int)D, (int)kraw, (int)kp, b + o_pw, s));
+    IFF_VIT_HIP(launch_vit_to_bf16(d->qkv_w, (int64_t)(L * 3 * D * D), b + o_qkv, s));
+    IFF_VIT_HIP(launch_vit_to_bf16(d->proj_w, (int64_t)(L * D * D), b + o_proj, s));
+    IFF_VIT_HIP(launch_vit_to_bf16(d->fc1_w, (int64_t)(L * F * D), b + o_fc1, s));
+    IFF_VIT_HIP(launch_vit_to_bf16(d->fc2_w, (int64_t)(L * D * F), b + o_fc2, s));
+    for (auto& x : vecs) IFF_VIT_HIP(hipMemcpyAsync(b + x.off, x.src, x.n * 4, hipMemcpyDeviceToDevice, s));
+    VitDev& w = v->dev;
+    w.patch_w = b + o_pw; w.qkv_w = b + o_qkv; w.proj_w = b + o_proj; w.fc1_w = b + o_fc1; w.fc2_w = b + o_fc2;
+    const float** dst[] = {&w.patch_b, &w.cls, &w.pos, &w.ln1_w, &w.ln1_b, &w.ln2_w, &w.ln2_b, &w.qkv_b, &w.proj_b, &w.fc1_b, &w.fc2_b,
+                           &w.ls1, &w.ls2, &w.norm_w, &w.norm_b};
+    for (size_t i = 0; i < sizeof(dst) / sizeof(dst[0]); ++i) *dst[i] = (const float*)(b + vecs[i].off);
+    w.dim = d->dim; w.depth = d->depth; w.heads = d->heads; w.mlp = d->mlp; w.patch = d->patch; w.gh = d->grid_h; w.gw = d->grid_w;
+    w.T = (int)T; w.kp = (int)kp; w.eps = d->ln_eps;
+    IFF_VIT_HIP(hipStreamSynchronize(s));      // the source tensors may be released by the caller after return
+    *out = v;
+    return 0;
+}
+
+extern "C" size_t iff_vit_workspace(const iff_vit* v, int32_t Q) { return (v && Q > 0) ? vit_workspace_bytes(v->dev, Q) : 0; }
+
+extern "C" int iff_vit_forward(const iff_vit* v, const float* images, int32_t Q, float* patch_tokens, float* cls_opt, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(v && Q >= 0, "iff_vit_forward: bad argument");
+    if (Q == 0) return 0;
+    IFF_REQUIRE(images && patch_tokens, "iff_vit_forward: null buffer");
+    if (!workspace || workspace_bytes < vit_workspace_bytes(v->dev, Q))
+        return fail(IFF_ERR_WORKSPACE, "iff_vit_forward: workspace %zu < %zu bytes", workspace_bytes, vit_workspace_bytes(v->dev, Q));
+    IFF_HIP(launch_vit_forward(v->dev, images, Q, v->dev.gh * v->dev.patch, v->dev.gw * v->dev.patch, patch_tokens, cls_opt, workspace,
+                               workspace_bytes, (hipStream_t)stream));
+    return 0;
+}

@@ -117,3 +117,26 @@ hipError_t launch_topk(const float* score, int Q, int64_t N, int k, int64_t* idx
 // pose_kernels.hip
 hipError_t launch_pose(const int64_t* idx, const float* val, int Q, int k, const float* rays_o, const float* rays_d, int64_t N,
                        int64_t ray_batch_stride, const float* up3, float* c2w, float* parts, hipStream_t s);
+
+// vit_kernels.hip -- the ViT-S/14 image backbone (pose_estimation/backbone.py:12-14)
+struct VitDev {
+    // bf16 GEMM weights in nn.Linear layout [out][in], stacked over the blocks
+    const void* patch_w;                  // [dim][kp]           patch_embed.proj.weight, k = c P P + dy P + dx, zero padded to kp
+    const void* qkv_w;                    // [depth][3 dim][dim]
+    const void* proj_w;                   // [depth][dim][dim]
+    const void* fc1_w;                    // [depth][mlp][dim]
+    const void* fc2_w;                    // [depth][dim][mlp]
+    // fp32 vectors
+    const float* patch_b; const float* cls; const float* pos;          // [dim], [dim], [T][dim] (position embedding at this grid)
+    const float* ln1_w; const float* ln1_b; const float* ln2_w; const float* ln2_b;      // [depth][dim]
+    const float* qkv_b; const float* proj_b; const float* fc1_b; const float* fc2_b;     // [depth][3 dim], [depth][dim], [depth][mlp], [depth][dim]
+    const float* ls1; const float* ls2;   // LayerScale gammas [depth][dim]
+    const float* norm_w; const float* norm_b;
+    int dim, depth, heads, mlp, patch, gh, gw, T, kp;
+    float eps;
+};
+size_t vit_workspace_bytes(const VitDev& v, int Q);
+hipError_t launch_vit_to_bf16(const float* src, int64_t n, void* dst, hipStream_t s);
+hipError_t launch_vit_pad_rows(const float* src, int rows, int cols, int KP, void* dst, hipStream_t s);
+hipError_t launch_vit_forward(const VitDev& v, const float* images, int Q, int H, int W, float* patch_tokens, float* cls_opt, void* ws,
+                              size_t ws_bytes, hipStream_t s);

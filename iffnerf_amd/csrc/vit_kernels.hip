@@ -1,0 +1,400 @@
+// vit_kernels.hip -- the image backbone of stage C: DINOv2's ViT-S/14 forward (pose_estimation/backbone.py:12-14, consumed by
+// pose_estimation/identification_module.py:137-146: forward_features(img)["x_norm_patchtokens"]) on the matrix cores.
+//
+//   patch embedding   14 x 14 / stride-14 convolution as a GEMM over an im2col image (bf16), + bias + position embedding
+//   12 blocks         LayerNorm -> QKV (384 -> 1152) -> 6-head attention over the 257 tokens -> projection, LayerScale, residual;
+//                     LayerNorm -> MLP 384 -> 1536 (exact GELU) -> 384, LayerScale, residual
+//   final LayerNorm   -> patch tokens [Q, 256, 384] fp32 (and the class token)
+//
+// Arithmetic: bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the residual stream, the LayerNorms, softmax
+// statistics and every epilogue are fp32.  One GEMM kernel (128 x 128 x 64 tiles, weights as the MFMA's A operand so that a lane
+// ends up with 4 consecutive output features of one token: 8- / 16-byte stores) with four epilogues; one attention kernel per
+// (image, head, 128-query block) that keeps K and V^T of the head in LDS, forms S^T = K Q^T so that a lane owns one query's whole
+// row of scores (row maximum and sum without cross-lane traffic) and feeds the probabilities to the P V product straight from the
+// accumulator registers (the k order of that product is permuted to the accumulator's row order, MI355X_MICROARCH / cdna guide 3).
+#include "iff_device.h"
+#include "iff_launch.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ im2col, class token, LayerNorm
+// images [Q,3,H,W] fp32 (already resized / cropped / normalised) -> patches [Q * gh * gw][KP] bf16, k = c * P * P + dy * P + dx
+// (the flattening of patch_embed.proj.weight [D,3,P,P]); columns >= 3 P P are zero
+__global__ void k_vit_im2col(const float* __restrict__ img, int Q, int H, int W, int P, int gh, int gw, int KP, __bf16* __restrict__ out) {
+    const int64_t n = (int64_t)Q * gh * gw * KP;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(t % KP);
+        const int64_t row = t / KP;
+        const int px = (int)(row % gw), py = (int)((row / gw) % gh), q = (int)(row / ((int64_t)gw * gh));
+        float v = 0.0f;
+        if (k < 3 * P * P) {
+            const int c = k / (P * P), r = k - c * P * P, dy = r / P, dx = r - dy * P;
+            v = img[(((int64_t)q * 3 + c) * H + (py * P + dy)) * W + (px * P + dx)];
+        }
+        out[t] = (__bf16)v;
+    }
+}
+
+// x[q * T + 0][:] = cls + pos[0]
+__global__ void k_vit_cls(const float* __restrict__ cls, const float* __restrict__ pos, int Q, int T, int D, float* __restrict__ x) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Q * D; t += gridDim.x * blockDim.x) {
+        const int q = t / D, c = t - q * D;
+        x[(int64_t)q * T * D + c] = cls[c] + pos[c];
+    }
+}
+
+// LayerNorm over rows of D = 384 (eps inside the sqrt, affine), one wave per row.  OUT_BF16: bf16 rows for the next GEMM;
+// otherwise fp32 rows with the class-token row of every image dropped (the x_norm_patchtokens output) and, when cls_out is
+// given, the class-token rows there.
+template <bool OUT_BF16>
+__global__ void __launch_bounds__(256) k_vit_layernorm(const float* __restrict__ x, int64_t M, int T, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float eps, __bf16* __restrict__ out_bf,
+                                                       float* __restrict__ out_f, float* __restrict__ cls_out) {
+    constexpr int D = 384;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * D;
+    float v[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float2 t = *reinterpret_cast<const float2*>(xr + 2 * lane + 128 * j);
+        v[2 * j] = t.x; v[2 * j + 1] = t.y;
+    }
+    float s = ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)D;
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { const float d = v[j] - mean; ss = fmaf(d, d, ss); }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = 2 * lane + 128 * j;
+        const float2 gg = *reinterpret_cast<const float2*>(g + c), bb = *reinterpret_cast<const float2*>(b + c);
+        const float y0 = (v[2 * j] - mean) * rstd * gg.x + bb.x, y1 = (v[2 * j + 1] - mean) * rstd * gg.y + bb.y;
+        if (OUT_BF16) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 o = {(__bf16)y0, (__bf16)y1};
+            *reinterpret_cast<bf16x2*>(out_bf + row * D + c) = o;
+        } else {
+            const int64_t q = row / T;
+            const int t = (int)(row - q * T);
+            float* dst = t == 0 ? (cls_out ? cls_out + q * D : nullptr) : out_f + (q * (T - 1) + (t - 1)) * D;
+            if (dst) *reinterpret_cast<float2*>(dst + c) = make_float2(y0, y1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// C[m][n] = sum_k X[m][k] W[n][k]   (X [M][K] bf16 activations, W [N][K] bf16 = nn.Linear weight), fp32 accumulation.
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_EMBED = 3 };
+struct GemmEpi {
+    const float* bias;        // [N]
+    // EPI_QKV: q (times `qscale`), k, v as [img][head][T][64] bf16
+    __bf16* q; __bf16* k; __bf16* v; int T; int heads; float qscale;
+    // EPI_GELU: out [M][N] bf16
+    __bf16* out;
+    // EPI_RESID: x[m][n] += ls[n] * (acc + bias[n])
+    float* x; const float* ls;
+    // EPI_EMBED: x[(m / G) * T + 1 + m % G][n] = acc + bias[n] + pos[1 + m % G][n]   (G patches per image)
+    const float* pos; int G;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;      // LDS rows padded to 144 B: conflict-free ds_read_b128
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt, int64_t M, int N, int K,
+                                                     GemmEpi e) {
+    __shared__ __attribute__((aligned(16))) __bf16 sW[GBN][GLD];
+    __shared__ __attribute__((aligned(16))) __bf16 sX[GBM][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = (wave & 1) * 64, wm = (wave >> 1) * 64;      // the wave's 64 x 64 corner of the tile
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * GBM;
+    const int n0 = blockIdx.x * GBN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    // a tile is 128 rows x 64 bf16 = 1024 chunks of 16 B: 4 per thread and operand
+    bf16x8 gw[4], gx[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
+            gw[r] = *reinterpret_cast<const bf16x8*>(Wt + (int64_t)(n0 + row) * K + k0 + kc);
+            const int64_t m = min(m0 + row, M - 1);
+            gx[r] = *reinterpret_cast<const bf16x8*>(X + m * K + k0 + kc);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += GBK) {
+        __syncthreads();                       // the previous step's fragments have been read
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
+            *reinterpret_cast<bf16x8*>(&sW[row][kc]) = gw[r];
+            *reinterpret_cast<bf16x8*>(&sX[row][kc]) = gx[r];
+        }
+        __syncthreads();
+        if (k0 + GBK < K) fetch(k0 + GBK);     // the next tile travels while this one is multiplied
+#pragma unroll
+        for (int ks = 0; ks < GBK / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(&sW[wn + 32 * a + lr][16 * ks + 8 * lh]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(&sX[wm + 32 * b + lr][16 * ks + 8 * lh]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh: four consecutive n per reg group
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t m = m0 + wm + 32 * b + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + wn + 32 * a + 8 * g4 + 4 * lh;
+                const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
+                float v[4] = {acc[a][b][4 * g4] + bi.x, acc[a][b][4 * g4 + 1] + bi.y, acc[a][b][4 * g4 + 2] + bi.z, acc[a][b][4 * g4 + 3] + bi.w};
+                if (EPI == EPI_QKV) {
+                    const int D = N / 3, which = n / D, c = n - which * D, head = c >> 6, d = c & 63;
+                    const int64_t img = m / e.T;
+                    const int t = (int)(m - img * e.T);
+                    __bf16* dst = (which == 0 ? e.q : (which == 1 ? e.k : e.v)) + (((img * e.heads + head) * e.T + t) << 6) + d;
+                    const float sc = which == 0 ? e.qscale : 1.0f;
+                    bf16x4 o = {(__bf16)(v[0] * sc), (__bf16)(v[1] * sc), (__bf16)(v[2] * sc), (__bf16)(v[3] * sc)};
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                } else if (EPI == EPI_GELU) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f)));
+                    *reinterpret_cast<bf16x4*>(e.out + m * N + n) = o;
+                } else if (EPI == EPI_RESID) {
+                    const float4 ls = *reinterpret_cast<const float4*>(e.ls + n);
+                    float4* xp = reinterpret_cast<float4*>(e.x + m * N + n);
+                    float4 xv = *xp;
+                    xv.x = fmaf(ls.x, v[0], xv.x); xv.y = fmaf(ls.y, v[1], xv.y); xv.z = fmaf(ls.z, v[2], xv.z); xv.w = fmaf(ls.w, v[3], xv.w);
+                    *xp = xv;
+                } else {
+                    const int64_t img = m / e.G;
+                    const int p = (int)(m - img * e.G);
+                    const float4 ps = *reinterpret_cast<const float4*>(e.pos + (int64_t)(1 + p) * N + n);
+                    *reinterpret_cast<float4*>(e.x + (img * e.T + 1 + p) * N + n) = make_float4(v[0] + ps.x, v[1] + ps.y, v[2] + ps.z, v[3] + ps.w);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// One workgroup = (image, head, block of 128 queries); wave w serves queries 32 w .. 32 w + 31 of the block.
+constexpr int AT_TP = 288;          // keys padded to 9 blocks of 32 (T = 257 tokens)
+constexpr int AT_KLD = 64 + 8;      // sK rows: 144 B
+constexpr int AT_VLD = AT_TP + 12;  // sVt rows: 600 B -> conflict-free ds_read_b64 down a column of d
+
+__global__ void __launch_bounds__(256, 2) k_vit_attention(const __bf16* __restrict__ Qh, const __bf16* __restrict__ Kh,
+                                                          const __bf16* __restrict__ Vh, int T, int heads, __bf16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) __bf16 sK[AT_TP][AT_KLD];
+    __shared__ __attribute__((aligned(16))) __bf16 sVt[64][AT_VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int ih = blockIdx.y;                               // image * heads + head
+    const int64_t base = (int64_t)ih * T * 64;
+    // K rows (zero beyond T) and V transposed
+    for (int chunk = tid; chunk < AT_TP * 8; chunk += 256) {
+        const int t = chunk >> 3, dc = (chunk & 7) * 8;
+        bf16x8 kv, vv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kv[i] = (__bf16)0.0f; vv[i] = (__bf16)0.0f; }
+        if (t < T) {
+            kv = *reinterpret_cast<const bf16x8*>(Kh + base + t * 64 + dc);
+            vv = *reinterpret_cast<const bf16x8*>(Vh + base + t * 64 + dc);
+        }
+        *reinterpret_cast<bf16x8*>(&sK[t][dc]) = kv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sVt[dc + i][t] = vv[i];
+    }
+    const int q = blockIdx.x * 128 + wave * 32 + lr;         // this lane's query (column of every MFMA below)
+    const int qc = min(q, T - 1);
+    bf16x8 fq[4];                                            // Q^T fragments: k = d = 16 ks + 8 lh + j
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const bf16x8*>(Qh + base + qc * 64 + 16 * ks + 8 * lh);
+    __syncthreads();
+    // S^T[t][q] = sum_d K[t][d] Q[q][d]   (Q carries the 1 / sqrt(64))
+    f32x16 S[AT_TP / 32];
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[b][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&sK[32 * b + lr][16 * ks + 8 * lh]);
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], S[b], 0, 0, 0);
+        }
+    }
+    // softmax over t for this lane's query: rows t = 32 b + (r & 3) + 8 (r >> 2) + 4 lh live in this lane and in lane ^ 32
+    float mx = -INFINITY;
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (t >= T) S[b][r] = -INFINITY;
+            mx = fmaxf(mx, S[b][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[b][r] = expf(S[b][r] - mx); sum += S[b][r]; }
+    sum += __shfl_xor(sum, 32, 64);
+    // O^T[d][q] = sum_t V^T[d][t] P^T[t][q]: the accumulator registers 8 s .. 8 s + 7 of block b are the B fragment of k-step
+    // (b, s); its element j is row 16 s + 8 (j >> 2) + 4 lh + (j & 3) of the block, so the V^T fragment is gathered in that order
+    f32x16 O[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[a][r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fp[j] = (__bf16)S[b][8 * s + j];
+            const int t0 = 32 * b + 16 * s + 4 * lh;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sVt[32 * a + lr][t0]);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sVt[32 * a + lr][t0 + 8]);
+                bf16x8 fv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                O[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp, O[a], 0, 0, 0);
+            }
+        }
+    if (q < T) {
+        const float inv = 1.0f / sum;
+        const int64_t img = ih / heads;
+        const int head = ih - (int)img * heads;
+        __bf16* dst = out + ((img * T + q) * heads + head) * 64;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 o = {(__bf16)(O[a][4 * g4] * inv), (__bf16)(O[a][4 * g4 + 1] * inv), (__bf16)(O[a][4 * g4 + 2] * inv),
+                            (__bf16)(O[a][4 * g4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(dst + 32 * a + 8 * g4 + 4 * lh) = o;
+            }
+    }
+}
+
+__global__ void k_vit_to_bf16(const float* __restrict__ src, int64_t n, __bf16* __restrict__ dst) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) dst[t] = (__bf16)src[t];
+}
+// patch_embed.proj.weight [D][3 P P] fp32 -> [D][KP] bf16, zero padded
+__global__ void k_vit_pad_rows(const float* __restrict__ src, int rows, int cols, int KP, __bf16* __restrict__ dst) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < rows * KP; t += gridDim.x * blockDim.x) {
+        const int r = t / KP, c = t - r * KP;
+        dst[t] = (__bf16)(c < cols ? src[r * cols + c] : 0.0f);
+    }
+}
+
+inline unsigned grid1(int64_t n, int block = 256, int cap = 256 * 16) {
+    int64_t g = (n + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <int EPI>
+hipError_t gemm(const __bf16* X, const __bf16* W, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
+    if (N % GBN != 0 || K % GBK != 0 || M < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_vit_gemm<EPI>), dim3((unsigned)(N / GBN), (unsigned)((M + GBM - 1) / GBM)), dim3(256), 0, s, X, W, M, N, K, e);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_vit_to_bf16(const float* src, int64_t n, void* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_vit_to_bf16, dim3(grid1(n)), dim3(256), 0, s, src, n, (__bf16*)dst);
+    return hipGetLastError();
+}
+hipError_t launch_vit_pad_rows(const float* src, int rows, int cols, int KP, void* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_vit_pad_rows, dim3(grid1((int64_t)rows * KP)), dim3(256), 0, s, src, rows, cols, KP, (__bf16*)dst);
+    return hipGetLastError();
+}
+
+size_t vit_workspace_bytes(const VitDev& v, int Q) {
+    const size_t M = (size_t)Q * v.T, G = (size_t)Q * (v.T - 1);
+    size_t b = 0;
+    auto take = [&](size_t bytes) { b += (bytes + 255) / 256 * 256; };
+    take(M * v.dim * 4);            // x      residual stream, fp32
+    take(M * v.dim * 2);            // xn     LayerNorm output / attention output, bf16
+    take(M * v.dim * 2 * 3);        // q, k, v per head
+    take(M * v.mlp * 2);            // MLP hidden
+    take(G * v.kp * 2);             // im2col
+    return b;
+}
+
+hipError_t launch_vit_forward(const VitDev& v, const float* images, int Q, int H, int W, float* patch_tokens, float* cls_opt, void* ws,
+                              size_t ws_bytes, hipStream_t s) {
+    if (Q < 1) return hipSuccess;
+    if (ws_bytes < vit_workspace_bytes(v, Q) || v.dim != 384 || v.heads * 64 != v.dim || v.T > AT_TP || H != v.gh * v.patch ||
+        W != v.gw * v.patch)
+        return hipErrorInvalidValue;
+    const int64_t M = (int64_t)Q * v.T, G = (int64_t)Q * (v.T - 1);
+    const int D = v.dim;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    float* x = (float*)take((size_t)M * D * 4);
+    __bf16* xn = (__bf16*)take((size_t)M * D * 2);
+    __bf16* q = (__bf16*)take((size_t)M * D * 2 * 3);
+    __bf16* k = q + M * D;
+    __bf16* vv = k + M * D;
+    __bf16* hid = (__bf16*)take((size_t)M * v.mlp * 2);
+    __bf16* col = (__bf16*)take((size_t)G * v.kp * 2);
+    hipError_t e;
+    hipLaunchKernelGGL(k_vit_im2col, dim3(grid1(G * v.kp)), dim3(256), 0, s, images, Q, H, W, v.patch, v.gh, v.gw, v.kp, col);
+    hipLaunchKernelGGL(k_vit_cls, dim3(grid1((int64_t)Q * D)), dim3(256), 0, s, v.cls, v.pos, Q, v.T, D, x);
+    GemmEpi ep = {};
+    ep.bias = v.patch_b; ep.x = x; ep.pos = v.pos; ep.G = v.T - 1; ep.T = v.T;
+    if ((e = gemm<EPI_EMBED>(col, (const __bf16*)v.patch_w, G, D, v.kp, ep, s)) != hipSuccess) return e;
+    const unsigned ln_grid = (unsigned)((M + 3) / 4);
+    for (int l = 0; l < v.depth; ++l) {
+        hipLaunchKernelGGL((k_vit_layernorm<true>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.ln1_w + (size_t)l * D, v.ln1_b + (size_t)l * D,
+                           v.eps, xn, nullptr, nullptr);
+        GemmEpi e0 = {};
+        e0.bias = v.qkv_b + (size_t)l * 3 * D; e0.q = q; e0.k = k; e0.v = vv; e0.T = v.T; e0.heads = v.heads; e0.qscale = 0.125f;
+        if ((e = gemm<EPI_QKV>(xn, (const __bf16*)v.qkv_w + (size_t)l * 3 * D * D, M, 3 * D, D, e0, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_vit_attention, dim3((unsigned)((v.T + 127) / 128), (unsigned)(Q * v.heads)), dim3(256), 0, s, q, k, vv, v.T,
+                           v.heads, xn);
+        GemmEpi e1 = {};
+        e1.bias = v.proj_b + (size_t)l * D; e1.x = x; e1.ls = v.ls1 + (size_t)l * D;
+        if ((e = gemm<EPI_RESID>(xn, (const __bf16*)v.proj_w + (size_t)l * D * D, M, D, D, e1, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_vit_layernorm<true>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.ln2_w + (size_t)l * D, v.ln2_b + (size_t)l * D,
+                           v.eps, xn, nullptr, nullptr);
+        GemmEpi e2 = {};
+        e2.bias = v.fc1_b + (size_t)l * v.mlp; e2.out = hid;
+        if ((e = gemm<EPI_GELU>(xn, (const __bf16*)v.fc1_w + (size_t)l * v.mlp * D, M, v.mlp, D, e2, s)) != hipSuccess) return e;
+        GemmEpi e3 = {};
+        e3.bias = v.fc2_b + (size_t)l * D; e3.x = x; e3.ls = v.ls2 + (size_t)l * D;
+        if ((e = gemm<EPI_RESID>(hid, (const __bf16*)v.fc2_w + (size_t)l * D * v.mlp, M, D, v.mlp, e3, s)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_vit_layernorm<false>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.norm_w, v.norm_b, v.eps, nullptr, patch_tokens,
+                       cls_opt);
+    return hipGetLastError();
+}

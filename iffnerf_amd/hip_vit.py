@@ -1,0 +1,155 @@
+"""The image backbone on the matrix cores: DINOv2 ViT-S/14 ``forward_features`` through ``iff_vit_forward``.
+
+``ViTHandle`` owns the bf16 / fp32 weight slab of one network; ``NativeViT`` wraps a backbone module (DINOv2's ``dinov2_vits14``
+from ``torch.hub`` -- reference pose_estimation/backbone.py:12-14 -- or the seeded stand-in of this package's backbone.py) so that
+``forward_features(x)["x_norm_patchtokens"]`` (what pose_estimation/identification_module.py:141 reads) runs in libiffnerf_hip
+under ``torch.no_grad``; with autograd enabled on a trainable backbone the wrapped module's own torch forward runs instead.
+State-dict keys of both sources are understood (``blocks.i.attn.qkv.*``, ``blocks.i.ls1.gamma``, ``blocks.i.mlp.fc1.*`` for
+DINOv2; ``blocks.i.qkv.*``, ``blocks.i.ls1``, ``blocks.i.fc1.*`` for the stand-in).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check, dptr, stream_ptr
+
+
+def interpolate_pos_embed(pos: torch.Tensor, gh: int, gw: int, patch: int = 14) -> torch.Tensor:
+    """DINOv2's ``interpolate_pos_encoding`` for an input of gh x gw patches: ``pos`` [1, 1 + n, D] -> [1 + gh*gw, D].  The class
+    position is kept; the patch grid is resized bicubically with the +0.1 scale-factor offset of the original implementation."""
+    pos = pos.detach().float()
+    n = pos.shape[1] - 1
+    if n == gh * gw:
+        return pos[0].contiguous()
+    side = int(round(math.sqrt(n)))
+    if side * side != n:
+        raise RuntimeError(f"position embedding has {n} patch positions: not a square grid")
+    grid = pos[0, 1:].reshape(1, side, side, -1).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=((gh + 0.1) / side, (gw + 0.1) / side), mode="bicubic")
+    if grid.shape[-2:] != (gh, gw):
+        raise RuntimeError("interpolated position grid has the wrong size")
+    return torch.cat((pos[0, :1], grid.permute(0, 2, 3, 1).reshape(gh * gw, -1)), dim=0).contiguous()
+
+
+def _pick(sd: Dict[str, torch.Tensor], *names):
+    for n in names:
+        if n in sd:
+            return sd[n]
+    raise RuntimeError(f"backbone state_dict has none of {names}")
+
+
+class ViTHandle:
+    """One ViT-S/14's weights on one GPU (``iff_vit``)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device, grid=(16, 16), patch: int = 14, heads: int = 6, ln_eps: float = 1e-6):
+        self._h = None
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"ViTHandle needs a GPU device (got {device}); libiffnerf_hip has no CPU path")
+        sd = {k: v.detach() for k, v in state_dict.items()}
+        depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+        dim = int(_pick(sd, "cls_token").shape[-1])
+        gh, gw = int(grid[0]), int(grid[1])
+
+        def stack(*alts):
+            return torch.stack([_pick(sd, *(a.format(i=i) for a in alts)).float() for i in range(depth)])
+
+        t = {
+            "patch_w": _pick(sd, "patch_embed.proj.weight", "patch_embed.weight").float().reshape(dim, -1),
+            "patch_b": _pick(sd, "patch_embed.proj.bias", "patch_embed.bias").float(),
+            "cls": _pick(sd, "cls_token").float().reshape(dim),
+            "pos": interpolate_pos_embed(_pick(sd, "pos_embed"), gh, gw, patch),
+            "ln1_w": stack("blocks.{i}.norm1.weight"), "ln1_b": stack("blocks.{i}.norm1.bias"),
+            "qkv_w": stack("blocks.{i}.attn.qkv.weight", "blocks.{i}.qkv.weight"),
+            "qkv_b": stack("blocks.{i}.attn.qkv.bias", "blocks.{i}.qkv.bias"),
+            "proj_w": stack("blocks.{i}.attn.proj.weight", "blocks.{i}.proj.weight"),
+            "proj_b": stack("blocks.{i}.attn.proj.bias", "blocks.{i}.proj.bias"),
+            "ls1": stack("blocks.{i}.ls1.gamma", "blocks.{i}.ls1"),
+            "ln2_w": stack("blocks.{i}.norm2.weight"), "ln2_b": stack("blocks.{i}.norm2.bias"),
+            "fc1_w": stack("blocks.{i}.mlp.fc1.weight", "blocks.{i}.fc1.weight"),
+            "fc1_b": stack("blocks.{i}.mlp.fc1.bias", "blocks.{i}.fc1.bias"),
+            "fc2_w": stack("blocks.{i}.mlp.fc2.weight", "blocks.{i}.fc2.weight"),
+            "fc2_b": stack("blocks.{i}.mlp.fc2.bias", "blocks.{i}.fc2.bias"),
+            "ls2": stack("blocks.{i}.ls2.gamma", "blocks.{i}.ls2"),
+            "norm_w": _pick(sd, "norm.weight").float(), "norm_b": _pick(sd, "norm.bias").float(),
+        }
+        if t["patch_w"].shape[1] != 3 * patch * patch:
+            raise RuntimeError(f"patch embedding has {t['patch_w'].shape[1]} inputs per patch, expected 3 x {patch} x {patch}")
+        d = _lib.VitDesc()
+        d.dim, d.depth, d.heads, d.mlp, d.patch, d.grid_h, d.grid_w = dim, depth, int(heads), int(t["fc1_w"].shape[1]), int(patch), gh, gw
+        d.ln_eps = float(ln_eps)
+        keep = []
+        for name, v in t.items():
+            v = v.to(device=device, dtype=torch.float32).contiguous()
+            keep.append(v)
+            setattr(d, name, dptr(v, name=name))
+        self.device, self.dim, self.grid, self.patch, self.depth = device, dim, (gh, gw), int(patch), depth
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            check(_lib.lib().iff_vit_create(C.byref(d), stream_ptr(device), C.byref(out)), "iff_vit_create")
+        self._h = out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().iff_vit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, images: torch.Tensor, want_cls: bool = False):
+        """images [Q,3,14 gh,14 gw] (resized / cropped / normalised) -> patch tokens [Q, gh*gw, dim] (+ class token [Q, dim])."""
+        gh, gw = self.grid
+        if images.dim() != 4 or images.shape[1] != 3 or tuple(images.shape[-2:]) != (gh * self.patch, gw * self.patch):
+            raise RuntimeError(f"images must be [Q,3,{gh * self.patch},{gw * self.patch}] (got {tuple(images.shape)})")
+        if not images.is_cuda:
+            raise RuntimeError("images must live on the GPU; libiffnerf_hip has no CPU path")
+        x = images.detach().to(torch.float32).contiguous()
+        Q = x.shape[0]
+        tok = x.new_empty(Q, gh * gw, self.dim)
+        cls = x.new_empty(Q, self.dim) if want_cls else None
+        L = _lib.lib()
+        ws_bytes = int(L.iff_vit_workspace(self._h, Q))
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(self.device):
+            check(L.iff_vit_forward(self._h, dptr(x), Q, dptr(tok), dptr(cls), ws.data_ptr(), ws.numel() * 4, stream_ptr(self.device)),
+                  "iff_vit_forward")
+        return (tok, cls) if want_cls else tok
+
+
+class NativeViT(torch.nn.Module):
+    """A backbone module (``forward_features``) served by ``iff_vit_forward``.  Keeps the wrapped module -- its parameters,
+    ``state_dict`` and training behaviour are unchanged; only no-grad inference on the GPU goes through the HIP kernels."""
+
+    def __init__(self, module: torch.nn.Module, grid=(16, 16), patch: int = 14):
+        super().__init__()
+        self.module, self.grid, self.patch = module, (int(grid[0]), int(grid[1])), int(patch)
+        self._handle: Optional[ViTHandle] = None
+        self._key = None
+
+    def _vit(self, device) -> ViTHandle:
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        if self._handle is None or self._key != key:
+            if self._handle is not None:
+                self._handle.close()
+            self._handle, self._key = ViTHandle(self.module.state_dict(), device, self.grid, self.patch), key
+        return self._handle
+
+    def forward_features(self, x, masks=None):
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.module.parameters()))
+        if needs_grad or masks is not None:
+            return self.module.forward_features(x) if masks is None else self.module.forward_features(x, masks)
+        tok, cls = self._vit(x.device).forward(x, want_cls=True)
+        return {"x_norm_clstoken": cls, "x_norm_patchtokens": tok}
+
+    def forward(self, x):
+        return self.forward_features(x)["x_norm_clstoken"]

@@ -11,9 +11,16 @@ import torch.nn.functional as F
 
 
 def create_backbone(type="dino", pretrained=False, filter_size=4, pool_only=True, _force_nonfinetuned=False, **kwargs):
+    """The reference's factory (backbone.py:3-14).  The hub module is wrapped in ``hip_vit.NativeViT``, which serves its no-grad
+    ``forward_features`` from ``iff_vit_forward`` (bf16 matrix cores) and keeps the module itself -- parameters, training path --
+    untouched (its state_dict keys gain the ``module.`` prefix of the wrapper; ``native=False`` in ``kwargs`` returns the stock
+    module exactly as the reference does)."""
     if type != "dino":
         raise RuntimeError("only the 'dino' backbone exists in the reference (backbone.py:11-14)")
     model = torch.hub.load("facebookresearch/dinov2", "dinov2_vits14")
+    if kwargs.get("native", True):
+        from ..hip_vit import NativeViT
+        model = NativeViT(model, (16, 16), 14)
     return model, (16, 16), 384
 
 
@@ -63,6 +70,10 @@ class SeededViTS14(torch.nn.Module):
         return {"x_norm_clstoken": t[:, 0], "x_norm_patchtokens": t[:, 1:]}
 
 
-def create_standin_backbone(seed: int = 0):
-    """(module, (16, 16), 384) like ``create_backbone("dino")``, without the network."""
-    return SeededViTS14(seed).eval(), (16, 16), 384
+def create_standin_backbone(seed: int = 0, native: bool = False):
+    """(module, (16, 16), 384) like ``create_backbone("dino")``, without the network.  ``native``: wrapped in ``hip_vit.NativeViT``."""
+    m = SeededViTS14(seed).eval()
+    if native:
+        from ..hip_vit import NativeViT
+        m = NativeViT(m, (16, 16), 14)
+    return m, (16, 16), 384

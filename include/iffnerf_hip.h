@@ -313,6 +313,41 @@ int iff_ray_logits_folded_timed(const iff_idnet* net, int32_t B, const float* o,
                                 float* row_sumexp, void* workspace, size_t workspace_bytes, float* trunk_ms_host,
                                 void* stream);
 
+/* ------------------------------------------------------------------------------------------- image backbone
+ * DINOv2 ViT-S/14 (pose_estimation/backbone.py:12-14: torch.hub "dinov2_vits14"), the network IdentificationModule.image_processing
+ * runs on every query image (pose_estimation/identification_module.py:137-146, forward_features(img)["x_norm_patchtokens"]):
+ * 14 x 14 patch embedding, class token, position embedding, `depth` pre-norm blocks (LayerNorm eps 1e-6, 6-head attention, MLP with
+ * exact GELU, LayerScale), final LayerNorm.  bf16 operands on the matrix cores, fp32 accumulation; the residual stream, LayerNorms,
+ * softmax statistics and outputs are fp32.  Weights are read once at create (device pointers, fp32, nn.Linear layouts, the per-block
+ * tensors stacked along a leading `depth` axis); `pos` is the position embedding ALREADY interpolated to the 1 + grid_h * grid_w
+ * tokens of this input size (DINOv2's interpolate_pos_encoding; the host mirror does it).  Built for dim = 384, heads = 6 (ViT-S)
+ * and at most 288 tokens (224 x 224 inputs: 257). */
+typedef struct iff_vit iff_vit;
+typedef struct iff_vit_desc {
+    int32_t dim, depth, heads, mlp, patch, grid_h, grid_w;
+    float   ln_eps;
+    const float* patch_w;  const float* patch_b;      /* patch_embed.proj.{weight [dim,3,patch,patch], bias [dim]} */
+    const float* cls;      const float* pos;          /* cls_token [dim]; position embedding [1 + grid_h*grid_w, dim] */
+    const float* ln1_w;    const float* ln1_b;        /* blocks.*.norm1.{weight,bias}    [depth, dim] */
+    const float* qkv_w;    const float* qkv_b;        /* blocks.*.attn.qkv.{weight,bias} [depth, 3 dim, dim], [depth, 3 dim] */
+    const float* proj_w;   const float* proj_b;       /* blocks.*.attn.proj              [depth, dim, dim], [depth, dim] */
+    const float* ls1;                                 /* blocks.*.ls1.gamma              [depth, dim] */
+    const float* ln2_w;    const float* ln2_b;        /* blocks.*.norm2 */
+    const float* fc1_w;    const float* fc1_b;        /* blocks.*.mlp.fc1                [depth, mlp, dim], [depth, mlp] */
+    const float* fc2_w;    const float* fc2_b;        /* blocks.*.mlp.fc2                [depth, dim, mlp], [depth, dim] */
+    const float* ls2;                                 /* blocks.*.ls2.gamma */
+    const float* norm_w;   const float* norm_b;       /* norm.{weight,bias} [dim] */
+} iff_vit_desc;
+/* builds the handle from the parameters of torch.hub's dinov2_vits14 (pose_estimation/backbone.py:12-14) */
+int  iff_vit_create(const iff_vit_desc* desc, void* stream, iff_vit** out);
+void iff_vit_destroy(iff_vit* vit);
+/* forward_features (backbone.py:12-14 / identification_module.py:141): images [Q,3,patch*grid_h,patch*grid_w] fp32, already resized,
+ * cropped and normalised -> patch_tokens [Q, grid_h*grid_w, dim] (x_norm_patchtokens) and, when cls_opt != NULL, cls_opt [Q, dim]
+ * (x_norm_clstoken).  Workspace: iff_vit_workspace(vit, Q). */
+size_t iff_vit_workspace(const iff_vit* vit, int32_t Q);
+int iff_vit_forward(const iff_vit* vit, const float* images, int32_t Q, float* patch_tokens, float* cls_opt, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* Image tokens for stage C: what IdentificationModule.image_processing does after the backbone
  * (pose_estimation/identification_module.py:149-160) -- append the 14-channel position code of get_img_position_encoding
  * (:76-99: grid position in [-1,1]^2, 'ij' indexing, then sin / cos of it at octaves 1, 2, 4) to every patch token, and turn

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 def test_header_cites_the_reference_for_every_entry_point():
     text = open(HEADER).read()
     for name in declared_functions():
-        if name in ("iff_last_error", "iff_abi_version", "iff_field_destroy", "iff_idnet_destroy", "iff_field_table_bytes",
+        if name in ("iff_last_error", "iff_abi_version", "iff_field_destroy", "iff_idnet_destroy", "iff_vit_destroy", "iff_field_table_bytes",
                     "iff_surface_sample_workspace", "iff_ray_encode_workspace", "iff_q_proj_workspace", "iff_topk_workspace"):
             continue
         pos = text.index(name + "(")

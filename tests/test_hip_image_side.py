@@ -142,3 +142,65 @@ def test_image_in_pose_out_capture(dev, monkeypatch):
     cq16.replay(imgs, masks)
     torch.cuda.synchronize()
     assert torch.isfinite(cq16.c2w).all() and cq16.idx.shape == idx.shape
+
+
+def test_native_vit_matches_the_fp32_torch_module(dev):
+    """iff_vit_forward (bf16 MFMA, fp32 accumulate / residual / LayerNorm / softmax) against the fp32 torch module of the same
+    weights: DINOv2 ViT-S/14's architecture with seeded stand-in weights (the real ones are not available offline; both state-dict
+    key schemes are understood by ViTHandle).  Token features agree to bf16-operand tolerance, and stage C fed with either token
+    set picks the same rays."""
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.hip_vit import NativeViT, ViTHandle
+    from iffnerf_amd.image_frontend import token_assemble
+    from iffnerf_amd.pipeline import PosePipeline
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    net, grid, C = create_standin_backbone(seed=3)
+    net = net.to(dev)
+    gen = torch.Generator().manual_seed(12)
+    for Q in (1, 5):
+        x = torch.randn(Q, 3, 224, 224, generator=gen).to(dev)
+        with torch.no_grad():
+            want = net.forward_features(x)
+        vit = ViTHandle(net.state_dict(), dev)
+        tok, cls = vit.forward(x, want_cls=True)
+        assert tok.shape == (Q, 256, 384) and cls.shape == (Q, 384)
+        ref, scale = want["x_norm_patchtokens"], float(want["x_norm_patchtokens"].abs().max())
+        err = float((tok - ref).abs().max())
+        cos = torch.nn.functional.cosine_similarity(tok.reshape(-1, 384), ref.reshape(-1, 384), dim=-1)
+        assert torch.isfinite(tok).all() and err <= 4e-2 * scale, (err, scale)           # bf16 operands: ~2^-8 per product, 12 blocks
+        assert float(cos.min()) > 0.9995
+        assert float((cls - want["x_norm_clstoken"]).abs().max()) <= 4e-2 * scale
+        # DINOv2's key names load too (attn.qkv / ls1.gamma / mlp.fc1) and give the same bits
+        sd = {}
+        for k, v in net.state_dict().items():
+            k2 = k
+            for a, b in ((".qkv.", ".attn.qkv."), (".proj.", ".attn.proj."), (".fc1.", ".mlp.fc1."), (".fc2.", ".mlp.fc2.")):
+                if k.startswith("blocks.") and a in k and "patch_embed" not in k:
+                    k2 = k.replace(a, b)
+            if k.startswith("blocks.") and (k.endswith(".ls1") or k.endswith(".ls2")):
+                k2 = k + ".gamma"
+            if k == "patch_embed.weight":
+                k2 = "patch_embed.proj.weight"
+            if k == "patch_embed.bias":
+                k2 = "patch_embed.proj.bias"
+            sd[k2] = v
+        assert torch.equal(ViTHandle(sd, dev).forward(x), tok)
+    # the wrapper: no-grad inference through the kernels, same dictionary as the module
+    wrapped = NativeViT(net)
+    with torch.no_grad():
+        out = wrapped.forward_features(x)
+    assert torch.equal(out["x_norm_patchtokens"], tok) and torch.equal(out["x_norm_clstoken"], cls)
+    # stage C on the golden-size ray set: tokens from either backbone select (nearly) the same top-100 rays
+    pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
+    ori, dirs, rgb = pipe.emit(300, seed=9)
+    for q in range(min(Q, 3)):
+        ta, _ = token_assemble(tok[q:q + 1], grid)
+        tb, _ = token_assemble(ref[q:q + 1].contiguous(), grid)
+        _, ia, _ = pipe.identify(ta[0], ori, dirs, rgb, k=100, materialize_map=False)
+        _, ib, _ = pipe.identify(tb[0], ori, dirs, rgb, k=100, materialize_map=False)
+        overlap = len(set(ia.tolist()) & set(ib.tolist()))
+        assert overlap >= 90, overlap
+    with pytest.raises(RuntimeError):
+        vit.forward(x.cpu())
+    with pytest.raises(RuntimeError):
+        vit.forward(torch.zeros(1, 3, 200, 224, device=dev))
