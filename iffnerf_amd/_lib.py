@@ -107,6 +107,7 @@ SIGNATURES = {
     "iff_vit_destroy": (None, [_VP]),
     "iff_vit_workspace": (_SZ, [_VP, _I32]),
     "iff_vit_forward": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _VP, _SZ, _VP]),
+    "iff_image_resize_crop": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, c_float_p, c_float_p, _VP, _VP]),
     "iff_token_assemble": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _F, c_float_p, c_float_p, _VP, _VP, _VP]),
     "iff_mask_token_rows": (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
     "iff_ray_cache_bytes": (_SZ, [_VP, _I64]),

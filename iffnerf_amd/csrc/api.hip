@@ -1183,3 +1183,18 @@ extern "C" int iff_vit_forward(const iff_vit* v, const float* images, int32_t Q,
                                workspace_bytes, (hipStream_t)stream));
     return 0;
 }
+
+extern "C" int iff_image_resize_crop(const float* src, int32_t Q, int32_t H, int32_t W, int32_t C, int32_t rh, int32_t rw, int32_t top,
+                                     int32_t left, int32_t ch, int32_t cw, int32_t cubic, const float* mean, const float* std, float* dst,
+                                     void* stream) {
+    IFF_REQUIRE(Q >= 0 && H >= 1 && W >= 1 && C >= 1 && C <= 4 && rh >= 1 && rw >= 1, "iff_image_resize_crop: bad shape");
+    IFF_REQUIRE(top >= 0 && left >= 0 && ch >= 1 && cw >= 1 && top + ch <= rh && left + cw <= rw, "iff_image_resize_crop: crop window outside the resized image");
+    if (Q == 0) return 0;
+    IFF_REQUIRE(src && dst, "iff_image_resize_crop: null buffer");
+    const float sup = cubic ? 2.0f : 1.0f;
+    const float sy = std::max((float)H / rh, 1.0f), sx = std::max((float)W / rw, 1.0f);
+    if (2.0f * sup * std::max(sx, sy) + 2.0f > 32.0f)
+        return fail(IFF_ERR_UNSUPPORTED, "iff_image_resize_crop: scale factor %.2f needs more than 32 filter taps", std::max(sx, sy));
+    IFF_HIP(launch_resize_crop(src, Q, H, W, C, rh, rw, top, left, ch, cw, cubic ? 1 : 0, mean, std, dst, (hipStream_t)stream));
+    return 0;
+}

@@ -135,6 +135,8 @@ struct VitDev {
     int dim, depth, heads, mlp, patch, gh, gw, T, kp;
     float eps;
 };
+hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int rh, int rw, int top, int left, int ch, int cw, int cubic,
+                              const float* mean, const float* std, float* dst, hipStream_t s);
 size_t vit_workspace_bytes(const VitDev& v, int Q);
 hipError_t launch_vit_to_bf16(const float* src, int64_t n, void* dst, hipStream_t s);
 hipError_t launch_vit_pad_rows(const float* src, int rows, int cols, int KP, void* dst, hipStream_t s);

@@ -108,32 +108,39 @@ struct GemmEpi {
     const float* pos; int G;
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;      // LDS rows padded to 144 B: conflict-free ds_read_b128
+constexpr int GBN = 128, GBK = 64, GLD = GBK + 8;      // LDS rows padded to 144 B: conflict-free ds_read_b128
 
-template <int EPI>
+// GBM = 128 (a wave: 64 features x 64 tokens) or 64 (64 x 32: twice the workgroups for the N = 384 products, which would
+// otherwise occupy 99 of the 256 CUs)
+template <int EPI, int GBM>
 __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt, int64_t M, int N, int K,
                                                      GemmEpi e) {
+    constexpr int MB = GBM / 64;                                // 32-token blocks per wave
     __shared__ __attribute__((aligned(16))) __bf16 sW[GBN][GLD];
     __shared__ __attribute__((aligned(16))) __bf16 sX[GBM][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = (wave & 1) * 64, wm = (wave >> 1) * 64;      // the wave's 64 x 64 corner of the tile
+    const int wn = (wave & 1) * 64, wm = (wave >> 1) * (32 * MB);      // the wave's corner of the tile
     const int lr = lane & 31, lh = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.y * GBM;
     const int n0 = blockIdx.x * GBN;
-    f32x16 acc[2][2];
+    f32x16 acc[2][MB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    // a tile is 128 rows x 64 bf16 = 1024 chunks of 16 B: 4 per thread and operand
-    bf16x8 gw[4], gx[4];
+    // a 128-row tile is 128 x 64 bf16 = 1024 chunks of 16 B: 4 per thread; the token tile 4 or 2
+    bf16x8 gw[4], gx[2 * MB];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
             gw[r] = *reinterpret_cast<const bf16x8*>(Wt + (int64_t)(n0 + row) * K + k0 + kc);
+        }
+#pragma unroll
+        for (int r = 0; r < 2 * MB; ++r) {
+            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
             const int64_t m = min(m0 + row, M - 1);
             gx[r] = *reinterpret_cast<const bf16x8*>(X + m * K + k0 + kc);
         }
@@ -145,26 +152,30 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
         for (int r = 0; r < 4; ++r) {
             const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
             *reinterpret_cast<bf16x8*>(&sW[row][kc]) = gw[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 2 * MB; ++r) {
+            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
             *reinterpret_cast<bf16x8*>(&sX[row][kc]) = gx[r];
         }
         __syncthreads();
         if (k0 + GBK < K) fetch(k0 + GBK);     // the next tile travels while this one is multiplied
 #pragma unroll
         for (int ks = 0; ks < GBK / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[2], fb[MB];
 #pragma unroll
             for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(&sW[wn + 32 * a + lr][16 * ks + 8 * lh]);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(&sX[wm + 32 * b + lr][16 * ks + 8 * lh]);
+            for (int b = 0; b < MB; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(&sX[wm + 32 * b + lr][16 * ks + 8 * lh]);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < MB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
     }
     // D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh: four consecutive n per reg group
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < MB; ++b) {
         const int64_t m = m0 + wm + 32 * b + lr;
         if (m >= M) continue;
 #pragma unroll
@@ -304,6 +315,68 @@ __global__ void __launch_bounds__(256, 2) k_vit_attention(const __bf16* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ image preprocessing
+// Antialiased resize (the separable triangle / cubic a = -0.5 filters ATen's upsample_*2d_aa kernels use, i.e. what
+// F.interpolate(..., antialias=True, align_corners=False) computes) of channels-last images, cropped to a window of the resized
+// image and normalised per channel, written channels-first -- Resize(256, BICUBIC) + CenterCrop(224) + Normalize of the reference
+// (pose_estimation/identification_module.py:36-61) in one pass over the pixels the crop needs.
+constexpr int RS_TAPS = 32;         // filter taps per axis the kernel holds (scale factors up to 7.5 bicubic, 15 bilinear)
+__device__ inline float aa_filter(float x, int cubic) {
+    x = fabsf(x);
+    if (!cubic) return x < 1.0f ? 1.0f - x : 0.0f;
+    const float a = -0.5f;
+    if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((x - 5.0f) * x + 8.0f) * x - 4.0f) * a;
+    return 0.0f;
+}
+// weights of output index `o` of an axis of `in` samples resized to `out`: first tap index and tap count returned, weights to w[]
+__device__ inline void aa_weights(int o, int in, int out, int cubic, float* w, int& first, int& count) {
+    const float scale = (float)in / (float)out;
+    const float support = (cubic ? 2.0f : 1.0f) * (scale >= 1.0f ? scale : 1.0f);
+    const float invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    const float center = scale * ((float)o + 0.5f);
+    first = max((int)(center - support + 0.5f), 0);
+    count = min(min((int)(center + support + 0.5f), in) - first, RS_TAPS);
+    float total = 0.0f;
+    for (int j = 0; j < count; ++j) { w[j] = aa_filter(((float)(j + first) - center + 0.5f) * invscale, cubic); total += w[j]; }
+    for (int j = 0; j < count; ++j) w[j] = total != 0.0f ? w[j] / total : w[j];
+    for (int j = count; j < RS_TAPS; ++j) w[j] = 0.0f;
+}
+
+struct ResizeArgs {
+    const float* src; int Q, H, W, C;            // [Q,H,W,C] (C <= 4)
+    int rh, rw;                                  // size of the (virtual) resized image
+    int top, left, ch, cw;                       // crop window inside it
+    int cubic;
+    float mean[4], inv_std[4];
+    float* dst;                                  // [Q,C,ch,cw]
+};
+__global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a) {
+    __shared__ float s_wx[16][RS_TAPS], s_wy[16][RS_TAPS];
+    __shared__ int s_fx[16], s_nx[16], s_fy[16], s_ny[16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16, q = blockIdx.z;
+    if (threadIdx.x < 16) aa_weights(a.left + min(ox0 + tx, a.cw - 1), a.W, a.rw, a.cubic, s_wx[tx], s_fx[tx], s_nx[tx]);
+    else if (threadIdx.x < 32) aa_weights(a.top + min(oy0 + tx, a.ch - 1), a.H, a.rh, a.cubic, s_wy[tx], s_fy[tx], s_ny[tx]);
+    __syncthreads();
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    if (ox >= a.cw || oy >= a.ch) return;
+    // rows first, then columns: the order of ATen's separable passes does not matter beyond fp32 rounding
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* img = a.src + (int64_t)q * a.H * a.W * a.C;
+    for (int j = 0; j < s_ny[ty]; ++j) {
+        const float* row = img + ((int64_t)(s_fy[ty] + j) * a.W + s_fx[tx]) * a.C;
+        float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < s_nx[tx]; ++i) {
+            const float w = s_wx[tx][i];
+            for (int c = 0; c < a.C; ++c) r[c] = fmaf(w, row[i * a.C + c], r[c]);
+        }
+        for (int c = 0; c < a.C; ++c) acc[c] = fmaf(s_wy[ty][j], r[c], acc[c]);
+    }
+    for (int c = 0; c < a.C; ++c)
+        a.dst[(((int64_t)q * a.C + c) * a.ch + oy) * a.cw + ox] = (acc[c] - a.mean[c]) * a.inv_std[c];
+}
+
 __global__ void k_vit_to_bf16(const float* __restrict__ src, int64_t n, __bf16* __restrict__ dst) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) dst[t] = (__bf16)src[t];
 }
@@ -323,11 +396,26 @@ inline unsigned grid1(int64_t n, int block = 256, int cap = 256 * 16) {
 template <int EPI>
 hipError_t gemm(const __bf16* X, const __bf16* W, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
     if (N % GBN != 0 || K % GBK != 0 || M < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_vit_gemm<EPI>), dim3((unsigned)(N / GBN), (unsigned)((M + GBM - 1) / GBM)), dim3(256), 0, s, X, W, M, N, K, e);
+    // 64-token tiles while 128-token tiles would leave CUs idle (256 CUs, two workgroups each)
+    if ((int64_t)(N / GBN) * ((M + 127) / 128) < 384)
+        hipLaunchKernelGGL((k_vit_gemm<EPI, 64>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, W, M, N, K, e);
+    else
+        hipLaunchKernelGGL((k_vit_gemm<EPI, 128>), dim3((unsigned)(N / GBN), (unsigned)((M + 127) / 128)), dim3(256), 0, s, X, W, M, N, K, e);
     return hipGetLastError();
 }
 
 }  // namespace
+
+hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int rh, int rw, int top, int left, int ch, int cw, int cubic,
+                              const float* mean, const float* std, float* dst, hipStream_t s) {
+    if (Q < 1) return hipSuccess;
+    ResizeArgs a;
+    a.src = src; a.Q = Q; a.H = H; a.W = W; a.C = C; a.rh = rh; a.rw = rw; a.top = top; a.left = left; a.ch = ch; a.cw = cw; a.cubic = cubic;
+    for (int c = 0; c < 4; ++c) { a.mean[c] = (mean && c < C) ? mean[c] : 0.0f; a.inv_std[c] = (std && c < C) ? 1.0f / std[c] : 1.0f; }
+    a.dst = dst;
+    hipLaunchKernelGGL(k_resize_crop, dim3((unsigned)((cw + 15) / 16), (unsigned)((ch + 15) / 16), (unsigned)Q), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_vit_to_bf16(const float* src, int64_t n, void* dst, hipStream_t s) {
     hipLaunchKernelGGL(k_vit_to_bf16, dim3(grid1(n)), dim3(256), 0, s, src, n, (__bf16*)dst);

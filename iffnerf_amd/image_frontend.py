@@ -57,16 +57,40 @@ def mask_token_rows(keep: torch.Tensor, row_max: torch.Tensor, row_sumexp: torch
               "iff_mask_token_rows")
 
 
+def resize_crop(src: torch.Tensor, resize_size: int, crop_size: int, cubic: bool, mean=None, std=None) -> torch.Tensor:
+    """``iff_image_resize_crop``: channels-last images [Q,H,W,C] -> the centre ``crop_size`` window of the antialiased resize whose
+    shorter edge is ``resize_size`` (torchvision Resize + CenterCrop of identification_module.py:36-61), normalised, channels-first
+    [Q,C,crop,crop].  ``crop_size`` None keeps the whole resized image."""
+    if not src.is_cuda:
+        raise RuntimeError("images must live on the GPU; libiffnerf_hip has no CPU path")
+    x = src.detach().to(torch.float32).contiguous()
+    Q, H, W, Cc = x.shape
+    if H <= W:
+        rh, rw = resize_size, max(1, int(resize_size * W / H))
+    else:
+        rh, rw = max(1, int(resize_size * H / W)), resize_size
+    ch, cw = (rh, rw) if crop_size is None else (crop_size, crop_size)
+    top, left = int(round((rh - ch) / 2.0)), int(round((rw - cw) / 2.0))
+    out = x.new_empty(Q, Cc, ch, cw)
+    m = None if mean is None else fvec(mean)
+    s = None if std is None else fvec(std)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().iff_image_resize_crop(dptr(x), Q, H, W, Cc, rh, rw, top, left, ch, cw, int(bool(cubic)), m, s, dptr(out),
+                                               stream_ptr(x.device)), "iff_image_resize_crop")
+    return out
+
+
 class ImageFrontEnd:
     """Resize / crop / normalise + backbone + token assembly for a batch of query images, all on the device."""
 
     def __init__(self, backbone: torch.nn.Module, grid=(16, 16), resize_size: int = 256, crop_size: int = 224,
-                 backbone_autocast: Optional[torch.dtype] = None):
+                 backbone_autocast: Optional[torch.dtype] = None, native_preprocess: bool = True):
         """``backbone_autocast``: None runs the backbone as it is (fp32: the reference's arithmetic); ``torch.bfloat16`` /
         ``torch.float16`` runs its matrix products under ``torch.autocast`` -- a throughput option of the third-party model, not
         parity-equivalent (token features move by ~1e-2 relative)."""
         self.backbone, self.grid, self.resize_size, self.crop_size = backbone, (int(grid[0]), int(grid[1])), resize_size, crop_size
         self.backbone_autocast = backbone_autocast
+        self.native_preprocess = bool(native_preprocess)     # iff_image_resize_crop instead of F.interpolate + crop + normalise
         self._norm = {}      # device -> (mean, std): made once, outside any capture (a host->device copy cannot be captured)
 
     def _mean_std(self, x):
@@ -80,15 +104,24 @@ class ImageFrontEnd:
     def tokens(self, imgs: torch.Tensor, masks: Optional[torch.Tensor] = None):
         """imgs [Q,H,W,3] in [0,1], masks [Q,H,W] (alpha) -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw]).
         The same arithmetic as identification_module.py:130-160 (``transformations`` / ``mask_transformations`` of the mirror)."""
-        x = _center_crop(_resize_short_edge(imgs.permute(0, 3, 1, 2), self.resize_size, "bicubic"), self.crop_size)
-        mean, std = self._mean_std(x)
+        if self.native_preprocess:
+            # resize + crop + normalise in one kernel (iff_image_resize_crop); the mask: resize + crop, then down to the token grid
+            xin = resize_crop(imgs, self.resize_size, self.crop_size, True, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD)
+        else:
+            x = _center_crop(_resize_short_edge(imgs.permute(0, 3, 1, 2), self.resize_size, "bicubic"), self.crop_size)
+            mean, std = self._mean_std(x)
+            xin = (x - mean) / std
         if self.backbone_autocast is None:
-            feats = self.backbone.forward_features((x - mean) / std)["x_norm_patchtokens"]
+            feats = self.backbone.forward_features(xin)["x_norm_patchtokens"]
         else:
             with torch.autocast(device_type="cuda", dtype=self.backbone_autocast):
-                feats = self.backbone.forward_features((x - mean) / std)["x_norm_patchtokens"]
+                feats = self.backbone.forward_features(xin)["x_norm_patchtokens"]
         mg = None
         if masks is not None:
-            m = _center_crop(_resize_short_edge(masks[:, None] * 1.0, self.resize_size, "bilinear"), self.crop_size)
-            mg = _resize_short_edge(m, self.grid[0], "bilinear").reshape(masks.shape[0], -1)
+            if self.native_preprocess:
+                m = resize_crop(masks[..., None] * 1.0, self.resize_size, self.crop_size, False)             # [Q,1,224,224]
+                mg = resize_crop(m.permute(0, 2, 3, 1), self.grid[0], None, False).reshape(masks.shape[0], -1)
+            else:
+                m = _center_crop(_resize_short_edge(masks[:, None] * 1.0, self.resize_size, "bilinear"), self.crop_size)
+                mg = _resize_short_edge(m, self.grid[0], "bilinear").reshape(masks.shape[0], -1)
         return token_assemble(feats, self.grid, mg, 0.1)

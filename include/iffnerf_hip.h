@@ -348,6 +348,17 @@ size_t iff_vit_workspace(const iff_vit* vit, int32_t Q);
 int iff_vit_forward(const iff_vit* vit, const float* images, int32_t Q, float* patch_tokens, float* cls_opt, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* Image preprocessing of IdentificationModule (pose_estimation/identification_module.py:36-61: torchvision Resize(256, BICUBIC) /
+ * Resize(BILINEAR), CenterCrop(224), Normalize): an antialiased separable resize -- the triangle (cubic = 0) or cubic a = -0.5
+ * (cubic = 1) filter stretched by the scale factor, as F.interpolate(antialias=True, align_corners=False) computes it -- of
+ * channels-last images src [Q,H,W,C] (C <= 4) to a virtual [resized_h, resized_w] image, of which only the crop window
+ * [crop_top, crop_left, crop_h, crop_w] is evaluated; every channel is then normalised, (v - mean[c]) / std[c] (host arrays of C
+ * floats, NULL = no normalisation), and written channels-first: dst [Q,C,crop_h,crop_w].  Scale factors up to 7.5 (cubic) / 15
+ * (triangle) per axis (32 filter taps); larger ones return IFF_ERR_UNSUPPORTED. */
+int iff_image_resize_crop(const float* src, int32_t Q, int32_t H, int32_t W, int32_t C, int32_t resized_h, int32_t resized_w,
+                          int32_t crop_top, int32_t crop_left, int32_t crop_h, int32_t crop_w, int32_t cubic, const float* mean_host_opt,
+                          const float* std_host_opt, float* dst, void* stream);
+
 /* Image tokens for stage C: what IdentificationModule.image_processing does after the backbone
  * (pose_estimation/identification_module.py:149-160) -- append the 14-channel position code of get_img_position_encoding
  * (:76-99: grid position in [-1,1]^2, 'ij' indexing, then sin / cos of it at octaves 1, 2, 4) to every patch token, and turn

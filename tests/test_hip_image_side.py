@@ -99,7 +99,7 @@ def test_image_in_pose_out_capture(dev, monkeypatch):
     pipe = PosePipeline.from_checkpoints(util.ckpt("small"), w, dev, model_up=(0.1, 0.2, 0.9))
     ori, dirs, rgb = pipe.emit(75, seed=3)
     rays = pipe.make_resident(ori, dirs, rgb)
-    fe = ImageFrontEnd(net, grid)
+    fe = ImageFrontEnd(net, grid, native_preprocess=False)          # the mirrored module's own torch ops: exact comparisons below
     gen = torch.Generator().manual_seed(2)
     Q, Hh, Ww = 3, 200, 260
     imgs = torch.rand(Q, Hh, Ww, 3, generator=gen).to(dev)
@@ -133,7 +133,7 @@ def test_image_in_pose_out_capture(dev, monkeypatch):
         assert torch.equal(cq.idx, idx) and torch.equal(cq.val, val) and torch.equal(cq.c2w, c2w)
     # the bf16-autocast option of the backbone: same masks, token features within bf16's reach of the fp32 ones, and a
     # capturable graph of its own (a throughput option: it is not parity-equivalent and nothing else uses it)
-    fe16 = ImageFrontEnd(net, grid, backbone_autocast=torch.bfloat16)
+    fe16 = ImageFrontEnd(net, grid, backbone_autocast=torch.bfloat16, native_preprocess=False)
     tok16, keep16 = fe16.tokens(imgs, masks)
     assert tok16.dtype == torch.float32 and torch.equal(keep16, keep) and torch.equal(tok16[..., 384:], tokens[..., 384:])
     rel = (tok16[..., :384] - tokens[..., :384]).norm() / tokens[..., :384].norm()
@@ -204,3 +204,42 @@ def test_native_vit_matches_the_fp32_torch_module(dev):
         vit.forward(x.cpu())
     with pytest.raises(RuntimeError):
         vit.forward(torch.zeros(1, 3, 200, 224, device=dev))
+
+
+def test_native_resize_crop_normalize_matches_the_torch_formulation(dev):
+    """iff_image_resize_crop (one kernel: antialiased bicubic / bilinear resize of the shorter edge, centre crop, normalisation,
+    channels-first) against the mirrored module's F.interpolate(antialias=True) + crop + normalise -- the torchvision transforms of
+    identification_module.py:36-61 as this package restates them (torchvision itself is absent from the image: that boundary stays
+    'parity unpinned')."""
+    from iffnerf_amd.image_frontend import ImageFrontEnd, resize_crop
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    from iffnerf_amd.pose_estimation.identification_module import (IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, _center_crop,
+                                                                   _resize_short_edge)
+    gen = torch.Generator().manual_seed(8)
+    mean = torch.tensor(IMAGENET_DEFAULT_MEAN, device=dev).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_DEFAULT_STD, device=dev).view(1, 3, 1, 1)
+    for (H, W) in ((800, 800), (600, 900), (1080, 1920), (300, 260), (224, 224), (150, 170)):
+        imgs = torch.rand(2, H, W, 3, generator=gen).to(dev)
+        want = (_center_crop(_resize_short_edge(imgs.permute(0, 3, 1, 2), 256, "bicubic"), 224) - mean) / std
+        got = resize_crop(imgs, 256, 224, True, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD)
+        assert got.shape == want.shape == (2, 3, 224, 224)
+        torch.testing.assert_close(got, want, atol=2e-5, rtol=0)
+        masks = (torch.rand(2, H, W, generator=gen) > 0.4).float().to(dev)
+        m_want = _center_crop(_resize_short_edge(masks[:, None], 256, "bilinear"), 224)
+        m_got = resize_crop(masks[..., None], 256, 224, False)
+        torch.testing.assert_close(m_got, m_want, atol=2e-6, rtol=0)
+        g_want = _resize_short_edge(m_want, 16, "bilinear")
+        g_got = resize_crop(m_got.permute(0, 2, 3, 1), 16, None, False)
+        torch.testing.assert_close(g_got, g_want, atol=2e-6, rtol=0)
+    # the front end with either preprocessing: same keep flags, tokens equal to the fp32 backbone's sensitivity
+    net, grid, _ = create_standin_backbone(seed=5)
+    net = net.to(dev)
+    imgs = torch.rand(3, 800, 800, 3, generator=gen).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(800), torch.arange(800), indexing="ij")
+    masks = (((yy - 380) ** 2 + (xx - 420) ** 2) <= 300 ** 2).float().to(dev)[None].expand(3, -1, -1).contiguous()
+    ta, ka = ImageFrontEnd(net, grid, native_preprocess=True).tokens(imgs, masks)
+    tb, kb = ImageFrontEnd(net, grid, native_preprocess=False).tokens(imgs, masks)
+    assert torch.equal(ka, kb) and 50 < int(ka[0].sum()) < 256
+    torch.testing.assert_close(ta, tb, atol=2e-4, rtol=0)
+    with pytest.raises(RuntimeError):
+        resize_crop(torch.rand(1, 4000, 4000, 3, device=dev), 256, 224, True)          # scale 15.6: beyond the kernel's 32 taps
