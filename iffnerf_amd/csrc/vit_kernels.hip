@@ -14,6 +14,7 @@
 // accumulator registers (the k order of that product is permuted to the accumulator's row order, MI355X_MICROARCH / cdna guide 3).
 #include "iff_device.h"
 #include "iff_launch.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -351,7 +352,11 @@ struct ResizeArgs {
     float mean[4], inv_std[4];
     float* dst;                                  // [Q,C,ch,cw]
 };
-__global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a) {
+// One workgroup = a 16 x 16 tile of the output.  Separable inside the tile: every input row the tile's 16 output rows touch is
+// filtered horizontally once for the tile's 16 columns (LDS), then the columns are filtered vertically -- the order of ATen's
+// kernel (horizontal sum per row, then the weighted sum of rows), ~3x fewer multiply-adds than a 2-D sum per output pixel.
+__global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows) {
+    extern __shared__ float s_tmp[];            // [rows][16][C]
     __shared__ float s_wx[16][RS_TAPS], s_wy[16][RS_TAPS];
     __shared__ int s_fx[16], s_nx[16], s_fy[16], s_ny[16];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -359,22 +364,34 @@ __global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a) {
     if (threadIdx.x < 16) aa_weights(a.left + min(ox0 + tx, a.cw - 1), a.W, a.rw, a.cubic, s_wx[tx], s_fx[tx], s_nx[tx]);
     else if (threadIdx.x < 32) aa_weights(a.top + min(oy0 + tx, a.ch - 1), a.H, a.rh, a.cubic, s_wy[tx], s_fy[tx], s_ny[tx]);
     __syncthreads();
+    const int ry0 = s_fy[0];
+    int ry1 = ry0;
+    for (int i = 0; i < 16; ++i) ry1 = max(ry1, s_fy[i] + s_ny[i]);
+    const int n_rows = min(ry1 - ry0, max_rows);
+    const int C = a.C;
+    const float* img = a.src + (int64_t)q * a.H * a.W * C;
+    for (int item = threadIdx.x; item < n_rows * 16; item += 256) {
+        const int r = item >> 4, ox = item & 15;
+        const float* row = img + ((int64_t)(ry0 + r) * a.W + s_fx[ox]) * C;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < s_nx[ox]; ++i) {
+            const float w = s_wx[ox][i];
+            for (int c = 0; c < C; ++c) acc[c] = fmaf(w, row[i * C + c], acc[c]);
+        }
+        for (int c = 0; c < C; ++c) s_tmp[item * C + c] = acc[c];
+    }
+    __syncthreads();
     const int ox = ox0 + tx, oy = oy0 + ty;
     if (ox >= a.cw || oy >= a.ch) return;
-    // rows first, then columns: the order of ATen's separable passes does not matter beyond fp32 rounding
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const float* img = a.src + (int64_t)q * a.H * a.W * a.C;
+    const int rbase = s_fy[ty] - ry0;
     for (int j = 0; j < s_ny[ty]; ++j) {
-        const float* row = img + ((int64_t)(s_fy[ty] + j) * a.W + s_fx[tx]) * a.C;
-        float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = 0; i < s_nx[tx]; ++i) {
-            const float w = s_wx[tx][i];
-            for (int c = 0; c < a.C; ++c) r[c] = fmaf(w, row[i * a.C + c], r[c]);
-        }
-        for (int c = 0; c < a.C; ++c) acc[c] = fmaf(s_wy[ty][j], r[c], acc[c]);
+        const float w = s_wy[ty][j];
+        const float* t = s_tmp + ((rbase + j) * 16 + tx) * C;
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(w, t[c], acc[c]);
     }
-    for (int c = 0; c < a.C; ++c)
-        a.dst[(((int64_t)q * a.C + c) * a.ch + oy) * a.cw + ox] = (acc[c] - a.mean[c]) * a.inv_std[c];
+    for (int c = 0; c < C; ++c)
+        a.dst[(((int64_t)q * C + c) * a.ch + oy) * a.cw + ox] = (acc[c] - a.mean[c]) * a.inv_std[c];
 }
 
 __global__ void k_vit_to_bf16(const float* __restrict__ src, int64_t n, __bf16* __restrict__ dst) {
@@ -396,8 +413,8 @@ inline unsigned grid1(int64_t n, int block = 256, int cap = 256 * 16) {
 template <int EPI>
 hipError_t gemm(const __bf16* X, const __bf16* W, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
     if (N % GBN != 0 || K % GBK != 0 || M < 1) return hipErrorInvalidValue;
-    // 64-token tiles while 128-token tiles would leave CUs idle (256 CUs, two workgroups each)
-    if ((int64_t)(N / GBN) * ((M + 127) / 128) < 384)
+    static const int force = [] { const char* e = getenv("IFF_VIT_TILE"); return e ? atoi(e) : 0; }();      // tuning aid
+    if (force != 128)       // 64-token tiles: with 128 the 4112-token batch leaves CUs idle or a single workgroup per CU
         hipLaunchKernelGGL((k_vit_gemm<EPI, 64>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, W, M, N, K, e);
     else
         hipLaunchKernelGGL((k_vit_gemm<EPI, 128>), dim3((unsigned)(N / GBN), (unsigned)((M + 127) / 128)), dim3(256), 0, s, X, W, M, N, K, e);
@@ -413,7 +430,12 @@ hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int 
     a.src = src; a.Q = Q; a.H = H; a.W = W; a.C = C; a.rh = rh; a.rw = rw; a.top = top; a.left = left; a.ch = ch; a.cw = cw; a.cubic = cubic;
     for (int c = 0; c < 4; ++c) { a.mean[c] = (mean && c < C) ? mean[c] : 0.0f; a.inv_std[c] = (std && c < C) ? 1.0f / std[c] : 1.0f; }
     a.dst = dst;
-    hipLaunchKernelGGL(k_resize_crop, dim3((unsigned)((cw + 15) / 16), (unsigned)((ch + 15) / 16), (unsigned)Q), dim3(256), 0, s, a);
+    // input rows one tile can touch: 16 output rows apart by the scale factor, plus the filter support on both sides
+    const float sy = (float)H / (float)rh, sup = (cubic ? 2.0f : 1.0f) * (sy >= 1.0f ? sy : 1.0f);
+    const int max_rows = (int)(15.0f * sy + 2.0f * sup) + 4;
+    const size_t lds = (size_t)max_rows * 16 * C * sizeof(float);
+    if (lds > 60 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_resize_crop, dim3((unsigned)((cw + 15) / 16), (unsigned)((ch + 15) / 16), (unsigned)Q), dim3(256), lds, s, a, max_rows);
     return hipGetLastError();
 }
 
