@@ -201,3 +201,72 @@ def test_batched_runs_large_point_counts_and_residency(small, dev):
     assert cap == cap16 and cap >= 256 and w1 == 47 and w16 == 12          # 4 lanes / 1 lane per candidate at P = 593
     w_big, _ = small.sampler_residency(20000, 1)
     assert w_big <= 256                                                     # never more than one workgroup per CU and run
+
+
+def _philox_np(i, j, c2, seed):
+    """Vectorised Philox4x32-10 for counters (i, j, c2, 0xA5) and the 64-bit key ``seed`` -> four uint32 arrays."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    mask = np.uint64(0xFFFFFFFF)
+    x, y = i.astype(np.uint64), j.astype(np.uint64)
+    z, w = np.full_like(x, c2), np.full_like(x, 0xA5)
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    for _ in range(10):
+        p0, p1 = M0 * x, M1 * z
+        x, y, z, w = ((p1 >> np.uint64(32)) ^ y ^ np.uint64(k0)) & mask, p1 & mask, ((p0 >> np.uint64(32)) ^ w ^ np.uint64(k1)) & mask, p0 & mask
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return x, y, z, w
+
+
+def test_accept_and_pick_decisions_of_one_iteration(small, dev):
+    """Every accept / select decision of one sampler iteration, replayed from the kernel's own random stream: for P samples x
+    m = 5 candidates x 8 seeds the candidates are rebuilt (independent Philox + the reference's formulas, float64), their alphas
+    taken from iff_point_alpha, and then (sampling.py:160-200)
+      * a sample moves iff one of its candidates beats the epoch threshold (outside a 1e-5 band around it),
+      * the candidate it moved to is one of the passing ones, and
+      * the pick is UNIFORM among the passing candidates: the rank of the chosen one among k passing candidates is tested
+        against the uniform distribution on {0..k-1} by chi-square for every k (the reference picks index
+        floor(u (k - 1 + 0.99)) in alpha order; the kernel gives every passing candidate a random priority and keeps the maximum)."""
+    ck = util.ckpt("small")
+    rho, P, m = rho_of(ck), 3000, 5
+    counts = {k: np.zeros(k) for k in range(2, m + 1)}
+    n_checked = 0
+    for seed in range(9000, 9008):
+        s0, a0, _ = small.surface_sample(P, rho, n_epochs=0, seed=seed)
+        s1, a1, st = small.surface_sample(P, rho, n_epochs=1, max_iterations=1, seed=seed)
+        st = st.cpu()
+        assert int(st[0, 0]) == 1 and int(st[0, 3]) == m
+        thresh = st[0, 2:3].view(torch.float32).item()
+        ii, jj = np.meshgrid(np.arange(P), np.arange(m), indexing="ij")
+        r = _philox_np(ii.ravel(), jj.ravel(), 0, seed)
+        u = [(v >> np.uint64(8)).astype(np.float64) / 16777216.0 for v in r]
+        theta, phi = 2 * np.pi * u[0], np.arccos(1 - 2 * u[1])
+        g = np.sqrt(-2 * np.log(1 - u[2])) * np.cos(2 * np.pi * u[3])
+        d = np.stack([np.sin(phi) * np.cos(theta), np.sin(phi) * np.sin(theta), np.cos(phi)], -1) * np.abs(g * rho)[:, None]
+        cand = s0.cpu().double().numpy()[ii.ravel()] + d                                  # [P*m, 3]
+        a_c = small.point_alpha(torch.from_numpy(cand).float().to(dev)).cpu().numpy().reshape(P, m)
+        clear = np.abs(a_c - thresh) > 1e-5                                                # decisions not inside the rounding band
+        passing = a_c > thresh
+        s0n, s1n = s0.cpu().double().numpy(), s1.cpu().double().numpy()
+        moved = (s1n != s0n).any(-1)
+        dist = np.abs(cand.reshape(P, m, 3) - s1n[:, None]).max(-1)                        # which candidate the sample sits on
+        chosen = dist.argmin(-1)
+        for i in range(P):
+            if not clear[i].all():
+                continue
+            n_checked += 1
+            assert moved[i] == passing[i].any(), (seed, i)
+            if moved[i]:
+                assert dist[i, chosen[i]] < 5e-6 and passing[i, chosen[i]], (seed, i)
+                k = int(passing[i].sum())
+                if k >= 2:
+                    counts[k][int(passing[i, :chosen[i]].sum())] += 1
+    assert n_checked > 0.95 * 8 * P
+    # chi-square against the uniform pick, 1e-4 critical values for k - 1 degrees of freedom
+    crit = {2: 15.14, 3: 18.42, 4: 21.11, 5: 23.51}
+    for k, c in counts.items():
+        n = c.sum()
+        if n < 200:
+            continue
+        chi2 = float(((c - n / k) ** 2 / (n / k)).sum())
+        assert chi2 < crit[k], (k, c.tolist(), chi2)
+    assert sum(c.sum() for c in counts.values()) > 2000
