@@ -102,6 +102,36 @@ __device__ __forceinline__ const f32q* line_chunk(const float* __restrict__ tab,
     return reinterpret_cast<const f32q*>(tab + (size_t)row * C + 4 * q);
 }
 
+// mask_value (iff_device.h) with its eight byte loads unconditional (indices clamped into the volume, the bounds test applied to
+// the loaded value afterwards): the same products and the same summation order, but all loads of a sample -- and of the three
+// samples a lane handles -- are in flight together instead of one L2 round trip per corner behind its bounds branch.
+__device__ __forceinline__ float mask_value_flat(const FieldDev& f, const float p[3]) {
+    float g[3];
+    mask_normalize(f, p, g);
+    const int W = f.mask_dims[2], H = f.mask_dims[1], D = f.mask_dims[0];
+    const float ix = unnorm(g[0], W), iy = unnorm(g[1], H), iz = unnorm(g[2], D);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
+    const bool ok = ix > -2.0f && ix < (float)(W + 1) && iy > -2.0f && iy < (float)(H + 1) && iz > -2.0f && iz < (float)(D + 1);
+    const int x0 = ok ? (int)fx : -2, y0 = ok ? (int)fy : -2, z0 = ok ? (int)fz : -2;
+    unsigned char v[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int x = x0 + (c8 & 1), y = y0 + ((c8 >> 1) & 1), z = z0 + (c8 >> 2);
+        const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1), zc = min(max(z, 0), D - 1);
+        v[c8] = f.mask[((size_t)zc * H + yc) * W + xc];
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {                  // corner order of mask_value: dz outermost, dx innermost
+        const int dx = c8 & 1, dy = (c8 >> 1) & 1, dz = c8 >> 2;
+        const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+        const bool in = (x >= 0) && (x < W) && (y >= 0) && (y < H) && (z >= 0) && (z < D);
+        acc = acc + (in ? (float)v[c8] : 0.0f) * (wx[dx] * wy[dy] * wz[dz]);
+    }
+    return ok ? acc : 0.0f;
+}
+
 struct RecView {           // one sample record, unpacked (all lanes of a sub-group read the same record)
     float w;               // compositing weight (after phase B)
     bool valid;
@@ -127,8 +157,10 @@ __device__ __forceinline__ RecView read_rec(const uint32_t* rec) {
 // compositing weights come from K4a's workspace (A/B aid).
 template <int MODE>
 __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, MarchArgs a, int64_t n_tiles) {
-    __shared__ __align__(16) float s_patch[PATCH_FLOATS];
-    __shared__ __align__(16) uint32_t s_rec[FR * FS * REC];
+    // the patch buffer and the sample records are one pool: phase D lays the two operands of its matrix product over both
+    __shared__ __align__(16) float s_pool[PATCH_FLOATS + FR * FS * REC];
+    float* const s_patch = s_pool;
+    uint32_t* const s_rec = reinterpret_cast<uint32_t*>(s_pool + PATCH_FLOATS);
     __shared__ __align__(16) float s_feat[FR * 28];
     __shared__ float s_ray[FR * 8];
     __shared__ int s_box[8];
@@ -233,7 +265,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
                 const int s = min(l8 + 8 * k, FS - 1);
                 const float z = z_of(f, 0, FS, 0.0f, s);
                 const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
-                mvs[k] = (live && inside_aabb(f, p)) ? mask_value(f, p) : 0.0f;
+                mvs[k] = (live && inside_aabb(f, p)) ? mask_value_flat(f, p) : 0.0f;
             }
         }
 #pragma unroll
@@ -287,8 +319,8 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     };
     auto fetch_basis = [&]() {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) pre[r] = *reinterpret_cast<const f32q*>(f.basis_l12 + 4 * (tid + NT * r));
-        if (tid < BASIS_FLOATS / 4 - 3 * NT) pre[3] = *reinterpret_cast<const f32q*>(f.basis_l12 + 4 * (tid + NT * 3));
+        for (int r = 0; r < 3; ++r) pre[r] = *reinterpret_cast<const f32q*>(f.basis + 4 * (tid + NT * r));
+        if (tid < BASIS_FLOATS / 4 - 3 * NT) pre[3] = *reinterpret_cast<const f32q*>(f.basis + 4 * (tid + NT * 3));
     };
     if (fits) fetch_app(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -487,42 +519,56 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
         fetch_basis();
     }
     // ---------------------------------------------------------------------------------------------------- phase D: basis_mat
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 3; ++r) *reinterpret_cast<f32q*>(s_patch + 4 * (tid + NT * r)) = pre[r];
-    if (tid < BASIS_FLOATS / 4 - 3 * NT) *reinterpret_cast<f32q*>(s_patch + 4 * (tid + NT * 3)) = pre[3];
+    // F[ray][o] = sum_k basis_mat[o][k] * A[ray][k] over the 144 weighted products (k = 48 plane + channel, the column order of
+    // basis_mat): one 32 x 32 x 144 product per tile on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain),
+    // k split over the four waves, the four partial tiles added in a fixed order -- the vector ALU only moves operands.
+    constexpr int DLD = 33;                            // operand rows padded: conflict-free ds_read_b32 down a column of k
+    float* const s_A = s_pool;                         // [144][DLD]  A^T: weighted products, column = ray of the tile
+    float* const s_B = s_pool + 144 * DLD;             // [144][DLD]  basis_mat^T, column = output feature
+    static_assert(2 * 144 * DLD <= PATCH_FLOATS + FR * FS * REC && 4 * 32 * 32 <= PATCH_FLOATS + FR * FS * REC, "phase D operands fit the pool");
     // even samples + odd samples: both sub-groups of a ray hold the ray's sums afterwards
 #pragma unroll
     for (int i = 0; i < 36; ++i) accp[i] = accp[i] + xor4_dpp(accp[i]);
-    __syncthreads();
-    STAMP(12);
-    f32q bn[9];                                        // the basis rows of the next output are read one trip ahead
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) bn[3 * j + q] = *reinterpret_cast<const f32q*>(s_patch + (h * 12 + c + 4 * j) * 12 + 4 * q);
-#pragma unroll 1
-    for (int oo = h; oo < 27; oo += 2) {
-        f32q bc[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) bc[q] = bn[q];
-        const int on = min(oo + 2, 26);
+    __syncthreads();                                   // every wave is done with the patch and the records
+    if (grp_on && h == 0) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) bn[3 * j + q] = *reinterpret_cast<const f32q*>(s_patch + (on * 12 + c + 4 * j) * 12 + 4 * q);
-        float v[3];
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const f32q b0 = bc[3 * j], b1 = bc[3 * j + 1], b2 = bc[3 * j + 2];
-            const float bl[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-            float acc = 0.0f;
+                for (int e4 = 0; e4 < 4; ++e4) s_A[(48 * i + 16 * j + 4 * c + e4) * DLD + g] = accp[12 * j + 4 * i + e4];
+    }
 #pragma unroll
-            for (int kk = 0; kk < 12; ++kk) acc = fmaf(bl[kk], accp[12 * j + kk], acc);
-            v[j] = acc;
+    for (int r = 0; r < 4; ++r) {
+        const int chunk = tid + NT * r;
+        if (chunk < BASIS_FLOATS / 4) {
+            const int o = chunk / 36, k4 = (chunk - o * 36) * 4;
+            s_B[(k4 + 0) * DLD + o] = pre[r].x; s_B[(k4 + 1) * DLD + o] = pre[r].y;
+            s_B[(k4 + 2) * DLD + o] = pre[r].z; s_B[(k4 + 3) * DLD + o] = pre[r].w;
         }
-        const float out = sum4_dpp((v[0] + v[1]) + v[2]);         // quarters (c, c+4, c+8), then the four lanes by xor butterfly
-        if (c == 0 && grp_on) s_feat[g * 28 + oo] = out;
+    }
+    __syncthreads();
+    STAMP(12);
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 dacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+    {
+        const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {                 // this wave's 36 values of k, two per instruction
+            const int k = 36 * wave + 2 * t + lh;
+            dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_A[k * DLD + lr], s_B[k * DLD + lr], dacc, 0, 0, 0);
+        }
+        __syncthreads();                               // the operands have been read: the partial tiles go over them
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_pool[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = dacc[r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < FR * 27; idx += NT) {
+        const int ry = idx / 27, o = idx - ry * 27;
+        const float* pp = s_pool + ry * 32 + o;
+        s_feat[ry * 28 + o] = (pp[0] + pp[32 * 32]) + (pp[2 * 32 * 32] + pp[3 * 32 * 32]);
     }
     if ((tid & 7) == 0 && grp_on) s_feat[g * 28 + 27] = any ? 1.0f : 0.0f;
     STAMP(13);
