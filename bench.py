@@ -424,7 +424,7 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     if pipe.field.march_plan(0, 20) == 2:
         kernels.append(gather_kernel(
             "k4f_fan_march<2> (TensorBase.forward up to the Ref head, fused per 27-ray fan: density, compositing, appearance, basis_mat)",
-            ("(anonymous namespace)::k4f_fan_march<2>",), "lds-gather", LDS_PEAK_GBS, bytes_a + bytes_b - rays_per_launch * 2 * 20 * 4,
+            ("k4f_fan_march<2>",), "lds-gather", LDS_PEAK_GBS, bytes_a + bytes_b - rays_per_launch * 2 * 20 * 4,
             march_launch_ms[1],
             "algorithmic bytes = 1184 B per valid sample + 3456 B per shaded sample (SURVEY 8d) x the kernel's own sample counters + "
             "rays in / features out.  The table patches a fan touches are staged once in LDS (coalesced row segments: `traffic` is "

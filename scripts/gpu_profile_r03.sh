@@ -14,7 +14,6 @@ for cfg in "${CFGS[@]}"; do
   mv gpurun_out/r03_${cfg}_pmc_counters.csv gpurun_out/r03_pmc_counters_$cfg.csv
   cp "$(ls $P/stats/*/*kernel_stats.csv $P/stats/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/r03_bench_kernel_stats_$cfg.csv
   cp "$(ls $P/stats_if1/*/*kernel_stats.csv $P/stats_if1/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/r03_bench_kernel_stats_inflight1_$cfg.csv
-  rm -rf $P/*/  # the raw per-pass directories are large; the summaries above are what is kept
   tail -12 gpurun_out/r03_${cfg}_summary.txt | cut -c1-400
 done
 ls -la gpurun_out/r03_*

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     return name.split("(")[0][:120]
 
 
