@@ -160,8 +160,9 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     // the patch buffer and the sample records are one pool: phase D lays the two operands of its matrix product over both
     __shared__ __align__(16) float s_pool[PATCH_FLOATS + FR * FS * REC];
     float* const s_patch = s_pool;
+    float* const s_feat = s_pool + 4 * 32 * 32;        // [FR][28] output rows: written after phase D's partial tiles, behind them
+    static_assert(4 * 32 * 32 + FR * 28 <= PATCH_FLOATS + FR * FS * REC, "output rows fit behind the partial tiles");
     uint32_t* const s_rec = reinterpret_cast<uint32_t*>(s_pool + PATCH_FLOATS);
-    __shared__ __align__(16) float s_feat[FR * 28];
     __shared__ float s_ray[FR * 8];
     __shared__ int s_box[8];
     const int tid = threadIdx.x;
