@@ -56,14 +56,15 @@ def test_defaults_and_workloads():
 
 
 def test_traffic_figure_is_keyed_on_the_kernel_sources():
-    """profiles/r02_hbm_traffic.json carries the fingerprint of the sources it was measured on; bench.py and the summariser
-    compute it the same way (bench.py reports `roofline.traffic` only while they agree)."""
+    """profiles/r03_hbm_traffic_<config>.json carries the fingerprint of the sources it was measured on and the workload; bench.py
+    and the summariser compute the fingerprint the same way (bench.py reports `roofline.traffic` only while both agree)."""
     import bench
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import summarize_pmc
     fp = bench.source_fingerprint()
     assert fp == summarize_pmc.source_fingerprint() and len(fp) == 16
-    j = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-    assert j["config"] == "lego16k" and len(j["source_sha16"]) == 16
-    for k in ("k5_trunk_h<1, 1, 2>", "k4b_appearance12<27>", "k4a_density_composite<1>"):
-        assert j["kernels"][k]["hbm_bytes_per_launch"] > 0 and j["kernels"][k]["vmem_rd_wave_insts"] > 0
+    for cfg, march in (("lego16k", "k4f_fan_march<2>"), ("truck32k", "k4f_fan_march<2>"), ("bicycle64k", "k4b_appearance12<27>")):
+        j = json.load(open(os.path.join(ROOT, "profiles", f"r03_hbm_traffic_{cfg}.json")))
+        assert j["config"] == cfg and len(j["source_sha16"]) == 16
+        for k in ("k5_trunk_h<1, 1, 2>", march):
+            assert j["kernels"][k]["hbm_bytes_per_launch"] > 0 and j["kernels"][k]["valu_wave_insts"] > 0, (cfg, k)
