@@ -539,7 +539,7 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
     const int C = d->feature_c, Fe = d->fea, IF = d->img_fea;
     if (int rc = check_idnet_dims(C, Fe, IF)) return rc;
     IFF_REQUIRE(d->gemm_mode >= 0 && d->gemm_mode <= 3, "iff_idnet_create: gemm_mode must be one of IFF_GEMM_* (0..3)");
-    IFF_REQUIRE(d->trunk_variant >= 0 && d->trunk_variant <= 3, "iff_idnet_create: trunk_variant must be 0 (choose) or 1..3");
+    IFF_REQUIRE(d->trunk_variant >= 0 && d->trunk_variant <= 4, "iff_idnet_create: trunk_variant must be 0 (choose) or 1..4");
     const int KQ = (IF + 15) / 16 * 16;
     const int XW = 160;                  // encoder input 141 padded to a multiple of 32 (identify_kernels.hip)
     const int QLD = C + 16;
@@ -1036,7 +1036,7 @@ static int validate_idnet_file(const char* path, const IdNetDev& v, size_t slab_
     auto small = [](int e) { return e >= -64 && e <= 64; };
     IFF_REQUIRE(v.qf_ld == v.feature_c + 16 && (v.gemm_mode == 0 || v.gemm_mode == 1) && (v.trunk_f16 == 0 || v.trunk_f16 == 1) &&
                     (v.trunk_f16 == 0 || f16) && (v.fused_trunk == 0 || (v.fused_trunk == 1 && fused)) && v.trunk_variant >= 0 &&
-                    v.trunk_variant <= 2 && small(v.e_x) && small(v.e_h1) && small(v.e_h2) && small(v.e_h3) && small(v.e_w1) &&
+                    v.trunk_variant <= 3 && small(v.e_x) && small(v.e_h1) && small(v.e_h2) && small(v.e_h3) && small(v.e_w1) &&
                     small(v.e_w2) && small(v.e_w3h) && small(v.e_w3x),
                 "%s: implausible identification-net parameters", path);
     return 0;

@@ -470,9 +470,258 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ two tiles, one stage apart
+// k5_trunk_h2: a workgroup of SIXTEEN waves serves two 64-ray tiles.  Waves 0-7 ("half A") run on tile 2 b, waves 8-15 ("half B")
+// on tile 2 b + 1, each exactly the program of k5_trunk_h<MODE, 1, 2> on its tile -- same work split (a wave = 32 features of all
+// 64 rays), same arithmetic, same results bit for bit, softmax partials included -- but as a list of stages in which matrix-core
+// stages and vector-ALU stages ALTERNATE
+//     [encoder input | layer 1 + x-part of layer 3 | split | layer 2 | split | layer 3 | split | (logits product | epilogue) per block]
+// and half B runs ONE STAGE BEHIND half A.  A workgroup's waves go to the four SIMDs in cyclic order, so every SIMD hosts two
+// waves of each half: at every moment two of its waves issue MFMAs and two do vector work (hi/lo split, sincos, exact division,
+// exp, stores), and the two pipes run side by side.  In k5_trunk_h all waves of a workgroup are in the same phase between two
+// barriers, and the two workgroups of a CU start together, take equally long and so stay in lockstep: the matrix pipe idles
+// through every vector phase.  The weight stream per ray is that of k5_trunk_h (one pass over the weights per 64 rays) -- a
+// split of ONE tile's rays over the halves doubles it (measured: 0.75-0.89 ms against 0.48-0.50 ms for k5_trunk_h, same box).
+// Stages are separated by workgroup barriers; both halves pass the same number of them.
+// MEASURED (same box, 16 x 16 011 rays, M = 256): 0.548 ms against 0.501 ms for k5_trunk_h<1, 1, 2> -- the enforced overlap does
+// NOT pay.  What it gives up is the reason the lockstep of two workgroups is not the loss it looks like: the two workgroups of a
+// CU stream the SAME weight fragments at the same time, so the second one hits the first one's lines in the vector L1 (hit rate
+// 0.71 in the counters); one stage apart the halves stream different layers and every fragment comes from L2.  The weight stream
+// (852 KB per 64-ray tile through a 64-B/clk path) is what the matrix pipe waits for.  Kept as iff_idnet_desc.trunk_variant = 4
+// for the A/B; not the default.
+template <int MODE>
+__global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_tiles) {
+    static_assert(MODE == 1 || MODE == 3, "the two-tile form serves the two logits launches");
+    constexpr int FG = 1, RG = 2, TR = 64;
+    __shared__ __attribute__((aligned(16))) _Float16 SS[2][2][TR][HSLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave16 = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar registers
+    const int half = wave16 >> 3, wave = wave16 & 7, th = tid & 511;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t tile = 2 * (int64_t)blockIdx.x + half;
+    const bool tile_on = tile < n_tiles;                      // an odd tile count leaves the last workgroup's half B idle
+    const int64_t row0 = tile * TR;
+    const int64_t N = a.N;
+    _Float16 (*S)[TR][HSLD] = SS[half];
+    {
+        const size_t qb = blockIdx.y;
+        if (MODE == 1) { a.ray_o += qb * N * 3; a.ray_d += qb * N * 3; a.ray_c += qb * N * 3; }
+        if (MODE == 3) a.planes += qb * 2 * (size_t)N * HC;
+        a.Qf += qb * (size_t)(a.Mpad / 256) * (HC / 16) * 2 * 8 * 64;
+        a.qscale += qb * (size_t)a.Mpad;
+        a.rowc += qb * (size_t)a.M * a.rowc_ld;
+        a.logits += qb * (size_t)a.M * N;
+        a.part += qb * (size_t)n_tiles * a.Mpad;
+    }
+    f32x16 acc[FG][RG], acc3[FG][RG];
+    auto zero = [](f32x16 (&ac)[FG][RG]) {
+#pragma unroll
+        for (int y = 0; y < RG; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ac[0][y][r] = 0.0f;
+    };
+    constexpr int KX = (141 + 15) / 16, KH = HC / 16;
+
+    auto load_act = [&](f16x8 (&v)[RG][2], int ks) {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) v[rg][pl] = *reinterpret_cast<const f16x8*>(&S[pl][32 * rg + lr][16 * ks + 8 * lh]);
+    };
+    auto write_planes = [&](const f32x16 (&ac)[FG][RG], const float* __restrict__ bias, float inv, float s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * wave + 8 * q + 4 * lh;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + f0);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                f16x4 p0, p1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = fmaxf(fmaf(ac[0][rg][4 * q + i], inv, bb[i]), 0.0f);
+                    _Float16 hi, lo;
+                    split_h(fminf(v * s, H_MAX), hi, lo);
+                    p0[i] = hi; p1[i] = lo;
+                }
+                *reinterpret_cast<f16x4*>(&S[0][32 * rg + lr][f0]) = p0;
+                *reinterpret_cast<f16x4*>(&S[1][32 * rg + lr][f0]) = p1;
+            }
+        }
+    };
+    // the k loop of k5_trunk_h: weight fragments DEPTH - 1 k-steps ahead in registers; DUAL: two weight streams over the same activations
+    auto phase = [&](auto nk_c, auto depth_c, auto dual_c, auto swap_c, f32x16 (&accA)[FG][RG], const uint4* __restrict__ WA,
+                     f32x16 (&accB)[FG][RG], const uint4* __restrict__ WB) {
+        constexpr int NK = decltype(nk_c)::value, DEPTH = decltype(depth_c)::value;
+        constexpr bool DUAL = decltype(dual_c)::value, SWAP = decltype(swap_c)::value;
+        WFragH<FG> wa[DEPTH], wb[DUAL ? DEPTH : 1];
+        f16x8 act[RG][2];
+        load_act(act, 0);
+#pragma unroll
+        for (int i = 0; i < DEPTH - 1; ++i) {
+            if (i < NK) {
+                trunk_load_w_h(wa[i], WA, i, wave, lane);
+                if (DUAL) trunk_load_w_h(wb[i], WB, i, wave, lane);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            if (ks + DEPTH - 1 < NK) {
+                trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wave, lane);
+                if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wave, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (SWAP) trunk_mfma_ht<FG, RG>(accA, wa[ks % DEPTH], act);
+            else trunk_mfma_h<FG, RG>(accA, wa[ks % DEPTH], act);
+            if (DUAL) trunk_mfma_h<FG, RG>(accB, wb[ks % DEPTH], act);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NK) load_act(act, ks + 1);
+        }
+    };
+    using std::integral_constant;
+    using no_t = integral_constant<bool, false>;
+    using yes_t = integral_constant<bool, true>;
+
+    const int n_tb = a.Mpad / 256;
+    const int tb_per = (n_tb + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int tb0 = (int)blockIdx.z * tb_per, tb1 = min(n_tb, tb0 + tb_per);
+    const float divisor = a.divisor, inv_div = 1.0f / divisor;
+
+    // The program of one half: every stage ends at a workgroup barrier.  `on` = this half has a tile (an odd tile count leaves the
+    // last workgroup's half B without one: it only keeps the barrier count).  Straight-line code per half (the two halves are
+    // two inlined copies): a loop over a runtime stage index keeps both accumulator sets live through every stage and spills.
+    auto program = [&](bool on) {
+        if (MODE == 3) {
+            if (on) {
+            for (int u = th; u < 2 * TR * (HC / 8); u += 512) {
+                const int pl = u / (TR * (HC / 8)), rem = u - pl * (TR * (HC / 8)), ray = rem / (HC / 8), ch = rem - ray * (HC / 8);
+                const int64_t gr = row0 + ray;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (gr < N) v = *reinterpret_cast<const uint4*>(a.planes + ((size_t)pl * N + gr) * HC + 8 * ch);
+                *reinterpret_cast<uint4*>(&S[pl][ray][8 * ch]) = v;
+            }
+            }
+            __syncthreads();
+        } else {
+            if (on) {
+            // encoder input (see k5_trunk_h): 94 work items per ray, 64 rays over the half's 512 threads
+            const float sx = a.sx;
+            auto put = [&](int ray, int col, float v) {
+                _Float16 hi, lo;
+                split_h(fminf(fmaxf(v * sx, -H_MAX), H_MAX), hi, lo);
+                S[0][ray][col] = hi; S[1][ray][col] = lo;
+            };
+            const int ray = th % TR;
+            const int64_t gr = row0 + ray;
+            const bool ok = gr < N;
+            float src[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                src[c] = ok ? a.ray_o[3 * gr + c] : 0.0f;
+                src[3 + c] = ok ? a.ray_d[3 * gr + c] : 0.0f;
+                src[6 + c] = ok ? a.ray_c[3 * gr + c] : 0.0f;
+            }
+            for (int item = th / TR; item < 94; item += 512 / TR) {
+                if (item < 66) {
+                    int blk = item < 24 ? 0 : (item < 48 ? 1 : 2);
+                    int b = item - 24 * blk;
+                    int F = blk == 2 ? 6 : 8;
+                    int j = b / F, k = b - j * F;
+                    const float c0 = blk == 0 ? src[0] : (blk == 1 ? src[3] : src[6]);
+                    const float c1 = blk == 0 ? src[1] : (blk == 1 ? src[4] : src[7]);
+                    const float c2 = blk == 0 ? src[2] : (blk == 1 ? src[5] : src[8]);
+                    float arg = (j == 0 ? c0 : (j == 1 ? c1 : c2)) * (float)(1 << k);
+                    float sv, cv;
+                    sincosf(arg, &sv, &cv);
+                    int col = 9 + 48 * blk + b;
+                    put(ray, col, sv);
+                    put(ray, col + 3 * F, cv);
+                } else if (item < 75) {
+                    const int ci = item - 66;
+                    float rv = src[0];
+#pragma unroll
+                    for (int u = 1; u < 9; ++u) rv = (ci == u) ? src[u] : rv;
+                    put(ray, ci, rv);
+                } else {
+                    put(ray, 141 + (item - 75), 0.0f);
+                }
+            }
+            }
+            __syncthreads();
+            zero(acc); zero(acc3);
+            if (on) phase(integral_constant<int, KX>{}, integral_constant<int, 2>{}, yes_t{}, no_t{}, acc, a.W1, acc3, a.W3x);
+            __syncthreads();
+            if (on) write_planes(acc, a.b1, a.inv1, a.s1);
+            __syncthreads();
+            zero(acc);
+            if (on) phase(integral_constant<int, KH>{}, integral_constant<int, 3>{}, no_t{}, no_t{}, acc, a.W2, acc, a.W2);
+            __syncthreads();
+            if (on) write_planes(acc, a.b2, a.inv2, a.s2);
+            __syncthreads();
+            if (on) phase(integral_constant<int, KH>{}, integral_constant<int, 3>{}, no_t{}, no_t{}, acc3, a.W3h, acc3, a.W3h);
+            __syncthreads();
+            if (on) write_planes(acc3, a.b3, a.inv3, a.s3);
+            __syncthreads();
+        }
+        for (int tb = tb0; tb < tb1; ++tb) {
+            zero(acc);
+            if (on) phase(integral_constant<int, KH>{}, integral_constant<int, 4>{}, no_t{}, yes_t{}, acc,
+                          a.Qf + (size_t)tb * (KH * 2 * 8 * 64), acc, a.Qf);
+            __syncthreads();
+            if (on) {
+                // logits epilogue of k5_trunk_h: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 32 wave + lr
+                const int tok = tb * 256 + 32 * wave + lr;
+                const bool tok_ok = tok < a.M;
+                const float rc = tok_ok ? a.rowc[(size_t)tok * a.rowc_ld] : 0.0f;
+                const float qs = a.qscale[tok];
+                float vmax = -INFINITY;
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t ray = row0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float num = fmaf(acc[0][rg][r], qs, rc);
+                        const float q1 = num * inv_div;
+                        const float v = fmaf(fmaf(-q1, divisor, num), inv_div, q1);
+                        acc[0][rg][r] = v;
+                        vmax = fmaxf(vmax, ray < N ? v : -INFINITY);
+                    }
+                vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+                float ssum = 0.0f;
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t ray0 = row0 + 32 * rg + 8 * q + 4 * lh;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ray0 + i < N) ssum += __expf(acc[0][rg][4 * q + i] - vmax);
+                        if (tok_ok) {
+                            float* dst = a.logits + (size_t)tok * N + ray0;
+                            if (ray0 + 3 < N) {
+                                f4uh o4 = {acc[0][rg][4 * q], acc[0][rg][4 * q + 1], acc[0][rg][4 * q + 2], acc[0][rg][4 * q + 3]};
+                                *reinterpret_cast<f4uh*>(dst) = o4;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (ray0 + i < N) dst[i] = acc[0][rg][4 * q + i];
+                            }
+                        }
+                    }
+                ssum += __shfl_xor(ssum, 32, 64);
+                if (lh == 0) a.part[(size_t)tile * a.Mpad + tok] = make_float2(vmax, ssum);
+            }
+            __syncthreads();
+        }
+    };
+    // half B runs one stage behind half A: one barrier ahead of its program, half A one barrier after its own
+    if (half == 0) { program(tile_on); __syncthreads(); }
+    else { __syncthreads(); program(tile_on); }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 // variant: 0 -> 8 waves x 32 features, 64 rays;  1 -> 4 waves x 64 features, 64 rays (two workgroups per CU);
-//          2 -> 8 waves x 32 features, 128 rays (half the weight stream per ray)
+//          2 -> 8 waves x 32 features, 128 rays (half the weight stream per ray);
+//          3 -> the logits launches as k5_trunk_h2: sixteen waves, two 64-ray tiles one stage apart (the work split of 0 per tile)
 int trunk_h_rays_per_wg(int variant) { return variant == 2 ? 128 : 64; }
 
 // workgroups per ray tile for the token blocks of a logits launch: enough that tiles x ray sets x split fills the chip's
@@ -506,6 +755,13 @@ static TrunkHArgs base_args(const IdNetDev& n, const float* o, const float* d, c
 
 template <int MODE>
 static hipError_t launch_variant(int variant, dim3 grid, const TrunkHArgs& a, hipStream_t s) {
+    if constexpr (MODE == 1 || MODE == 3) {
+        if (variant == 3) {          // two tiles per workgroup, one stage apart (the cache build and the feature output keep the 8-wave form)
+            const int64_t n_tiles = grid.x;
+            hipLaunchKernelGGL((k5_trunk_h2<MODE>), dim3((unsigned)((n_tiles + 1) / 2), grid.y, grid.z), dim3(1024), 0, s, a, n_tiles);
+            return hipGetLastError();
+        }
+    }
     if (variant == 1) hipLaunchKernelGGL((k5_trunk_h<MODE, 2, 2>), grid, dim3(256), 0, s, a);
     else if (variant == 2) hipLaunchKernelGGL((k5_trunk_h<MODE, 1, 4>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k5_trunk_h<MODE, 1, 2>), grid, dim3(512), 0, s, a);

@@ -408,3 +408,28 @@ def test_near_tie_stress(golden, dev, mode):
     idx, _ = H.topk(score, 100)
     score_ref = oid.test_image(w, tok, o2, d2, c2, 100)[2]
     util.assert_topk_matches(idx.cpu(), score_ref, 100, rel_tie=2e-5)
+
+
+def test_two_tile_trunk_form_is_bit_identical(dev):
+    """iff_idnet_desc.trunk_variant = 4 (k5_trunk_h2: sixteen waves, two 64-ray tiles one stage apart -- the matrix-core and the
+    vector stages of a CU side by side) against the default eight-wave form: logits, softmax row statistics and the cached-encoder
+    path are the same bits (an odd tile count and a ragged last tile included)."""
+    from iffnerf_amd import hip_identify as H
+    w = synthetic.make_id_weights(seed=99)
+    g = torch.Generator().manual_seed(4)
+    for B, N, M in ((3, 64 * 5 + 17, 256), (1, 64 * 4, 137), (2, 1000, 300)):
+        o = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1).to(dev)
+        c = torch.rand(B, N, 3, generator=g).to(dev)
+        tok = torch.stack([synthetic.make_tokens(M, 384, seed=20 + q) for q in range(B)]).to(dev)
+        outs = []
+        for var in (1, 4):
+            net = H.IdNetHandle(w, dev, gemm_mode=H.GEMM_F16X2, trunk_variant=var)
+            qf = net.q_fold(tok.reshape(B * M, -1))
+            fused = net.ray_logits_folded_batched(qf, o.reshape(-1, 3), d.reshape(-1, 3), c.reshape(-1, 3), B)
+            cached = net.logits_from_cache(qf[:M], net.build_ray_cache(o[0], d[0], c[0]), N)
+            outs.append((fused, cached))
+            for x, y in zip(cached, net.ray_logits_folded(qf[:M], o[0], d[0], c[0])):
+                assert torch.equal(x, y)
+        for x, y in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
+            assert torch.equal(x, y), (B, N, M)
