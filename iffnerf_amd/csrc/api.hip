@@ -362,7 +362,7 @@ extern "C" size_t iff_surface_sample_workspace(int64_t P) { return P > 0 ? sampl
 extern "C" int iff_surface_sample_residency(const iff_field* f, int32_t B, int64_t P, int32_t* wgs_per_run, int32_t* device_capacity) {
     IFF_REQUIRE(f && wgs_per_run && device_capacity && B >= 1, "iff_surface_sample_residency: bad argument");
     int w = 0, c = 0;
-    IFF_HIP(sampler_residency(P, f->n_cus, sampler_lpc(f->dev, B), &w, &c));
+    IFF_HIP(sampler_residency(P, f->n_cus, sampler_lpc(f->dev, B), B, &w, &c));
     *wgs_per_run = w; *device_capacity = c;
     return 0;
 }

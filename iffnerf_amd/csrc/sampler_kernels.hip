@@ -378,7 +378,12 @@ int sampler_lpc(const FieldDev& f, int B) {
     return B >= 8 ? 1 : 4;
 }
 
-hipError_t sampler_residency(int64_t P, int n_cus, int lpc, int* wgs_per_query, int* capacity) {
+// B = runs per launch.  A launch takes at most a quarter of the device's sampler slots when it can: a caller that keeps steps in
+// flight on several streams (bench.py: four) then has room for all of them -- the sampler is latency-bound (parked at grid
+// barriers 80 % of its life), so fewer, longer-looping workgroups per run cost little, while a launch that fills the device alone
+// (640^3 model: 47 KB of LDS per workgroup, 3 per CU) clamps the whole pipeline to two steps in flight.  Results do not depend on
+// the workgroup count (every candidate has its own counter-based stream; picks go through order-independent atomics).
+hipError_t sampler_residency(int64_t P, int n_cus, int lpc, int B, int* wgs_per_query, int* capacity) {
     if (P < 1 || P > SAMPLER_MAX_POINTS) return hipErrorInvalidValue;
     const size_t lds = (size_t)P * sizeof(int) * (P <= SAMPLER_CACHE_POINTS ? 5 : 1);
     if (lds > 48 * 1024) {
@@ -390,8 +395,11 @@ hipError_t sampler_residency(int64_t P, int n_cus, int lpc, int* wgs_per_query, 
     if (e != hipSuccess) return e;
     if (per_cu < 1) return hipErrorInvalidValue;
     int64_t want = (5 * P * lpc + 255) / 256;
-    *wgs_per_query = (int)(want < 1 ? 1 : (want > n_cus ? n_cus : want));
-    *capacity = per_cu * n_cus;
+    want = want < 1 ? 1 : (want > n_cus ? n_cus : want);
+    const int64_t cap = (int64_t)per_cu * n_cus;
+    if (B >= 1 && want * B * 4 > cap) want = cap / (4 * (int64_t)B) >= 1 ? cap / (4 * (int64_t)B) : (cap / B >= 1 ? (want < cap / B ? want : cap / B) : 1);
+    *wgs_per_query = (int)want;
+    *capacity = (int)cap;
     return hipSuccess;
 }
 
@@ -406,7 +414,7 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
     // one group of workgroups per query; all groups must be co-resident (in-kernel barriers)
     int wgs = 0, capacity = 0;
     const int lpc = sampler_lpc(f, B);
-    hipError_t e = sampler_residency(P, n_cus, lpc, &wgs, &capacity);
+    hipError_t e = sampler_residency(P, n_cus, lpc, B, &wgs, &capacity);
     if (e != hipSuccess) return e;
     if ((int64_t)wgs * B > capacity) {
         wgs = capacity / B;
