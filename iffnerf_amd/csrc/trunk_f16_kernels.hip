@@ -35,6 +35,24 @@ __device__ inline void split_h(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// Four accumulator values -> the hi/lo halves of min(relu(acc inv + bias) s, H_MAX), with `is` = inv s and `bs` = bias s (s is a
+// power of two: relu(fma(acc, inv, bias)) s == relu(fma(acc, inv s, bias s)) bit for bit in the normal range).  Packed-pair
+// instructions throughout: v_pk_fma_f32, v_med3_f32 (relu and the clamp in one), v_cvt_pk_f16_f32, v_pk_add_f32 -- 4 vector
+// instructions per value where the scalar formulation compiles to 7.
+__device__ __forceinline__ void relu_split_quad(float a0, float a1, float a2, float a3, f32x2 is, f32x2 bs01, f32x2 bs23, f16x4& hi, f16x4& lo) {
+    f32x2 t01 = __builtin_elementwise_fma(f32x2{a0, a1}, is, bs01);
+    f32x2 t23 = __builtin_elementwise_fma(f32x2{a2, a3}, is, bs23);
+    t01.x = __builtin_amdgcn_fmed3f(t01.x, 0.0f, H_MAX); t01.y = __builtin_amdgcn_fmed3f(t01.y, 0.0f, H_MAX);
+    t23.x = __builtin_amdgcn_fmed3f(t23.x, 0.0f, H_MAX); t23.y = __builtin_amdgcn_fmed3f(t23.y, 0.0f, H_MAX);
+    const f16x2 h01 = __builtin_convertvector(t01, f16x2), h23 = __builtin_convertvector(t23, f16x2);
+    const f32x2 r01 = t01 - __builtin_convertvector(h01, f32x2), r23 = t23 - __builtin_convertvector(h23, f32x2);
+    const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+    hi = f16x4{h01.x, h01.y, h23.x, h23.y};
+    lo = f16x4{l01.x, l01.y, l23.x, l23.y};
+}
+
 // ------------------------------------------------------------------------------------------------ weight prep
 // nn.Linear weight W [256][ld] (columns col0 .. col0+ncols-1), times `scale` (a power of two) -> fragment order
 // Wf[ks][plane][nb][lane][8] halves, plane 0 = hi, 1 = lo: lane l of the (nb, ks) fragment holds
@@ -111,6 +129,62 @@ __global__ void __launch_bounds__(256) k_qf_frag_h(const float* __restrict__ qf,
     }
 }
 
+// The encoder input of one 64-ray tile, by eight waves (ray_preprocessor.py:30-37, tensorBase.py:14-20):
+// x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141 columns, zero-padded to 160; rows beyond N are zero) as hi/lo planes in LDS.
+// lane = ray; wave w < 8 = source component w of [o.xyz, d.xyz, rgb.xy]: its raw column and its F frequencies, unrolled -- no
+// per-item decoding, the column arithmetic is scalar; rgb.z (the 66 = 8 x 8 + 2 frequency pairs do not divide by eight) goes
+// three frequencies each to waves 6 and 7, whose own components have F = 6: every wave evaluates 8 or 9 sincosf (one argument
+// reduction serves the sin and the cos column).  Values are those of the per-item loop this replaces (same arguments, same sincosf).
+// Measured with the stage stamps (-DTRUNK_STAMPS): the encoder input was 20 % of a tile's time in the item loop.
+__device__ __forceinline__ void encode_tile64(_Float16 (*S)[64][HSLD], const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                              const float* __restrict__ ray_c, int64_t row0, int64_t N, float sx, int wave, int lane) {
+    auto put = [&](int col, float v) {
+        _Float16 hi, lo;
+        split_h(__builtin_amdgcn_fmed3f(v * sx, -H_MAX, H_MAX), hi, lo);
+        S[0][lane][col] = hi; S[1][lane][col] = lo;
+    };
+    const int64_t gr = row0 + lane;
+    const bool ok = gr < N;
+    const int blk = wave < 3 ? 0 : (wave < 6 ? 1 : 2), j = wave - 3 * blk;          // scalar
+    const float* __restrict__ base = blk == 0 ? ray_o : (blk == 1 ? ray_d : ray_c);
+    const float v = ok ? base[3 * gr + j] : 0.0f;
+    const float vz = (ok && wave >= 6) ? ray_c[3 * gr + 2] : 0.0f;
+    put(wave, v);
+    if (wave == 7) put(8, vz);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+        if (wave + 8 * pc < 19) {
+            S[0][lane][141 + wave + 8 * pc] = (_Float16)0.0f; S[1][lane][141 + wave + 8 * pc] = (_Float16)0.0f;
+        }
+    if (wave < 6) {
+        const int col0 = 9 + 48 * blk + 8 * j;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float sv, cv;
+            sincosf(v * (float)(1 << k), &sv, &cv);
+            put(col0 + k, sv);
+            put(col0 + 24 + k, cv);
+        }
+    } else {
+        const int col0 = 105 + 6 * j;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            float sv, cv;
+            sincosf(v * (float)(1 << k), &sv, &cv);
+            put(col0 + k, sv);
+            put(col0 + 18 + k, cv);
+        }
+        const int k0 = 3 * (wave - 6);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            float sv, cv;
+            sincosf(vz * (float)(1 << (k0 + kk)), &sv, &cv);
+            put(105 + 12 + k0 + kk, sv);
+            put(105 + 18 + 12 + k0 + kk, cv);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ the fused kernel
 struct TrunkHArgs {
     const float* ray_o; const float* ray_d; const float* ray_c; int64_t N;
@@ -173,6 +247,79 @@ __device__ inline void trunk_mfma_ht(f32x16 (&acc)[FG][RG], const WFragH<FG>& w,
 
 struct __attribute__((packed, aligned(4))) f4uh { float x, y, z, w; };     // 16-byte store at 4-byte alignment
 
+// The epilogue of one logits tile of one wave: acc[rg][r] (rows = rays row0 + 32 rg + (r & 3) + 8 (r >> 2) + 4 lh, this lane's
+// column = one token) -> logits (acc qs + rc) / divisor into `dst_row` (= logits + token N), and the tile's softmax partial
+// (max, sum exp) of that token over the rays < N.  (acc qs + rc) / divisor is correctly rounded (qs is a power of two, so acc qs is
+// exact): quotient estimate by the reciprocal, exact remainder, one correction.  Tiles that lie wholly inside N (all but the last)
+// take the packed form: v_pk_fma_f32 / v_pk_mul_f32 on register pairs, no per-ray bound checks; the values, the maximum and the
+// ORDER of the sum are those of the masked form, so a row's statistics do not depend on which form served a tile.
+template <int RG>
+__device__ __forceinline__ float2 logits_tile_epilogue(f32x16 (&acc)[RG], float qs, float rc, float divisor, float inv_div, bool tok_ok,
+                                              float* __restrict__ dst_row, int64_t row0, int64_t N, int lh) {
+    float vmax = -INFINITY, ssum = 0.0f;
+    if (row0 + 32 * RG <= N) {                                  // wave-uniform
+        const f32x2 qs2 = {qs, qs}, rc2 = {rc, rc}, dv2 = {divisor, divisor}, id2 = {inv_div, inv_div};
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 num = __builtin_elementwise_fma(f32x2{acc[rg][r], acc[rg][r + 1]}, qs2, rc2);
+                const f32x2 q1 = num * id2;
+                const f32x2 v = __builtin_elementwise_fma(__builtin_elementwise_fma(-q1, dv2, num), id2, q1);
+                acc[rg][r] = v.x; acc[rg][r + 1] = v.y;
+                vmax = fmaxf(fmaxf(vmax, v.x), v.y);             // v_max3_f32
+            }
+        vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+        const f32x2 vm2 = {vmax, vmax};
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 d01 = f32x2{acc[rg][4 * q], acc[rg][4 * q + 1]} - vm2, d23 = f32x2{acc[rg][4 * q + 2], acc[rg][4 * q + 3]} - vm2;
+                ssum += __expf(d01.x); ssum += __expf(d01.y); ssum += __expf(d23.x); ssum += __expf(d23.y);
+                if (tok_ok) {
+                    f4uh o4 = {acc[rg][4 * q], acc[rg][4 * q + 1], acc[rg][4 * q + 2], acc[rg][4 * q + 3]};
+                    *reinterpret_cast<f4uh*>(dst_row + row0 + 32 * rg + 8 * q + 4 * lh) = o4;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t ray = row0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float num = fmaf(acc[rg][r], qs, rc);
+                const float q1 = num * inv_div;
+                const float v = fmaf(fmaf(-q1, divisor, num), inv_div, q1);
+                acc[rg][r] = v;
+                vmax = fmaxf(vmax, ray < N ? v : -INFINITY);
+            }
+        vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t ray0 = row0 + 32 * rg + 8 * q + 4 * lh;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ray0 + i < N) ssum += __expf(acc[rg][4 * q + i] - vmax);   // denominator only: <= 4e-6 relative, common to the whole token row
+                if (tok_ok) {
+                    float* dst = dst_row + ray0;
+                    if (ray0 + 3 < N) {
+                        f4uh o4 = {acc[rg][4 * q], acc[rg][4 * q + 1], acc[rg][4 * q + 2], acc[rg][4 * q + 3]};
+                        *reinterpret_cast<f4uh*>(dst) = o4;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ray0 + i < N) dst[i] = acc[rg][4 * q + i];
+                    }
+                }
+            }
+    }
+    ssum += __shfl_xor(ssum, 32, 64);
+    return make_float2(vmax, ssum);
+}
+
 // FG = 32-feature groups per wave (8 / FG waves per workgroup), RG = 32-ray groups per workgroup (TR = 32 RG rays).
 // MODE 0: rays -> h3 [N][256] fp32 (iff_ray_trunk).  MODE 1: rays -> logits + softmax partials (the fused per-query launch).
 // MODE 2: rays -> the h3 hi/lo planes in HBM (iff_ray_cache_build: the encoder once per resident ray set).
@@ -186,6 +333,15 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
     const int lr = lane & 31, lh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * TR;
     const int64_t N = a.N;
+#ifdef TRUNK_STAMPS
+    // diagnostic build only: wave w stores the low word of s_memtime at stage boundary k over logits[32 w + k][row0] (of query 0's
+    // first token block) once the tile is done -- scripts/trunk_stamps.py reads the per-stage timeline of every tile out of them
+    uint32_t stamp[16];
+#define TSTAMP(k) stamp[k] = (uint32_t)__builtin_amdgcn_s_memtime()
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+    TSTAMP(0);
     {   // blockIdx.y = query of a batch: its own rays [N,3], folded query planes, logits [M,N] and partials
         const size_t qb = blockIdx.y;
         a.ray_o += qb * N * 3; a.ray_d += qb * N * 3; a.ray_c += qb * N * 3;
@@ -217,7 +373,9 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
         // x = [o, d, rgb, PE(o,8), PE(d,8), PE(rgb,6)] (141 columns, zero-padded to 160; rows beyond N are zero).
         // Work items per ray: 66 (source component, frequency) pairs -- one sincosf serves the sin and the cos column --
         // plus the 9 raw values and the 19 pad columns: 94 items x TR rays over NT threads.
-        {
+        if constexpr (NT == 512 && TR == 64) {
+            encode_tile64(S, a.ray_o, a.ray_d, a.ray_c, row0, N, a.sx, __builtin_amdgcn_readfirstlane(wave), lane);
+        } else {
             const float sx = a.sx;
             auto put = [&](int ray, int col, float v) {
                 _Float16 hi, lo;
@@ -263,6 +421,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
             }
         }
         __syncthreads();
+        TSTAMP(1);
     }
 
     auto load_act = [&](f16x8 (&v)[RG][2], int ks) {
@@ -279,17 +438,11 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
             for (int q = 0; q < 4; ++q) {
                 const int f0 = 32 * FG * wave + 32 * fg + 8 * q + 4 * lh;     // features f0..f0+3 <- registers 4q..4q+3
                 const float4 bv = *reinterpret_cast<const float4*>(bias + f0);
-                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                const f32x2 is = {inv * s, inv * s}, bs01 = {bv.x * s, bv.y * s}, bs23 = {bv.z * s, bv.w * s};
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg) {
                     f16x4 p0, p1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = fmaxf(fmaf(acc[fg][rg][4 * q + i], inv, bb[i]), 0.0f);
-                        _Float16 hi, lo;
-                        split_h(fminf(v * s, H_MAX), hi, lo);
-                        p0[i] = hi; p1[i] = lo;
-                    }
+                    relu_split_quad(acc[fg][rg][4 * q], acc[fg][rg][4 * q + 1], acc[fg][rg][4 * q + 2], acc[fg][rg][4 * q + 3], is, bs01, bs23, p0, p1);
                     *reinterpret_cast<f16x4*>(&S[0][32 * rg + lr][f0]) = p0;
                     *reinterpret_cast<f16x4*>(&S[1][32 * rg + lr][f0]) = p1;
                 }
@@ -325,19 +478,28 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
                 if (DUAL) trunk_load_w_h(wb[i], WB, i, wave, lane);
             }
         }
+#ifndef TRUNK_EXP
+#define TRUNK_EXP 0
+#endif
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            if (ks + DEPTH - 1 < NK) {
+            if (ks + DEPTH - 1 < NK && !((TRUNK_EXP & 1) && ks + DEPTH - 1 >= DEPTH)) {
                 trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wave, lane);
                 if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wave, lane);
             }
             if (AB == 2 && ks + 1 < NK) load_act(act[(ks + 1) & 1], ks + 1);
             __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them)
+            if (!(TRUNK_EXP & 4)) {
             if (SWAP) trunk_mfma_ht<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
             else trunk_mfma_h<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
             if (DUAL) trunk_mfma_h<FG, RG>(accB, wb[ks % DEPTH], act[ks & (AB - 1)]);
+            } else {
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) { accA[0][rg][ks & 15] += (float)wa[ks % DEPTH].p[0][0][0] + (float)wa[ks % DEPTH].p[0][1][0] + (float)act[ks & (AB - 1)][rg][0][0] + (float)act[ks & (AB - 1)][rg][1][0]; }
+                if (DUAL) accB[0][0][ks & 15] += (float)wb[ks % DEPTH].p[0][0][0] + (float)wb[ks % DEPTH].p[0][1][0];
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (AB == 1 && ks + 1 < NK) load_act(act[0], ks + 1);
+            if (AB == 1 && ks + 1 < NK && !((TRUNK_EXP & 2) && ks >= 1)) load_act(act[0], ks + 1);
         }
     };
     using std::integral_constant;
@@ -352,20 +514,30 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
     if (MODE != 3) {
         // layer 1 and the x-part of layer 3, one pass over x
         phase(integral_constant<int, KX>{}, integral_constant<int, DEPTH_DUAL>{}, yes_t{}, no_t{}, acc, a.W1, acc3, a.W3x);
+        TSTAMP(2);
         __syncthreads();                      // every wave has finished reading x
+        TSTAMP(3);
         write_planes(acc, a.b1, a.inv1, a.s1);
+        TSTAMP(4);
         __syncthreads();
+        TSTAMP(5);
 
         // layer 2
         zero(acc);
         phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc, a.W2, acc, a.W2);
+        TSTAMP(6);
         __syncthreads();
+        TSTAMP(7);
         write_planes(acc, a.b2, a.inv2, a.s2);
+        TSTAMP(8);
         __syncthreads();
+        TSTAMP(9);
 
         // layer 3, h-part, on top of the x-part
         phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_ONE>{}, no_t{}, no_t{}, acc3, a.W3h, acc3, a.W3h);
+        TSTAMP(10);
         __syncthreads();                      // every wave has finished reading h2
+        TSTAMP(11);
     }
     if (MODE == 2) {
         // the cache: h3 planes from LDS to HBM, whole 512-B rows per 32 lanes
@@ -381,7 +553,9 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
     if (LOGITS) {
         if (MODE == 1) {
             write_planes(acc3, a.b3, a.inv3, a.s3);           // h3 planes
+        TSTAMP(12);
             __syncthreads();
+        TSTAMP(13);
         }
         // gridDim.z workgroups share a ray tile's token blocks (many query images against one ray set: without the split a
         // 16 011-ray set is 251 workgroups -- half the chip's workgroup slots -- however many images it serves)
@@ -393,6 +567,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
             zero(acc);
             phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_LOGITS>{}, no_t{}, yes_t{}, acc,
                   a.Qf + (size_t)tb * (KH * 2 * 8 * 64), acc, a.Qf);
+            TSTAMP(14);
             // tile: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 32 FG wave + 32 tg + lr
 #pragma unroll
             for (int tg = 0; tg < FG; ++tg) {
@@ -400,46 +575,15 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
                 const bool tok_ok = tok < a.M;
                 const float rc = tok_ok ? a.rowc[(size_t)tok * a.rowc_ld] : 0.0f;
                 const float qs = a.qscale[tok];
-                float vmax = -INFINITY;
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t ray = row0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        // (acc qs + rc) / divisor, correctly rounded (qs is a power of two: acc qs is exact): quotient
-                        // estimate by the reciprocal, exact remainder, one correction
-                        const float num = fmaf(acc[tg][rg][r], qs, rc);
-                        const float q1 = num * inv_div;
-                        const float v = fmaf(fmaf(-q1, divisor, num), inv_div, q1);
-                        acc[tg][rg][r] = v;
-                        vmax = fmaxf(vmax, ray < N ? v : -INFINITY);
-                    }
-                vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
-                float ssum = 0.0f;
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int64_t ray0 = row0 + 32 * rg + 8 * q + 4 * lh;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (ray0 + i < N) ssum += __expf(acc[tg][rg][4 * q + i] - vmax);   // denominator only: <= 4e-6 relative, common to the whole token row
-                        if (tok_ok) {
-                            float* dst = a.logits + (size_t)tok * N + ray0;
-                            if (ray0 + 3 < N) {
-                                f4uh o4 = {acc[tg][rg][4 * q], acc[tg][rg][4 * q + 1], acc[tg][rg][4 * q + 2], acc[tg][rg][4 * q + 3]};
-                                *reinterpret_cast<f4uh*>(dst) = o4;
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (ray0 + i < N) dst[i] = acc[tg][rg][4 * q + i];
-                            }
-                        }
-                    }
-                ssum += __shfl_xor(ssum, 32, 64);
-                if (lh == 0) a.part[(size_t)blockIdx.x * a.Mpad + tok] = make_float2(vmax, ssum);
+                const float2 st = logits_tile_epilogue<RG>(acc[tg], qs, rc, divisor, inv_div, tok_ok, a.logits + (size_t)tok * N, row0, N, lh);
+                if (lh == 0) a.part[(size_t)blockIdx.x * a.Mpad + tok] = st;
             }
         }
+#ifdef TRUNK_STAMPS
+        TSTAMP(15);
+        if (MODE == 1 && lane == 0 && row0 + TR <= N)
+            for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(a.logits)[(size_t)(32 * wave + k) * N + row0] = stamp[k];
+#endif
         return;
     }
     // h3 = relu(acc3 inv3 + b3).  A lane holds 4 consecutive features of one ray per register quad; the tile is transposed
@@ -532,17 +676,11 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
         for (int q = 0; q < 4; ++q) {
             const int f0 = 32 * wave + 8 * q + 4 * lh;
             const float4 bv = *reinterpret_cast<const float4*>(bias + f0);
-            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            const f32x2 is = {inv * s, inv * s}, bs01 = {bv.x * s, bv.y * s}, bs23 = {bv.z * s, bv.w * s};
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
                 f16x4 p0, p1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = fmaxf(fmaf(ac[0][rg][4 * q + i], inv, bb[i]), 0.0f);
-                    _Float16 hi, lo;
-                    split_h(fminf(v * s, H_MAX), hi, lo);
-                    p0[i] = hi; p1[i] = lo;
-                }
+                relu_split_quad(ac[0][rg][4 * q], ac[0][rg][4 * q + 1], ac[0][rg][4 * q + 2], ac[0][rg][4 * q + 3], is, bs01, bs23, p0, p1);
                 *reinterpret_cast<f16x4*>(&S[0][32 * rg + lr][f0]) = p0;
                 *reinterpret_cast<f16x4*>(&S[1][32 * rg + lr][f0]) = p1;
             }
@@ -565,7 +703,7 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            if (ks + DEPTH - 1 < NK) {
+            if (ks + DEPTH - 1 < NK && !((TRUNK_EXP & 1) && ks + DEPTH - 1 >= DEPTH)) {
                 trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wave, lane);
                 if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wave, lane);
             }
@@ -574,7 +712,7 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
             else trunk_mfma_h<FG, RG>(accA, wa[ks % DEPTH], act);
             if (DUAL) trunk_mfma_h<FG, RG>(accB, wb[ks % DEPTH], act);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NK) load_act(act, ks + 1);
+            if (ks + 1 < NK && !((TRUNK_EXP & 2) && ks >= 1)) load_act(act, ks + 1);
         }
     };
     using std::integral_constant;
@@ -602,50 +740,7 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
             }
             __syncthreads();
         } else {
-            if (on) {
-            // encoder input (see k5_trunk_h): 94 work items per ray, 64 rays over the half's 512 threads
-            const float sx = a.sx;
-            auto put = [&](int ray, int col, float v) {
-                _Float16 hi, lo;
-                split_h(fminf(fmaxf(v * sx, -H_MAX), H_MAX), hi, lo);
-                S[0][ray][col] = hi; S[1][ray][col] = lo;
-            };
-            const int ray = th % TR;
-            const int64_t gr = row0 + ray;
-            const bool ok = gr < N;
-            float src[9];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                src[c] = ok ? a.ray_o[3 * gr + c] : 0.0f;
-                src[3 + c] = ok ? a.ray_d[3 * gr + c] : 0.0f;
-                src[6 + c] = ok ? a.ray_c[3 * gr + c] : 0.0f;
-            }
-            for (int item = th / TR; item < 94; item += 512 / TR) {
-                if (item < 66) {
-                    int blk = item < 24 ? 0 : (item < 48 ? 1 : 2);
-                    int b = item - 24 * blk;
-                    int F = blk == 2 ? 6 : 8;
-                    int j = b / F, k = b - j * F;
-                    const float c0 = blk == 0 ? src[0] : (blk == 1 ? src[3] : src[6]);
-                    const float c1 = blk == 0 ? src[1] : (blk == 1 ? src[4] : src[7]);
-                    const float c2 = blk == 0 ? src[2] : (blk == 1 ? src[5] : src[8]);
-                    float arg = (j == 0 ? c0 : (j == 1 ? c1 : c2)) * (float)(1 << k);
-                    float sv, cv;
-                    sincosf(arg, &sv, &cv);
-                    int col = 9 + 48 * blk + b;
-                    put(ray, col, sv);
-                    put(ray, col + 3 * F, cv);
-                } else if (item < 75) {
-                    const int ci = item - 66;
-                    float rv = src[0];
-#pragma unroll
-                    for (int u = 1; u < 9; ++u) rv = (ci == u) ? src[u] : rv;
-                    put(ray, ci, rv);
-                } else {
-                    put(ray, 141 + (item - 75), 0.0f);
-                }
-            }
-            }
+            if (on) encode_tile64(S, a.ray_o, a.ray_d, a.ray_c, row0, N, a.sx, wave, lane);     // the encoder input (see k5_trunk_h)
             __syncthreads();
             zero(acc); zero(acc3);
             if (on) phase(integral_constant<int, KX>{}, integral_constant<int, 2>{}, yes_t{}, no_t{}, acc, a.W1, acc3, a.W3x);
@@ -673,42 +768,8 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
                 const bool tok_ok = tok < a.M;
                 const float rc = tok_ok ? a.rowc[(size_t)tok * a.rowc_ld] : 0.0f;
                 const float qs = a.qscale[tok];
-                float vmax = -INFINITY;
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t ray = row0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float num = fmaf(acc[0][rg][r], qs, rc);
-                        const float q1 = num * inv_div;
-                        const float v = fmaf(fmaf(-q1, divisor, num), inv_div, q1);
-                        acc[0][rg][r] = v;
-                        vmax = fmaxf(vmax, ray < N ? v : -INFINITY);
-                    }
-                vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
-                float ssum = 0.0f;
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int64_t ray0 = row0 + 32 * rg + 8 * q + 4 * lh;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (ray0 + i < N) ssum += __expf(acc[0][rg][4 * q + i] - vmax);
-                        if (tok_ok) {
-                            float* dst = a.logits + (size_t)tok * N + ray0;
-                            if (ray0 + 3 < N) {
-                                f4uh o4 = {acc[0][rg][4 * q], acc[0][rg][4 * q + 1], acc[0][rg][4 * q + 2], acc[0][rg][4 * q + 3]};
-                                *reinterpret_cast<f4uh*>(dst) = o4;
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (ray0 + i < N) dst[i] = acc[0][rg][4 * q + i];
-                            }
-                        }
-                    }
-                ssum += __shfl_xor(ssum, 32, 64);
-                if (lh == 0) a.part[(size_t)tile * a.Mpad + tok] = make_float2(vmax, ssum);
+                const float2 st = logits_tile_epilogue<RG>(acc[0], qs, rc, divisor, inv_div, tok_ok, a.logits + (size_t)tok * N, row0, N, lh);
+                if (lh == 0) a.part[(size_t)tile * a.Mpad + tok] = st;
             }
             __syncthreads();
         }
