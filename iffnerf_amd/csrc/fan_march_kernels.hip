@@ -50,6 +50,11 @@ typedef uint32_t u32q __attribute__((ext_vector_type(4)));
 #else
 #define STAMP(k) do { } while (0)
 #endif
+#if defined(FAN_STAMPS) && FAN_STAMPS == 2
+#define ESTAMP(k) STAMP(k)
+#else
+#define ESTAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ f32q splat(float v) { return (f32q)(v); }
 // cross-lane moves as DPP modifiers of vector-ALU instructions (__shfl_xor compiles to ds_bpermute_b32: a round trip through
@@ -153,7 +158,125 @@ __device__ __forceinline__ RecView read_rec(const uint32_t* rec) {
     return unpack_rec(*reinterpret_cast<const u32q*>(rec), *reinterpret_cast<const u32q*>(rec + 4));
 }
 
-// MODE 2: the whole march of a tile (density, compositing, appearance, basis_mat).  MODE 1: appearance + basis_mat only, the
+// Ref.forward (models/ref.py:103-152, normals=None) for one ray by EIGHT lanes (`sub` = the lane's index in the group): the per-ray
+// part of the head after the two matrix products (bottleneck rows and the ten small-head rows, phase E of the fused kernel) --
+// activations, reflection, integrated directional encoding (ref_utils.py:82-112), the specular layer, sigmoid and sRGB.
+// `sb` = this ray's LDS row: [0, fc) the bottleneck outputs (bias added), [fc, fc + 10) scratch for the small heads; `F` = the ray's
+// feature row; `small` = the head up to bott_w (the four small heads), `tail` = the head from spec_w on (spec_w, spec_b, ide_mat),
+// both in LDS.
+// The arithmetic is ref_shade_group16's (iff_device.h), operation for operation: that kernel spreads the specular sum of a ray
+// over 16 lanes (lane l takes the encoding pairs l, l + 16 and the bottleneck features l + 16 t) and adds the lanes by butterfly
+// (xor 1, 2, 4, 8); here lane `sub` carries the partial sums l = sub and l = sub + 8, the butterfly runs over xor 1, 2, 4 on each
+// and the two results are added -- the xor-8 step -- so both forms return the same bits.  The three colour channels are
+// finished by sub = 0, 1, 2; the return value is this lane's channel (sub < 3).
+__device__ __forceinline__ float ref_head_oct(const float* small, const HeadOff& ho, int fc, float* sb, const float* F, const float* tail,
+                                             const float d[3], int sub) {
+    // the ten small-head rows (normal 0-2, tint 3-5, diffuse 6-8, roughness 9), rows sub and sub + 8 on this lane: the fmaf chain,
+    // bias add and activation of ref_shade_group16, computed once per ray and handed round the group through the ray's LDS row
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = sub + 8 * u;
+        if (row < 10) {
+            const int blk = row / 3, o = row - 3 * blk;                       // blk 0 normal, 1 tint, 2 diffuse, 3 roughness
+            const int w_off = blk == 0 ? ho.normal_w : (blk == 1 ? ho.tint_w : (blk == 2 ? ho.diffuse_w : ho.rough_w));
+            const int b_off = blk == 0 ? ho.normal_b : (blk == 1 ? ho.tint_b : (blk == 2 ? ho.diffuse_b : ho.rough_b));
+            const float* wr = small + w_off + o * 28;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < 28; k4 += 4) {
+                const f32q w4 = *reinterpret_cast<const f32q*>(wr + k4), f4 = *reinterpret_cast<const f32q*>(F + k4);
+                acc = fmaf(w4[0], f4[0], acc); acc = fmaf(w4[1], f4[1], acc); acc = fmaf(w4[2], f4[2], acc);
+                acc = fmaf(w4[3], k4 + 3 == 27 ? 0.0f : f4[3], acc);           // column 27 of the row is the shaded flag, not a feature
+            }
+            const float raw = acc + small[b_off + o];
+            const float x = raw + (blk == 2 ? -1.0986122886681098f : -1.0f);     // diffuse: - ln 3; roughness: - 1
+            float mine = raw;
+            if (blk == 3) mine = softplusf_(x);
+            else if (blk != 0) mine = sigmoidf_(blk == 1 ? raw : x);
+            sb[fc + row] = mine;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the eight lanes of a ray are lanes of one wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float nr[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) nr[o] = sb[fc + o];
+    const int ch = sub < 3 ? sub : 0;                            // this lane's colour channel (sub < 3; the others repeat channel 0 and drop it)
+    const float tint_c = sb[fc + 3 + ch], diff_c = sb[fc + 6 + ch];
+    const float rough = sb[fc + 9];
+    float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
+    float n[3] = {-(nr[0] / nn), -(nr[1] / nn), -(nr[2] / nn)};
+    float v[3] = {-d[0], -d[1], -d[2]};
+    float ndv = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
+    float r[3] = {2.0f * ndv * n[0] - v[0], 2.0f * ndv * n[1] - v[1], 2.0f * ndv * n[2] - v[2]};
+    float dot = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+    const int K = fc + 39, KL = ho.spec_ld;
+    const float* spec_w = tail;                                 // [3][KL]
+    const float* spec_b = tail + (ho.spec_b - ho.spec_w);
+    const float* ide_mat = tail + (ho.ide_mat - ho.spec_w);     // [9][19]
+    float part[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    float zp[9];
+    zp[0] = 1.0f;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) zp[k] = zp[k - 1] * r[2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int i = sub + 8 * u;                              // pairs sub, sub + 8, sub + 16: partial sums l = i & 15
+        if (i < 19) {
+            const int l = (i < 2) ? 1 : (i < 5) ? 2 : (i < 10) ? 4 : 8;
+            const int m = i - ((i < 2) ? 0 : (i < 5) ? 2 : (i < 10) ? 5 : 10);
+            float pr = 1.0f, pi = 0.0f;
+            for (int q = 0; q < m; ++q) {
+                float t = pr * r[0] - pi * r[1];
+                pi = pr * r[1] + pi * r[0];
+                pr = t;
+            }
+            float poly = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) poly = fmaf(zp[k], ide_mat[k * 19 + i], poly);
+            const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
+            const float re = pr * poly * att, im = pi * poly * att;
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+                part[o][u & 1] = fmaf(spec_w[o * KL + fc + 2 * i], re, fmaf(spec_w[o * KL + fc + 2 * i + 1], im, part[o][u & 1]));
+        }
+    }
+    // bottleneck features j = 16 t + sub + 8 u into partial sum u, t ascending.  All LDS reads of a batch of two t are issued
+    // before the batch's first fmaf (one read-to-use round trip per batch, not per feature)
+#pragma unroll 4
+    for (int j0 = 0; j0 < fc; j0 += 32) {
+        float b[4], wv[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + 8 * q + sub;                     // q = 2 t' + u
+            b[q] = sb[j];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) wv[o][q] = spec_w[o * KL + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) part[o][q & 1] = fmaf(wv[o][q], b[q], part[o][q & 1]);
+    }
+    float ps[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float first = fmaf(spec_w[o * KL + K - 1], dot, part[o][0]) + spec_b[o];
+        float lo = sub == 0 ? first : part[o][0], hi = part[o][1];
+        lo += dpp_mov<0xB1>(lo); hi += dpp_mov<0xB1>(hi);       // xor 1
+        lo += dpp_mov<0x4E>(lo); hi += dpp_mov<0x4E>(hi);       // xor 2
+        lo += xor4_dpp(lo); hi += xor4_dpp(hi);                 // xor 4
+        ps[o] = lo + hi;                                        // xor 8
+    }
+    const float sg = sigmoidf_(ch == 0 ? ps[0] : (ch == 1 ? ps[1] : ps[2]));
+    float c = srgbf_(tint_c * sg + diff_c);
+    c = fminf(fmaxf(c, 0.0f), 1.0f);
+    return c * 1.002f - 0.001f;
+}
+
+// MODE 2: the whole march of a tile (density, compositing, appearance, basis_mat).  MODE 3: MODE 2 + the Ref head and the
+// background blend (phase E): the tile leaves the kernel as colours, no feature rows and no second launch.  MODE 1: appearance + basis_mat only, the
 // compositing weights come from K4a's workspace (A/B aid).
 template <int MODE>
 __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, MarchArgs a, int64_t n_tiles) {
@@ -238,7 +361,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     // density patches: 3 x 576 plane chunks = two full rounds per plane + one round in which wave w takes the last 64 chunks of
     // plane w; the three lines (48 chunks each) likewise by waves 0..2 in one round
     f32q pre[8];
-    if (MODE == 2 && fits) {
+    if (MODE >= 2 && fits) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pa = mat_a(i), pb = mat_b(i);
@@ -299,7 +422,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
         }
     }
     STAMP(2);
-    if (MODE == 2 && fits) {
+    if (MODE >= 2 && fits) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -332,7 +455,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     const bool live = grp_on && g < n_live;
     uint32_t* recs = s_rec + gg * FS * REC;
     unsigned shmask = 0u;
-    if (MODE == 2) {
+    if (MODE >= 2) {
         // the 540 samples of the tile over the 64 four-lane sub-groups of the workgroup: sub-group q takes the samples t = q + 64 it
         // (t = 20 ray + s: the record index), its four lanes gather a sample together (one 16-B quarter of the density texel each)
         // and lane c finishes the sample of trip it = 4 k + c; the record of the next sample is read one trip ahead
@@ -432,6 +555,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
             }
         }
         if (writer) {
+            if (MODE == 3) s_ray[g * 8 + 6] = run_acc;          // phase E blends with it
             a.acc[r_glob] = run_acc;
             a.depth[r_glob] = run_depth + (1.0f - run_acc) * sr[7];
             if (a.counts) { a.counts[r_glob * 2] = run_valid; a.counts[r_glob * 2 + 1] = run_app; }
@@ -548,6 +672,23 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
             s_B[(k4 + 2) * DLD + o] = pre[r].z; s_B[(k4 + 3) * DLD + o] = pre[r].w;
         }
     }
+    f32q bias_pre[4], stage_pre = splat(0.0f);
+    if (MODE == 3) {
+        // the two head slices phase E keeps in LDS (from spec_w on: spec_w, spec_b, ide_mat; up to bott_w: the small heads), 16 B per thread
+        const HeadOff hq = head_offsets(f.app_dim, f.feature_c);
+        const int n_tail4 = (hq.total - hq.spec_w) / 4, n_small4 = hq.bott_w / 4;
+        if (tid < n_tail4) stage_pre = *reinterpret_cast<const f32q*>(f.head + hq.spec_w + 4 * tid);
+        else if (tid < n_tail4 + n_small4) stage_pre = *reinterpret_cast<const f32q*>(f.head + 4 * (tid - n_tail4));
+    }
+    if (MODE == 3 && 32 * wave < f.feature_c) {
+        // phase E's matrix operand (this wave's 32 bottleneck rows, one row per lane) and biases: in flight through phase D
+        const HeadOff hq = head_offsets(f.app_dim, f.feature_c);
+        const float* wr = f.head + hq.bott_w + (32 * wave + (lane & 31)) * 28;
+#pragma unroll
+        for (int k4 = 0; k4 < 7; ++k4) pre[k4] = *reinterpret_cast<const f32q*>(wr + 4 * k4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_pre[q] = *reinterpret_cast<const f32q*>(f.head + hq.bott_b + 32 * wave + 8 * q + 4 * (lane >> 5));
+    }
     __syncthreads();
     STAMP(12);
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -572,10 +713,72 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
         s_feat[ry * 28 + o] = (pp[0] + pp[32 * 32]) + (pp[2 * 32 * 32] + pp[3 * 32 * 32]);
     }
     if ((tid & 7) == 0 && grp_on) s_feat[g * 28 + 27] = any ? 1.0f : 0.0f;
+    if (MODE == 3 && tid < 5 * 28) s_feat[FR * 28 + tid] = 0.0f;             // rows 27..31 of the matrix operand
     STAMP(13);
     __syncthreads();
-    if (tid < n_live * 7)
-        *reinterpret_cast<f32q*>(a.feat + ray0 * 28 + 4 * tid) = *reinterpret_cast<const f32q*>(s_feat + 4 * tid);
+    if (MODE != 3) {
+        if (tid < n_live * 7)
+            *reinterpret_cast<f32q*>(a.feat + ray0 * 28 + 4 * tid) = *reinterpret_cast<const f32q*>(s_feat + 4 * tid);
+        STAMP(14);
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------------- phase E: the Ref head
+    // (models/ref.py:103-152; the separate launch k_ref_shade spends 16 lanes per ray on it.)  The bottleneck (feature_c rows over
+    // the ray's 27 features) runs as W[32 rows][28] x F^T[28][32 rays] tiles on the fp32 matrix cores (the same k-ordered fmaf
+    // chain as the vector code: identical bits), one 32-row block per wave; eight lanes per ray then finish it (ref_head_oct).
+    constexpr int BLD = 164;                           // floats per ray in s_b: 160 rows + 4 (16-B aligned rows, spread over the banks)
+    float* const s_b = s_pool + 5120;                  // behind the output rows
+    static_assert(4 * 32 * 32 + 32 * 28 <= 5120 && 5120 + 32 * BLD + 680 + 296 <= PATCH_FLOATS + FR * FS * REC, "phase E operands fit the pool");
+    const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
+    const int fc = f.feature_c;
+    float* const s_tail = s_b + 32 * BLD;              // the head from spec_w on (spec_w, spec_b, ide_mat) ...
+    float* const s_small = s_tail + 680;               // ... and up to bott_w (the small heads): what ref_head_oct reads per lane
+    {
+        const int n_tail4 = (ho.total - ho.spec_w) / 4, n_small4 = ho.bott_w / 4;         // <= 170 + 74 <= NT (fan_head_fusable)
+        if (tid < n_tail4) *reinterpret_cast<f32q*>(s_tail + 4 * tid) = stage_pre;
+        else if (tid < n_tail4 + n_small4) *reinterpret_cast<f32q*>(s_small + 4 * (tid - n_tail4)) = stage_pre;
+    }
+    {
+        const int lr = lane & 31, lh = lane >> 5;
+        if (32 * wave < fc) {                          // feature_c <= 128: one block per wave
+            const int blk = wave;
+            const f32q (&w)[8] = pre;
+            f32x16 e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 14; ++ks) {
+                const float av = lh ? w[ks >> 1][2 * (ks & 1) + 1] : w[ks >> 1][2 * (ks & 1)];
+                float bv = s_feat[lr * 28 + 2 * ks + lh];
+                if (ks == 13) bv = lh ? 0.0f : bv;                             // column 27 is the shaded flag, not a feature
+                e = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, e, 0, 0, 0);
+            }
+            // rows 32 blk + 8 q + 4 lh + i (register 4 q + i) of ray lr, plus the bias
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r0 = 32 * blk + 8 * q + 4 * lh;
+                const f32q bias = bias_pre[q];
+                f32q o4 = {e[4 * q] + bias[0], e[4 * q + 1] + bias[1], e[4 * q + 2] + bias[2], e[4 * q + 3] + bias[3]};
+                *reinterpret_cast<f32q*>(s_b + lr * BLD + r0) = o4;
+            }
+        }
+    }
+    ESTAMP(6);
+    __syncthreads();
+    ESTAMP(7);
+    if (grp_on) {                                      // g = ray of the tile, eight lanes each
+        const int sub = tid & 7;
+        const float* sr = s_ray + g * 8;
+        const float d[3] = {sr[3], sr[4], sr[5]};
+        const float cch = ref_head_oct(s_small, ho, fc, s_b + g * BLD, s_feat + g * 28, s_tail, d, sub);
+        if (sub < 3 && g < n_live) {
+            const bool shaded = s_feat[g * 28 + 27] != 0.0f;
+            const float acc = sr[6];
+            float v = shaded ? cch : 0.0f;
+            v = v * acc + (sub == 0 ? a.bg[0] : (sub == 1 ? a.bg[1] : a.bg[2])) * (1.0f - acc);
+            a.rgb[3 * (ray0 + g) + sub] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+    }
     STAMP(14);
 }
 
@@ -594,12 +797,18 @@ bool fan_march_eligible(const FieldDev& f, int mode, int S) {
     return true;
 }
 
+// the fused Ref head (phase E) is laid out for the reference's head: 27 features in rows of 28, a bottleneck of at most 128 rows
+bool fan_head_fusable(const FieldDev& f) {
+    return f.app_dim == 27 && f.feature_c >= 32 && f.feature_c <= 128 && f.feature_c % 32 == 0 && f.head != nullptr;
+}
+
 hipError_t launch_fan_march(const FieldDev& f, const MarchArgs& a, int variant, hipStream_t s) {
     const int64_t n_tiles = (a.R + FR - 1) / FR;
     if (n_tiles == 0) return hipSuccess;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
     const int64_t grid = n_tiles;
     if (variant == 1) hipLaunchKernelGGL((k4f_fan_march<1>), dim3((unsigned)grid), dim3(NT), 0, s, f, a, n_tiles);
+    else if (variant == 3) hipLaunchKernelGGL((k4f_fan_march<3>), dim3((unsigned)grid), dim3(NT), 0, s, f, a, n_tiles);
     else hipLaunchKernelGGL((k4f_fan_march<2>), dim3((unsigned)grid), dim3(NT), 0, s, f, a, n_tiles);
     return hipGetLastError();
 }

@@ -418,8 +418,11 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     }
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
+    // the fused kernel also runs the Ref head and the blend when the caller wants colours (IFF_MARCH_FAN_HEAD=0: keep the separate launch)
+    static const bool head_env = [] { const char* v = getenv("IFF_MARCH_FAN_HEAD"); return !(v && v[0] == '0'); }();
+    const bool fuse_head = fan == 2 && !feat_out && head_env && fan_head_fusable(f);
     if (fan) {
-        e = launch_fan_march(f, a, fan, s);
+        e = launch_fan_march(f, a, fuse_head ? 3 : fan, s);
         if (e != hipSuccess) return e;
     } else if (mode == 0 && S <= 32) {
         const int64_t tiles12 = (R + 19) / 20;
@@ -433,7 +436,7 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (stage_ms_host) (void)hipEventRecord(ev[2], s);
-    if (!feat_out) e = launch_shade_blend(f, rays, ray_cols, a.feat, acc, a.bg, R, rgb, s);
+    if (!feat_out && !fuse_head) e = launch_shade_blend(f, rays, ray_cols, a.feat, acc, a.bg, R, rgb, s);
     if (stage_ms_host) {
         (void)hipEventRecord(ev[3], s);
         hipError_t es = hipEventSynchronize(ev[3]);

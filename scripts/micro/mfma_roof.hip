@@ -9,7 +9,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int NACC, int V>
-__global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
+__global__ void __launch_bounds__(256) k(float* out, int iters, float seed, unsigned long long* clk) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     f32x16 acc[NACC];
     for (int c = 0; c < NACC; ++c)
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
@@ -39,28 +40,33 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
         for (int r = 0; r < 16; ++r) s += acc[c][r];
     for (int i = 0; i < 8; ++i) s += v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = __builtin_amdgcn_s_memtime() - t0;
 }
 
 template <int NACC, int V>
 void run(const char* name, int waves_per_simd, float* out) {
-    const int iters = 2000;
+    static unsigned long long* clk = nullptr;
+    if (!clk) hipHostMalloc(&clk, 8);
+    const int iters = 20000;
     const int blocks = 256 * waves_per_simd;           // 256-thread blocks: one wave per SIMD each
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<NACC, V>), dim3(blocks), dim3(256), 0, 0, out, 10, 1.0f);
+    hipLaunchKernelGGL((k<NACC, V>), dim3(blocks), dim3(256), 0, 0, out, 10, 1.0f, clk);
     hipDeviceSynchronize();
     float best = 1e9f;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k<NACC, V>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+        hipLaunchKernelGGL((k<NACC, V>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f, clk);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
+    hipDeviceSynchronize();
+    const double ghz = (double)clk[0] / (best * 1e-3) * 1e-9;
     const double flop = (double)blocks * 4 * iters * 3 * NACC * 32768.0;
     const double clk_per_mfma = best * 1e-3 * 2.4e9 / ((double)iters * 3 * NACC * waves_per_simd);
-    printf("%-28s waves/SIMD %d  %.3f ms  %.0f TFLOP/s  (%.1f clk @2.4GHz per MFMA per SIMD)\n", name, waves_per_simd, best, flop / best * 1e-9, clk_per_mfma);
+    printf("%-28s waves/SIMD %d  %.3f ms  %.0f TFLOP/s  (%.1f clk @2.4GHz per MFMA per SIMD)  s_memtime/wall = %.2f GHz\n", name, waves_per_simd, best, flop / best * 1e-9, clk_per_mfma, ghz);
 }
 
 int main() {

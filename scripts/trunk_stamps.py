@@ -16,11 +16,23 @@ qf = net.q_fold(tok.reshape(B * M, -1))
 for _ in range(3):
     out = net.ray_logits_folded_batched(qf, o.reshape(-1, 3), d.reshape(-1, 3), c.reshape(-1, 3), B)
 torch.cuda.synchronize()
+ms = []
+out = net.ray_logits_folded_batched(qf, o.reshape(-1, 3), d.reshape(-1, 3), c.reshape(-1, 3), B, trunk_ms=ms)
+torch.cuda.synchronize()
 lg = out[0].reshape(B, M, N)
 n_full = N // 64
 st = lg[:, :, : n_full * 64 : 64].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff    # [B, 256, tiles]
 st = st.reshape(B, 8, 32, n_full)[:, :, :16, :]                  # [B, wave, k, tile]
 st = np.moveaxis(st, 3, 1).reshape(-1, 8, 16)                      # [tile, wave, k]
+t_first, t_last = st[:, :, 0].min(), st[:, :, 15].max()
+print(f"launch: {ms[0]:.4f} ms by events; first start -> last end {int(t_last - t_first)} ticks = {(t_last - t_first) / ms[0] * 1e-6:.3f} GHz if s_memtime is the core clock")
+# the counters of the eight XCDs are not aligned: split the tiles into clusters of start values (gaps > 1e6 ticks) and take each cluster's span
+order = np.argsort(st[:, 0, 0])
+s0, e0 = st[order, 0, 0], st[order, :, 15].max(axis=1)
+cuts = np.flatnonzero(np.diff(s0) > 1_000_000) + 1
+spans = [int(e.max() - b.min()) for b, e in zip(np.split(s0, cuts), np.split(e0, cuts))]
+print("per-XCD spans (ticks):", spans, "tiles per cluster:", [len(b) for b in np.split(s0, cuts)])
+print(f"  -> {np.median(spans) / ms[0] * 1e-6:.3f} GHz if s_memtime is the core clock and a cluster spans the whole launch")
 dd = (st - st[:, :1, :1]) & 0xffffffff
 names = ["start", "PE done", "M1 done", "bar", "V1 done", "bar", "M2 done", "bar", "V2 done", "bar", "M3 done", "bar", "V3 done", "bar", "ML done", "epilogue"]
 med = np.median(dd, axis=0)
