@@ -421,10 +421,12 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                 "unit": "GB/s", "frac": round(gbs / peak, 4), "traffic": traffic(*keys), "avg_launch_ms": round(ms, 4),
                 "algorithmic_bytes_per_launch": round(nbytes), "peak_basis": peak_basis, "binding": binding(ms, *keys), "note": note}
 
-    if pipe.field.march_plan(0, 20) == 2:
+    plan = pipe.field.march_plan(0, 20)
+    if plan in (2, 3):
         kernels.append(gather_kernel(
+            "k4f_fan_march<3> (TensorBase.forward, fused per 27-ray fan: density, compositing, appearance, basis_mat, Ref head, blend)" if plan == 3 else
             "k4f_fan_march<2> (TensorBase.forward up to the Ref head, fused per 27-ray fan: density, compositing, appearance, basis_mat)",
-            ("k4f_fan_march<2>",), "lds-gather", LDS_PEAK_GBS, bytes_a + bytes_b - rays_per_launch * 2 * 20 * 4,
+            ("k4f_fan_march<%d>" % plan,), "lds-gather", LDS_PEAK_GBS, bytes_a + bytes_b - rays_per_launch * 2 * 20 * 4,
             march_launch_ms[1],
             "algorithmic bytes = 1184 B per valid sample + 3456 B per shaded sample (SURVEY 8d) x the kernel's own sample counters + "
             "rays in / features out.  The table patches a fan touches are staged once in LDS (coalesced row segments: `traffic` is "
@@ -446,8 +448,9 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     result["roofline"]["traffic_source"] = traffic_source
     result["roofline"]["selected_as"] = "the longest launch of a step by this run's hipEvent timings"
     others = {k["kernel"].split(" (")[0]: k for k in kernels[1:]}
-    others["k_ref_shade<27, true>"] = {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>"),
-                                       "note": "Ref head per ray (ref.py:103-152): vector ALU from LDS-staged weights, no roofline"}
+    if plan != 3:
+        others["k_ref_shade<27, true>"] = {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>"),
+                                           "note": "Ref head per ray (ref.py:103-152): vector ALU from LDS-staged weights, no roofline"}
     result["roofline"]["other_kernels"] = others
     if world_size == 1 and not shared:
         # warm path (rays resident: the reference's eval semantics, train_eval_pose_est.py:131-149): stage C only, 16 query

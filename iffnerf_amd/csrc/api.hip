@@ -275,7 +275,8 @@ extern "C" int32_t iff_march_default_samples(const iff_field* f, int32_t mode) {
 
 extern "C" int32_t iff_march_plan(const iff_field* f, int32_t mode, int32_t n_samples) {
     if (!f) return IFF_MARCH_PLAN_GENERAL;
-    return march_plan(f->dev, mode, march_samples(f, mode, n_samples));
+    const int plan = march_plan(f->dev, mode, march_samples(f, mode, n_samples));
+    return (plan == IFF_MARCH_PLAN_FAN && march_head_fused(f->dev)) ? IFF_MARCH_PLAN_FAN_HEAD : plan;
 }
 
 extern "C" size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples) {

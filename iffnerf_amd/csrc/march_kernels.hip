@@ -385,6 +385,12 @@ int march_plan(const FieldDev& f, int mode, int S) {
     return (fan_knob > 0 && f.density_lanes == 0 && fan_march_eligible(f, mode, S)) ? (fan_knob == 1 ? 1 : 2) : 0;
 }
 
+// the colours call of the fused plan also runs the Ref head in the fan kernel (IFF_MARCH_FAN_HEAD=0, read once: keep the separate launch)
+bool march_head_fused(const FieldDev& f) {
+    static const bool head_env = [] { const char* v = getenv("IFF_MARCH_FAN_HEAD"); return !(v && v[0] == '0'); }();
+    return head_env && fan_head_fusable(f);
+}
+
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
                         float* rgb, float* depth, float* acc, float* alpha, int* counts, float* feat_out, void* ws,
                         size_t ws_bytes, float* stage_ms_host, hipStream_t s) {
@@ -418,9 +424,7 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     }
     if (stage_ms_host) (void)hipEventRecord(ev[1], s);
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
-    // the fused kernel also runs the Ref head and the blend when the caller wants colours (IFF_MARCH_FAN_HEAD=0: keep the separate launch)
-    static const bool head_env = [] { const char* v = getenv("IFF_MARCH_FAN_HEAD"); return !(v && v[0] == '0'); }();
-    const bool fuse_head = fan == 2 && !feat_out && head_env && fan_head_fusable(f);
+    const bool fuse_head = fan == 2 && !feat_out && march_head_fused(f);
     if (fan) {
         e = launch_fan_march(f, a, fuse_head ? 3 : fan, s);
         if (e != hipSuccess) return e;

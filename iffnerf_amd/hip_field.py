@@ -205,7 +205,7 @@ class FieldHandle:
 
     # ------------------------------------------------------------------ march
     def march_plan(self, mode: int = MARCH_POINT, n_samples: int = -1) -> int:
-        """``iff_march_plan``: 2 when the fused fan kernel serves this march, 0 for the general kernels."""
+        """``iff_march_plan``: 0 the general kernels, 2 the fused fan kernel + the Ref head launch, 3 the fan kernel with the head fused in."""
         return int(_lib.lib().iff_march_plan(self._h, int(mode), int(n_samples)))
 
     def march(self, rays: torch.Tensor, mode: int, n_samples: int = -1, bg=(0.0, 0.0, 0.0), want_alpha: bool = True,

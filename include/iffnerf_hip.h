@@ -157,22 +157,29 @@ size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t 
 int32_t iff_march_default_samples(const iff_field* f, int32_t mode);
 /* Which kernels serve TensorBase.forward (models/tensorBase.py:775-917) for this (mode, n_samples) on this handle:
  *   IFF_MARCH_PLAN_GENERAL  three launches: density + compositing per sample from the vector caches, appearance gather, Ref head
- *   IFF_MARCH_PLAN_FAN      two launches: the fused fan kernel + Ref head.  Rays are taken 27 at a time (one iso-cell fan of
+ *   IFF_MARCH_PLAN_FAN      two launches: the fused fan kernel + Ref head (models/ref.py:103-152).  Rays are taken 27 at a time (one iso-cell fan of
  *                           pose_estimation/sampling.py:442-488 when they come from iff_isocell_emit); the table patches the 540
  *                           samples of a tile touch are staged once in LDS and density, compositing, appearance and basis_mat run
  *                           from there.  Chosen for the point-centred 20-sample march of a field without unisphere contraction
  *                           whose ten steps span about five texels (every reference config); any rays are accepted -- a tile
  *                           whose samples do not fit one patch is gathered from global memory by the same kernel, same results.
- * Both plans produce the same alpha / acc / depth / sample counters bit for bit; colours agree to fp32 summation order. */
-#define IFF_MARCH_PLAN_GENERAL 0
-#define IFF_MARCH_PLAN_FAN     2
+ *   IFF_MARCH_PLAN_FAN_HEAD one launch: the fan kernel also runs the Ref head and the background blend of its 27 rays (the
+ *                           bottleneck rows on the fp32 matrix cores) -- iff_march_shade under the conditions of
+ *                           IFF_MARCH_PLAN_FAN when the head has the reference's shape (27 features, feature_c a multiple of 32
+ *                           up to 128).  iff_march_features (no colours) runs the same kernel without that phase.
+ * All plans produce the same alpha / acc / depth / sample counters bit for bit; the fan plans' colours are bit-identical to each
+ * other and agree with the general plan's to fp32 summation order. */
+#define IFF_MARCH_PLAN_GENERAL  0
+#define IFF_MARCH_PLAN_FAN      2
+#define IFF_MARCH_PLAN_FAN_HEAD 3
 int32_t iff_march_plan(const iff_field* f, int32_t mode, int32_t n_samples);
 int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                     int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
                     float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream);
 /* Same call (models/tensorBase.py:775-917), but SYNCHRONOUS and instrumented: stage_ms_host[3] receives the durations of
  * its launches from hipEvents on `stream`: (density+compositing, appearance gather, Ref shading) under
- * IFF_MARCH_PLAN_GENERAL, (0, fused fan kernel, Ref shading) under IFF_MARCH_PLAN_FAN.  Measurement aid for bench.py's
+ * IFF_MARCH_PLAN_GENERAL, (0, fused fan kernel, Ref shading) under IFF_MARCH_PLAN_FAN, (0, fused fan kernel incl. the head, 0)
+ * under IFF_MARCH_PLAN_FAN_HEAD.  Measurement aid for bench.py's
  * roofline; not for the timed path. */
 int iff_march_shade_timed(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                           int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,

@@ -211,3 +211,13 @@ def test_fan_march_equals_the_general_kernels(dev):
             fa, fb = fan.march_features(rays, 0, 20)[0], gen.march_features(rays, 0, 20)[0]
             close(fa, fb.cpu(), 2e-5, 2e-6, what="weighted features")
             assert torch.equal(fa[:, 27], fb[:, 27])
+            # the Ref head fused into the fan kernel (plan 3: bottleneck on the fp32 matrix cores, eight lanes per ray) against the
+            # separate head kernel (16 lanes per ray) on the fan kernel's own features, blended as k_ref_shade blends: EQUAL colours
+            assert fan.march_plan(0, 20) == (3 if os.environ.get("IFF_MARCH_FAN_HEAD", "1") != "0" else 2) and gen.march_plan(0, 20) == 0
+            for bg in ((0.0, 0.0, 0.0), (1.0, 0.5, 0.25)):
+                fused = fan.march(rays, 0, 20, bg=bg)
+                c = fan.ref_shade(rays[:, 3:6].contiguous(), fa[:, :27].contiguous())
+                c = torch.where(fa[:, 27:28] != 0, c, torch.zeros_like(c))
+                acc = fused[2].reshape(-1, 1)
+                want = (c * acc + torch.tensor(bg, device=c.device) * (1.0 - acc)).clamp(0.0, 1.0)
+                assert torch.equal(fused[0], want), (which, over, tuple(rays.shape), bg, float((fused[0] - want).abs().max()))
