@@ -478,28 +478,19 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
                 if (DUAL) trunk_load_w_h(wb[i], WB, i, wave, lane);
             }
         }
-#ifndef TRUNK_EXP
-#define TRUNK_EXP 0
-#endif
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            if (ks + DEPTH - 1 < NK && !((TRUNK_EXP & 1) && ks + DEPTH - 1 >= DEPTH)) {
+            if (ks + DEPTH - 1 < NK) {
                 trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wave, lane);
                 if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wave, lane);
             }
             if (AB == 2 && ks + 1 < NK) load_act(act[(ks + 1) & 1], ks + 1);
             __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them)
-            if (!(TRUNK_EXP & 4)) {
             if (SWAP) trunk_mfma_ht<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
             else trunk_mfma_h<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
             if (DUAL) trunk_mfma_h<FG, RG>(accB, wb[ks % DEPTH], act[ks & (AB - 1)]);
-            } else {
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg) { accA[0][rg][ks & 15] += (float)wa[ks % DEPTH].p[0][0][0] + (float)wa[ks % DEPTH].p[0][1][0] + (float)act[ks & (AB - 1)][rg][0][0] + (float)act[ks & (AB - 1)][rg][1][0]; }
-                if (DUAL) accB[0][0][ks & 15] += (float)wb[ks % DEPTH].p[0][0][0] + (float)wb[ks % DEPTH].p[0][1][0];
-            }
             __builtin_amdgcn_sched_barrier(0);
-            if (AB == 1 && ks + 1 < NK && !((TRUNK_EXP & 2) && ks >= 1)) load_act(act[0], ks + 1);
+            if (AB == 1 && ks + 1 < NK) load_act(act[0], ks + 1);
         }
     };
     using std::integral_constant;
@@ -703,7 +694,7 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
-            if (ks + DEPTH - 1 < NK && !((TRUNK_EXP & 1) && ks + DEPTH - 1 >= DEPTH)) {
+            if (ks + DEPTH - 1 < NK) {
                 trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wave, lane);
                 if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wave, lane);
             }
@@ -712,7 +703,7 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
             else trunk_mfma_h<FG, RG>(accA, wa[ks % DEPTH], act);
             if (DUAL) trunk_mfma_h<FG, RG>(accB, wb[ks % DEPTH], act);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NK && !((TRUNK_EXP & 2) && ks >= 1)) load_act(act, ks + 1);
+            if (ks + 1 < NK) load_act(act, ks + 1);
         }
     };
     using std::integral_constant;
