@@ -276,6 +276,9 @@ def main():
                                       f"every query's rays sharded over {world_size} ranks (RCCL all_gathers over xGMI: "
                                       f"{'statistics, candidates' if shared else 'points + folded queries, statistics, candidates'})"},
         }
+        if sharded:      # what the process group itself reports (the collectives really ran over this many ranks of this backend)
+            result["config"]["rccl_world_size"] = dist.get_world_size()
+            result["config"]["collective_backend"] = dist.get_backend()
         if not args.no_instrument:
             instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, rank, device)
         if world_size == 1 and not args.no_cpu_baseline:

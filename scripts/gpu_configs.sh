@@ -24,5 +24,6 @@ run lego16k --steps 100 --warmup 10 --no-cpu-baseline
 run truck32k --config truck32k --steps 40 --warmup 5 --no-cpu-baseline
 run bicycle64k --config bicycle64k --steps 30 --warmup 5 --no-cpu-baseline
 run lego_b64 --config lego_b64 --steps 60 --warmup 10 --no-cpu-baseline
+run lego540k --config lego540k --steps 12 --warmup 3 --no-cpu-baseline
 run lego16k_sharded_ws1 --steps 100 --warmup 10 --no-cpu-baseline --no-instrument --force-sharded
 run lego_b64_sharded_ws1 --config lego_b64 --steps 60 --warmup 10 --no-cpu-baseline --no-instrument --force-sharded
