@@ -364,6 +364,11 @@ extern "C" int iff_surface_sample_residency(const iff_field* f, int32_t B, int64
     IFF_REQUIRE(f && wgs_per_run && device_capacity && B >= 1, "iff_surface_sample_residency: bad argument");
     int w = 0, c = 0;
     IFF_HIP(sampler_residency(P, f->n_cus, sampler_lpc(f->dev, B), B, &w, &c));
+    if (sampler_stepped()) {       // no workgroup waits for another one: nothing has to be resident together
+        const int64_t want = (5 * P * sampler_lpc(f->dev, B) + 255) / 256;
+        w = (int)(want > 1024 ? 1024 : want);
+        c = 0x7fffffff;
+    }
     *wgs_per_run = w; *device_capacity = c;
     return 0;
 }

@@ -44,9 +44,11 @@ constexpr int SAMPLER_MAX_ITERS = 4095;
 constexpr int SAMPLER_MAX_POINTS = 32768;          // the invalid list lives in LDS (4 B per sample)
 constexpr int SAMPLER_CACHE_POINTS = 4096;        // up to here alpha + positions are cached in LDS too (20 B per sample)
 struct SamplerWs {
-    unsigned barrier_count;     // monotonic arrivals
+    unsigned barrier_count;     // monotonic arrivals (persistent form)
     unsigned abort_flag;
-    unsigned pad[62];
+    float thresh;               // stepped form: this epoch's threshold, written by the epoch's first iteration launch
+    int done_epoch;             // stepped form: epoch + 1 once an iteration launch found no invalid sample left in `epoch`
+    unsigned pad[60];
     // followed by: winners[2][P] (u64, double-buffered by epoch parity)
 };
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -359,6 +361,262 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the stepped form
+// The same sampler as a chain of SHORT launches -- seeds | per epoch: S iteration launches, a finisher, the apply step -- with the
+// kernel boundary as the grid barrier.  The persistent launch above is parked at its barriers for 80 % of its life, and next to
+// the throughput kernels of other steps it stays resident 0.8 ms per step (2-3 launches at any time under four steps in flight):
+// each of its waves holds 128 VGPR, so a SIMD that hosts one cannot take the third wave of the fan march (3 x 168) or the
+// fourth of the trunk (4 x 126) -- measured with the sampler free-running on side streams: march 0.53 -> 0.77 ms, trunk 0.39 ->
+// 0.66 ms per step (scripts/sampler_interference.py).  A launch of this form holds its slots for the few microseconds it works.
+// Same arithmetic, same random streams, same order-independent picks: the samples are those of the persistent form bit for bit
+// (tests/test_hip_sampler.py).  No workgroup waits for another one: no co-residency requirement, no spins, no timeout.
+//   k_ss_seed        seeds and their alpha (sampling.py:78-116,131-140); clears the statistics
+//   k_ss_iter        iteration `it` of `epoch` for every run that still has invalid samples: every workgroup rebuilds the run's
+//                    ascending list of invalid samples from the winner slots (it == 0: also the epoch's threshold, which workgroup
+//                    0 of the run leaves in the workspace for the later launches), then its share of the 5 P candidates
+//   k_ss_finish      iterations S, S + 1, ... up to max_iterations for a run that has not converged after the S static launches
+//                    (one workgroup per run looping with workgroup barriers; returns at once otherwise -- the reference's bound
+//                    of 200 iterations is kept, 3-6 are observed on every bench model)
+//   k_ss_apply       the accepted samples move to their winning candidate (sampling.py:205-213); per-epoch statistics
+constexpr int SS_SLOTS = 8;              // static iteration launches per epoch
+
+struct SsRun {                           // one run's views, resolved from blockIdx
+    int q_id, wg_id;
+    SamplerWs* ws;
+    unsigned long long* winners_base;
+};
+__device__ __forceinline__ SsRun ss_resolve(SamplerArgs& a, int wgs_per_run) {
+    SsRun r;
+    r.q_id = (int)(blockIdx.x / (unsigned)wgs_per_run);
+    r.wg_id = (int)(blockIdx.x - (unsigned)r.q_id * (unsigned)wgs_per_run);
+    unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) + (unsigned long long)r.q_id * 0x9E3779B97F4A7C15ull;
+    if (a.seed_dev) sd += __hip_atomic_load(a.seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.seed_lo = (uint32_t)(sd & 0xffffffffull); a.seed_hi = (uint32_t)(sd >> 32);
+    a.ws += (size_t)r.q_id * a.ws_stride;
+    a.samples += (size_t)r.q_id * a.P * 3;
+    a.alpha += (size_t)r.q_id * a.P;
+    a.stats += (size_t)r.q_id * 4 * (a.n_epochs > 0 ? a.n_epochs : 1);
+    r.ws = (SamplerWs*)a.ws;
+    r.winners_base = (unsigned long long*)(a.ws + align_up(sizeof(SamplerWs), 256));
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_ss_seed(FieldDev f, SamplerArgs a, int wgs_per_run) {
+    const SsRun r = ss_resolve(a, wgs_per_run);
+    const int P = (int)a.P, lpc = a.lpc, lsh = (a.lpc == 4) ? 2 : 0;
+    const int64_t gtid = r.wg_id * (int64_t)blockDim.x + threadIdx.x, gthreads = (int64_t)wgs_per_run * blockDim.x;
+    for (int64_t t = gtid; t < 4 * (int64_t)a.n_epochs; t += gthreads) a.stats[t] = 0;
+    const int W = f.mask_dims[2], H = f.mask_dims[1], D = f.mask_dims[0];
+    const int64_t nt = (int64_t)P * lpc;
+    for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
+        bool live = t < nt;
+        int i = live ? (int)(t >> lsh) : 0;
+        int sub = (int)(t & (lpc - 1));
+        U4 rr = philox4x32_10(U4{(uint32_t)i, 0u, 0u, 0x5eedu}, a.seed_lo, a.seed_hi);
+        float p[3];
+        if (f.mask && a.n_occ > 0) {
+            int pick = (int)(((unsigned long long)rr.x * (unsigned long long)a.n_occ) >> 32);
+            int v = a.occ_list[pick];
+            int x = v % W, y = (v / W) % H, z = v / (W * H);
+            float sv[3] = {(float)x + u01(rr.y), (float)y + u01(rr.z), (float)z + u01(rr.w)};
+            float dims[3] = {(float)W - 1.0f, (float)H - 1.0f, (float)D - 1.0f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = ((f.mask_hi[c] - f.mask_lo[c]) * sv[c]) / dims[c] + f.mask_lo[c];
+        } else {
+            float u[3] = {u01(rr.y), u01(rr.z), u01(rr.w)};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = u[c] * (f.aabb_hi[c] - f.aabb_lo[c]) + f.aabb_lo[c];
+        }
+        float al = (lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live);
+        if (live && sub == 0) {
+            a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
+            a.alpha[i] = al;
+        }
+    }
+}
+
+// threshold = torch.quantile(alpha, 0.6), linear interpolation (the persistent form's code): every thread of the workgroup returns it
+__device__ inline float ss_threshold(const float* alpha_src, int P, int* hist) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float pos = 0.6f * (float)(P - 1);
+    int lo = (int)floorf(pos);
+    int hi = min(lo + 1, P - 1);
+    float frac = pos - (float)lo;
+    const uint32_t klo = iff_wg_select_key<false>(alpha_src, P, lo + 1, hist);
+    int cnt_le = 0;
+    uint32_t kmin = 0xffffffffu;
+    for (int t = tid; t < P; t += 256) {
+        uint32_t key = iff_order_key(alpha_src[t]);
+        cnt_le += (key <= klo) ? 1 : 0;
+        kmin = (key > klo && key < kmin) ? key : kmin;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cnt_le += __shfl_xor(cnt_le, off, 64);
+        uint32_t o = (uint32_t)__shfl_xor((int)kmin, off, 64);
+        kmin = o < kmin ? o : kmin;
+    }
+    if (lane == 0) { hist[wave] = cnt_le; hist[4 + wave] = (int)kmin; }
+    __syncthreads();
+    cnt_le = hist[0] + hist[1] + hist[2] + hist[3];
+    kmin = (uint32_t)hist[4];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) kmin = (uint32_t)hist[4 + w] < kmin ? (uint32_t)hist[4 + w] : kmin;
+    __syncthreads();
+    const uint32_t khi = (hi == lo || cnt_le >= hi + 1) ? klo : kmin;
+    float vlo = iff_order_key_inv(klo);
+    float vhi = iff_order_key_inv(khi);
+    return (frac < 0.5f) ? (vlo + (vhi - vlo) * frac) : (vhi - (vhi - vlo) * (1.0f - frac));
+}
+
+// A sample is still invalid at the start of iteration `it` if its slot is empty or holds a key of iteration >= it: the other
+// workgroups of the same launch post their keys of iteration `it` while this one may still be reading the slots
+__device__ __forceinline__ bool ss_still_invalid(unsigned long long wv, int it) { return wv == 0ull || (int)((wv >> 20) & 0xfffull) >= it; }
+
+// the ascending list of samples that are still invalid at the start of iteration `it`, into s_list; returns their number.  Each wave owns a contiguous
+// quarter of the samples: one counting pass, the four wave totals through LDS, one writing pass (two workgroup barriers whatever P)
+__device__ inline int ss_build_list(const unsigned long long* winners, int P, int it, int* s_list, int* s_tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_wave = ((P + 255) / 256) * 64;                  // a multiple of 64
+    const int w0 = wave * per_wave, w1 = min(P, w0 + per_wave);
+    int cnt = 0;
+    for (int c0 = w0; c0 < w1; c0 += 64) {
+        const int i = c0 + lane;
+        const bool stay = i < w1 && ss_still_invalid(__hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), it);
+        cnt += __popcll(__ballot(stay));
+    }
+    if (lane == 0) s_tot[wave] = cnt;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_tot[w];
+    const int K = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    for (int c0 = w0; c0 < w1; c0 += 64) {
+        const int i = c0 + lane;
+        const bool stay = i < w1 && ss_still_invalid(__hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), it);
+        const unsigned long long bal = __ballot(stay);
+        if (stay) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        base += __popcll(bal);
+    }
+    __syncthreads();
+    return K;
+}
+
+// one iteration of one run by `wgs` workgroups (this one is number wg_id): list, candidate budget, candidates.  Returns the number
+// of invalid samples it found (0: nothing was done).  `thresh`, s_alpha / s_pos are the caller's
+__device__ inline int ss_iteration(const FieldDev& f, const SamplerArgs& a, unsigned long long* winners, int epoch, int it, int wg_id, int wgs,
+                                   float thresh, int* s_list, const float* s_pos, int* s_tot, int& m_out) {
+    const int P = (int)a.P, lpc = a.lpc, lsh = (a.lpc == 4) ? 2 : 0;
+    const int K = ss_build_list(winners, P, it, s_list, s_tot);
+    if (K == 0) return 0;
+    const int64_t gtid = wg_id * (int64_t)blockDim.x + threadIdx.x, gthreads = (int64_t)wgs * blockDim.x;
+    const int m = (5 * P) / K;
+    m_out = m;
+    const int64_t nt = (int64_t)K * m * lpc;
+    for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
+        bool live = t < nt;
+        int64_t slot = live ? (t >> lsh) : 0;
+        int sub = (int)(t & (lpc - 1));
+        int li = (int)(slot / m), j = (int)(slot - (int64_t)li * m);
+        int i = s_list[li];
+        const float* ps = a.cache_lds ? s_pos : a.samples;
+        float base[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]}, p[3];
+        uint32_t prio;
+        candidate_position(a, base, i, j, epoch, it, p, prio);
+        float al = (lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live);
+        if (live && sub == 0 && al > thresh) {
+            unsigned long long key = ((unsigned long long)prio << 32) | ((unsigned long long)it << 20) | (unsigned long long)(unsigned)(j + 1);
+            atomicMax(&winners[i], key);
+        }
+    }
+    return K;
+}
+
+// FINISH = false: iteration `it0` by the run's wgs_per_run workgroups.  FINISH = true: one workgroup per run, iterations it0 .. max
+template <bool FINISH>
+__global__ void __launch_bounds__(256) k_ss_iter(FieldDev f, SamplerArgs a, int wgs_per_run, int epoch, int it0) {
+    extern __shared__ int s_list[];               // [P] invalid sample ids; then (cache_lds) alpha [P], pos [3P]
+    __shared__ int hist[264];
+    __shared__ int s_tot[4];
+    __shared__ int s_done;
+    const SsRun r = ss_resolve(a, wgs_per_run);
+    const int P = (int)a.P, tid = threadIdx.x;
+    // this run's epoch has converged already?  ONE read per workgroup: workgroup 0 of this very launch may be setting the flag, and
+    // threads of one workgroup that read it at different times would part ways before a workgroup barrier
+    if (tid == 0) s_done = __hip_atomic_load(&r.ws->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_done == epoch + 1) return;
+    unsigned long long* winners = r.winners_base + (size_t)(epoch & 1) * P;
+    float* s_alpha = reinterpret_cast<float*>(s_list + P);
+    float* s_pos = s_alpha + P;
+    if (a.cache_lds) {
+        for (int t = tid; t < P; t += 256) {
+            if (it0 == 0) s_alpha[t] = a.alpha[t];
+            s_pos[3 * t] = a.samples[3 * t]; s_pos[3 * t + 1] = a.samples[3 * t + 1]; s_pos[3 * t + 2] = a.samples[3 * t + 2];
+        }
+        __syncthreads();
+    }
+    float thresh;
+    if (it0 == 0) {
+        thresh = ss_threshold(a.cache_lds ? s_alpha : a.alpha, P, hist);
+        if (r.wg_id == 0 && tid == 0) { r.ws->thresh = thresh; a.stats[epoch * 4 + 2] = __float_as_int(thresh); }
+    } else {
+        thresh = r.ws->thresh;                    // written by an earlier launch of this epoch
+    }
+    for (int it = it0; it < a.max_iterations; ++it) {
+        int m = 0;
+        const int K = ss_iteration(f, a, winners, epoch, it, FINISH ? 0 : r.wg_id, FINISH ? 1 : wgs_per_run, thresh, s_list, s_pos, s_tot, m);
+        if (K == 0) {
+            if (r.wg_id == 0 && tid == 0) __hip_atomic_store(&r.ws->done_epoch, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (r.wg_id == 0 && tid == 0) { a.stats[epoch * 4 + 0] = it + 1; a.stats[epoch * 4 + 3] = m; }
+        if (!FINISH) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's atomics have reached the memory side
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ss_apply(FieldDev f, SamplerArgs a, int wgs_per_run, int epoch) {
+    __shared__ int s_cnt[4];
+    const SsRun r = ss_resolve(a, wgs_per_run);
+    const int P = (int)a.P, lpc = a.lpc, lsh = (a.lpc == 4) ? 2 : 0;
+    unsigned long long* winners = r.winners_base + (size_t)(epoch & 1) * P;
+    unsigned long long* winners_next = r.winners_base + (size_t)((epoch + 1) & 1) * P;
+    const int64_t gtid = r.wg_id * (int64_t)blockDim.x + threadIdx.x, gthreads = (int64_t)wgs_per_run * blockDim.x;
+    const int64_t nt = (int64_t)P * lpc;
+    int left = 0;
+    for (int64_t t = gtid; t < ((nt + 63) & ~(int64_t)63); t += gthreads) {
+        bool live = t < nt;
+        int i = live ? (int)(t >> lsh) : 0;
+        int sub = (int)(t & (lpc - 1));
+        unsigned long long wv = live ? __hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        bool moved = wv != 0ull;
+        int j = (int)(wv & 0xfffffull) - 1, wit = (int)((wv >> 20) & 0xfffull);
+        float base[3] = {a.samples[3 * i], a.samples[3 * i + 1], a.samples[3 * i + 2]}, p[3];
+        uint32_t prio;
+        candidate_position(a, base, i, moved ? j : 0, epoch, wit, p, prio);
+        float al = (lpc == 1) ? alpha1(f, p, live && moved) : alpha4(f, p, sub, live && moved);
+        if (live && sub == 0) {
+            if (moved) {
+                a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
+                a.alpha[i] = al;
+            } else {
+                left += 1;
+            }
+            __hip_atomic_store(&winners_next[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // samples still invalid when the epoch's loop ended (stats[1]; 0 unless max_iterations cut it short)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) left += __shfl_xor(left, off, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = left;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (tot) atomicAdd(&a.stats[epoch * 4 + 1], tot);
+    }
+}
+
 __global__ void k_zero_u64(unsigned long long* p, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0ull;
@@ -403,6 +661,38 @@ hipError_t sampler_residency(int64_t P, int n_cus, int lpc, int B, int* wgs_per_
     return hipSuccess;
 }
 
+// IFF_SAMPLER_PERSISTENT=1 (environment, read at every call: a test switches it) keeps the one-launch form
+bool sampler_stepped() {
+    const char* v = getenv("IFF_SAMPLER_PERSISTENT");
+    return !(v && v[0] == '1');
+}
+
+static hipError_t launch_surface_sample_stepped(const FieldDev& f, SamplerArgs a, int B, hipStream_t s) {
+    const int64_t P = a.P;
+    const int lpc = a.lpc;
+    const int wgs_pts = (int)((P * lpc + 255) / 256);                    // one thread per (point, lane)
+    int64_t want = (5 * P * lpc + 255) / 256;                            // one thread per candidate of an iteration
+    if (want > 1024) want = 1024;
+    const int wgs_it = (int)want;
+    const size_t lds = (size_t)P * sizeof(int) * (a.cache_lds ? 5 : 1);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ss_iter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ss_iter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    a.wgs_per_query = wgs_it;
+    hipLaunchKernelGGL(k_ss_seed, dim3((unsigned)(wgs_pts * B)), dim3(256), 0, s, f, a, wgs_pts);
+    for (int epoch = 0; epoch < a.n_epochs; ++epoch) {
+        const int slots = a.max_iterations < SS_SLOTS ? a.max_iterations : SS_SLOTS;
+        for (int it = 0; it < slots; ++it)
+            hipLaunchKernelGGL((k_ss_iter<false>), dim3((unsigned)(wgs_it * B)), dim3(256), lds, s, f, a, wgs_it, epoch, it);
+        if (a.max_iterations > slots)
+            hipLaunchKernelGGL((k_ss_iter<true>), dim3((unsigned)B), dim3(256), lds, s, f, a, 1, epoch, slots);
+        hipLaunchKernelGGL(k_ss_apply, dim3((unsigned)(wgs_pts * B)), dim3(256), 0, s, f, a, wgs_pts, epoch);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int B, int64_t P, int n_epochs,
                                      int max_iterations, uint64_t seed, const uint64_t* seed_dev, float rho, float* samples,
                                      float* alpha, int* stats, void* ws, size_t ws_bytes, int n_cus, hipStream_t s) {
@@ -411,6 +701,21 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
         return hipErrorInvalidValue;
     const size_t per_query = sampler_workspace_bytes(P);
     if (ws_bytes < per_query * (size_t)B) return hipErrorInvalidValue;
+    if (sampler_stepped()) {
+        const int64_t n_words = (int64_t)(per_query * (size_t)B / 8);
+        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, (unsigned long long*)ws, n_words);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+        SamplerArgs a;
+        a.P = P; a.n_epochs = n_epochs; a.max_iterations = max_iterations;
+        a.seed_lo = (uint32_t)(seed & 0xffffffffu); a.seed_hi = (uint32_t)(seed >> 32);
+        a.seed_dev = (const unsigned long long*)seed_dev;
+        a.rho = rho; a.samples = samples; a.alpha = alpha; a.stats = stats; a.ws = (unsigned char*)ws;
+        a.occ_list = occ_list; a.n_occ = n_occ;
+        a.wgs_per_query = 0; a.ws_stride = per_query; a.lpc = sampler_lpc(f, B);
+        a.cache_lds = P <= SAMPLER_CACHE_POINTS ? 1 : 0;
+        return launch_surface_sample_stepped(f, a, B, s);
+    }
     // one group of workgroups per query; all groups must be co-resident (in-kernel barriers)
     int wgs = 0, capacity = 0;
     const int lpc = sampler_lpc(f, B);

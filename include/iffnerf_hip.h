@@ -222,12 +222,13 @@ int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t 
  * queries: run b draws with seed + b * IFF_SAMPLER_SEED_STRIDE (mod 2^64) and is bit-identical to the single call
  * with that seed.  samples [B,P,3], alpha [B,P], stats [B,n_epochs,4]; workspace B * iff_surface_sample_workspace(P). */
 #define IFF_SAMPLER_SEED_STRIDE 0x9E3779B97F4A7C15ull
-/* The sampler is one persistent launch whose workgroups meet at in-kernel barriers (sampling.py:143-213 is a loop of
- * data-dependent length), so all of them must be resident together.  wgs_per_run = workgroups of one run at P points
- * inside a launch of B runs (large batches use a form with a quarter of the workgroups per run); device_capacity =
- * sampler workgroups the device holds at once (from the kernel's register / LDS footprint).  A caller that keeps
- * several sampler launches in flight (streams, graphs) must keep sum(B * wgs_per_run) <= device_capacity; one batched
- * launch clamps itself. */
+/* The sampler runs as a chain of short launches (seeds; per epoch 8 iteration launches, a finisher for the rare run that needs
+ * more, the apply step), the kernel boundary being the grid barrier of sampling.py:143-213's loop: no workgroup waits for another
+ * one and nothing has to be resident together -- device_capacity is then INT32_MAX and wgs_per_run the workgroups of one run's
+ * iteration launch.  With IFF_SAMPLER_PERSISTENT=1 in the environment the sampler is ONE persistent launch whose workgroups meet
+ * at in-kernel barriers; all of them must then be resident together: device_capacity = sampler workgroups the device holds at
+ * once (from the kernel's register / LDS footprint), and a caller that keeps several sampler launches in flight (streams, graphs)
+ * must keep sum(B * wgs_per_run) <= device_capacity; one batched launch clamps itself.  Both forms draw the same samples bit for bit. */
 int iff_surface_sample_residency(const iff_field* f, int32_t B, int64_t P, int32_t* wgs_per_run, int32_t* device_capacity);
 int iff_surface_sample_batched(const iff_field* f, int32_t B, int64_t P, int32_t n_epochs, int32_t max_iterations,
                                uint64_t seed, const uint64_t* seed_dev_opt, float rho, float* samples, float* alpha,

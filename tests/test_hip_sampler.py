@@ -4,6 +4,8 @@ The reference consumes torch's CPU generator with data-dependent trip counts, so
 on the device: parity here is (i) the invariants the reference's algorithm guarantees, checked
 exactly, and (ii) agreement of the sample distribution with the oracle's (same algorithm, CPU generator).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -196,11 +198,43 @@ def test_batched_runs_large_point_counts_and_residency(small, dev):
             assert torch.equal(s[b], s1) and torch.equal(a[b], a1) and torch.equal(st[b], st1), (B, P, b)
         assert torch.equal(small.point_alpha(s.reshape(-1, 3)), a.reshape(-1))
         assert not torch.equal(s[0], s[1])
+    # the stepped form (default) has no co-residency requirement; the persistent form reports the device's capacity
     w1, cap = small.sampler_residency(593, 1)
     w16, cap16 = small.sampler_residency(593, 16)
-    assert cap == cap16 and cap >= 256 and w1 == 47 and w16 == 12          # 4 lanes / 1 lane per candidate at P = 593
-    w_big, _ = small.sampler_residency(20000, 1)
-    assert w_big <= 256                                                     # never more than one workgroup per CU and run
+    assert cap == cap16 == 2 ** 31 - 1 and w1 == 47 and w16 == 12          # 4 lanes / 1 lane per candidate at P = 593
+    os.environ["IFF_SAMPLER_PERSISTENT"] = "1"
+    try:
+        w1, cap = small.sampler_residency(593, 1)
+        w16, cap16 = small.sampler_residency(593, 16)
+        assert cap == cap16 and 256 <= cap < 2 ** 31 - 1 and w1 == 47 and w16 == 12
+        w_big, _ = small.sampler_residency(20000, 1)
+        assert w_big <= 256                                                 # never more than one workgroup per CU and run
+    finally:
+        del os.environ["IFF_SAMPLER_PERSISTENT"]
+
+
+def test_stepped_launches_equal_the_persistent_launch(small, dev):
+    """The sampler as a chain of short launches (the default: seeds | per epoch 8 iteration launches + finisher + apply, the kernel
+    boundary as the grid barrier) draws the SAME samples, alphas and statistics as the one persistent launch with in-kernel grid
+    barriers (IFF_SAMPLER_PERSISTENT=1), bit for bit: both lane forms, point counts below and above the LDS-cache limit, an
+    iteration bound below the number of static launches, and a jitter so small that an epoch needs more than the 8 static
+    iteration launches (the finisher's loop)."""
+    rho = rho_of(util.ckpt("small"))
+    cases = [(1, 593, rho, 4, 200), (16, 593, rho, 4, 200), (3, 5000, rho, 3, 200), (8, 300, rho, 2, 3), (2, 700, rho * 0.02, 2, 200),
+             (9, 400, rho * 0.02, 2, 12)]
+    long_epochs = 0
+    for B, P, r, E, mi in cases:
+        got = small.surface_sample_batched(B, P, r, n_epochs=E, max_iterations=mi, seed=4321)
+        os.environ["IFF_SAMPLER_PERSISTENT"] = "1"
+        try:
+            want = small.surface_sample_batched(B, P, r, n_epochs=E, max_iterations=mi, seed=4321)
+        finally:
+            del os.environ["IFF_SAMPLER_PERSISTENT"]
+        assert (want[2][..., 3] != -1).all(), "in-kernel barrier timed out"
+        for x, y, what in zip(got, want, ("samples", "alpha", "stats")):
+            assert torch.equal(x, y), (B, P, r, E, mi, what, (got[2] - want[2]).abs().max().item() if what == "stats" else None)
+        long_epochs += int((got[2][..., 0] > 8).sum())
+    assert long_epochs > 0, "no case went past the static iteration launches: the finisher was not exercised"
 
 
 def _philox_np(i, j, c2, seed):
@@ -270,3 +304,37 @@ def test_accept_and_pick_decisions_of_one_iteration(small, dev):
         chi2 = float(((c - n / k) ** 2 / (n / k)).sum())
         assert chi2 < crit[k], (k, c.tolist(), chi2)
     assert sum(c.sum() for c in counts.values()) > 2000
+
+
+def test_concurrent_replays_reproduce_the_sequential_result(small, dev):
+    """Four captured sampler launches (16 runs each) replayed side by side on their own streams, 30 rounds: every replay returns
+    the samples, alphas and statistics of the same graph replayed alone, bit for bit.  Next to other work the workgroups of one
+    launch start far apart in time; whatever a workgroup reads that another one of the same launch may be writing (the winner
+    slots, the converged flag) must not make its threads -- or the workgroups of a run -- disagree."""
+    rho, B, P = rho_of(util.ckpt("small")), 16, 593
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    graphs, outs, refs = [], [], []
+    for g in range(4):
+        with torch.cuda.stream(streams[g]):
+            small.surface_sample_batched(B, P, rho, 4, 200, seed=(g + 1) << 40)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=streams[g]):
+            out = small.surface_sample_batched(B, P, rho, 4, 200, seed=(g + 1) << 40)
+        graphs.append(gr)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for g in range(4):
+        graphs[g].replay()
+        torch.cuda.synchronize()
+        refs.append([t.clone() for t in outs[g]])
+        eager = small.surface_sample_batched(B, P, rho, 4, 200, seed=(g + 1) << 40)
+        assert all(torch.equal(x, y) for x, y in zip(eager, refs[g]))
+    for rnd in range(30):
+        for g in range(4):
+            with torch.cuda.stream(streams[g]):
+                graphs[g].replay()
+        torch.cuda.synchronize()
+        for g in range(4):
+            for x, y, what in zip(outs[g], refs[g], ("samples", "alpha", "stats")):
+                assert torch.equal(x, y), (rnd, g, what)
