@@ -387,8 +387,13 @@ struct SsRun {                           // one run's views, resolved from block
 };
 __device__ __forceinline__ SsRun ss_resolve(SamplerArgs& a, int wgs_per_run) {
     SsRun r;
-    r.q_id = (int)(blockIdx.x / (unsigned)wgs_per_run);
-    r.wg_id = (int)(blockIdx.x - (unsigned)r.q_id * (unsigned)wgs_per_run);
+    // Workgroups are dealt round-robin over the 8 XCDs (observed; speed only): give the workgroups that share an XCD consecutive
+    // run-major ids, so that a run's candidates -- which touch the same few hundred KB of density texels in every iteration -- stay
+    // with ONE XCD's 4-MB L2 instead of being spread over all eight (16 runs x 1.5 MB each then thrash every L2)
+    unsigned vb = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    r.q_id = (int)(vb / (unsigned)wgs_per_run);
+    r.wg_id = (int)(vb - (unsigned)r.q_id * (unsigned)wgs_per_run);
     unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) + (unsigned long long)r.q_id * 0x9E3779B97F4A7C15ull;
     if (a.seed_dev) sd += __hip_atomic_load(a.seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a.seed_lo = (uint32_t)(sd & 0xffffffffull); a.seed_hi = (uint32_t)(sd >> 32);
@@ -633,6 +638,7 @@ __global__ void k_zero_u64(unsigned long long* p, int64_t n) {
 int sampler_lpc(const FieldDev& f, int B) {
     if (f.n_density != 16 || f.density_lanes == 4) return 4;
     if (f.density_lanes == 1) return 1;
+    if (sampler_stepped()) return 4;          // no residency to economise on: the four-lane form needs a quarter of the texture-path cycles per candidate
     return B >= 8 ? 1 : 4;
 }
 

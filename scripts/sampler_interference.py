@@ -18,8 +18,9 @@ ori0, dirs0, rays0 = isocell_emit(pipe.cells, s0, nrm0, want_rays6=True)
 rgb0 = pipe.field.march(rays0, 0, 20, want_alpha=False)[0]
 qf0 = pipe.idnet.q_fold(tokens.reshape(B * M, -1))
 
-def capture(fn, n=4):
-    gs, ss = [], [torch.cuda.Stream(device=dev) for _ in range(n)]
+print("stream priority range (least, greatest):", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else None, flush=True)
+def capture(fn, n=4, priority=0):
+    gs, ss = [], [torch.cuda.Stream(device=dev, priority=priority) for _ in range(n)]
     for i in range(n):
         with torch.cuda.stream(ss[i]):
             fn(i)
@@ -43,10 +44,19 @@ def run(main, side, steps=200):
     t0 = time.perf_counter(); go(steps); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
-sampler = capture(lambda i: pipe.field.surface_sample_batched(B, P, pipe.rho, n_epochs=4, max_iterations=200, seed=77 + i))
-march = capture(lambda i: pipe.field.march(rays0, 0, 20, want_alpha=False))
-trunk = capture(lambda i: pipe.idnet.ray_logits_folded_batched(qf0, ori0, dirs0, rgb0, B))
+tiny = [torch.zeros(64, device=dev) for _ in range(4)]
+def empty_chain(i, n=int(os.environ.get("CHAIN", "42"))):
+    for _ in range(n):
+        tiny[i].add_(1.0)
+    return tiny[i]
+dummy = capture(empty_chain)
+MAIN_PRIO = int(os.environ.get("MAIN_PRIO", "0"))
+SIDE_PRIO = int(os.environ.get("SIDE_PRIO", "0"))
+sampler = capture(lambda i: pipe.field.surface_sample_batched(B, P, pipe.rho, n_epochs=4, max_iterations=200, seed=77 + i), priority=SIDE_PRIO)
+march = capture(lambda i: pipe.field.march(rays0, 0, 20, want_alpha=False), priority=MAIN_PRIO)
+trunk = capture(lambda i: pipe.idnet.ray_logits_folded_batched(qf0, ori0, dirs0, rgb0, B), priority=MAIN_PRIO)
 for name, m in (("march (fan kernel + head)", march), ("trunk", trunk)):
-    a, b = run(m, None), run(m, sampler)
-    print(json.dumps({"kernel": name, "ms_per_step_alone": round(a, 4), "ms_per_step_next_to_samplers": round(b, 4), "slowdown": round(b / a, 3)}), flush=True)
+    a, b, c = run(m, None), run(m, sampler), run(m, dummy)
+    print(json.dumps({"kernel": name, "ms_per_step_alone": round(a, 4), "ms_per_step_next_to_samplers": round(b, 4), "slowdown": round(b / a, 3),
+                      "ms_per_step_next_to_chains_of_empty_kernels": round(c, 4)}), flush=True)
 print(json.dumps({"sampler_alone_ms_per_launch_4_in_flight": round(run(sampler, None), 4)}))
