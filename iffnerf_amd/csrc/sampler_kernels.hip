@@ -374,11 +374,13 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
 //   k_ss_iter        iteration `it` of `epoch` for every run that still has invalid samples: every workgroup rebuilds the run's
 //                    ascending list of invalid samples from the winner slots (it == 0: also the epoch's threshold, which workgroup
 //                    0 of the run leaves in the workspace for the later launches), then its share of the 5 P candidates
-//   k_ss_finish      iterations S, S + 1, ... up to max_iterations for a run that has not converged after the S static launches
+//   k_ss_iter<true>  (the finisher) iterations S, S + 1, ... up to max_iterations for a run that has not converged after the S static launches
 //                    (one workgroup per run looping with workgroup barriers; returns at once otherwise -- the reference's bound
 //                    of 200 iterations is kept, 3-6 are observed on every bench model)
 //   k_ss_apply       the accepted samples move to their winning candidate (sampling.py:205-213); per-epoch statistics
-constexpr int SS_SLOTS = 8;              // static iteration launches per epoch
+// static iteration launches per epoch: the first epoch moves every sample (5-6 iterations on the bench models), the later ones only
+// the 40 % below the new quantile (3); a run that needs more continues in the finisher.  An idle launch costs 4.6 us of the chain
+__host__ __device__ inline int ss_slots(int epoch) { return epoch == 0 ? 8 : 5; }
 
 struct SsRun {                           // one run's views, resolved from blockIdx
     int q_id, wg_id;
@@ -506,13 +508,10 @@ __device__ inline int ss_build_list(const unsigned long long* winners, int P, in
     return K;
 }
 
-// one iteration of one run by `wgs` workgroups (this one is number wg_id): list, candidate budget, candidates.  Returns the number
-// of invalid samples it found (0: nothing was done).  `thresh`, s_alpha / s_pos are the caller's
-__device__ inline int ss_iteration(const FieldDev& f, const SamplerArgs& a, unsigned long long* winners, int epoch, int it, int wg_id, int wgs,
-                                   float thresh, int* s_list, const float* s_pos, int* s_tot, int& m_out) {
+// the candidates of iteration `it`: K invalid samples (s_list), m = 5 P / K candidates each, this workgroup's share
+__device__ inline void ss_candidates(const FieldDev& f, const SamplerArgs& a, unsigned long long* winners, int epoch, int it, int wg_id, int wgs,
+                                     float thresh, int K, const int* s_list, const float* s_pos, int& m_out) {
     const int P = (int)a.P, lpc = a.lpc, lsh = (a.lpc == 4) ? 2 : 0;
-    const int K = ss_build_list(winners, P, it, s_list, s_tot);
-    if (K == 0) return 0;
     const int64_t gtid = wg_id * (int64_t)blockDim.x + threadIdx.x, gthreads = (int64_t)wgs * blockDim.x;
     const int m = (5 * P) / K;
     m_out = m;
@@ -533,6 +532,42 @@ __device__ inline int ss_iteration(const FieldDev& f, const SamplerArgs& a, unsi
             atomicMax(&winners[i], key);
         }
     }
+}
+
+// The list from winner slots that are already in registers (chunk c of this wave = samples w0 + 64 c + lane): the iteration launch
+// requests them together with the positions and the converged flag, so that ONE memory round trip precedes the candidates
+template <int NW>
+__device__ inline int ss_build_list_regs(const unsigned long long (&wv)[NW], int nch, int w0, int w1, int it, int* s_list, int* s_tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < NW; ++c)
+        if (c < nch) cnt += __popcll(__ballot(w0 + 64 * c + lane < w1 && ss_still_invalid(wv[c], it)));
+    if (lane == 0) s_tot[wave] = cnt;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_tot[w];
+    const int K = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+#pragma unroll
+    for (int c = 0; c < NW; ++c)
+        if (c < nch) {
+            const int i = w0 + 64 * c + lane;
+            const bool stay = i < w1 && ss_still_invalid(wv[c], it);
+            const unsigned long long bal = __ballot(stay);
+            if (stay) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            base += __popcll(bal);
+        }
+    __syncthreads();
+    return K;
+}
+
+// one iteration of one run by `wgs` workgroups (this one is number wg_id): list, candidate budget, candidates.  Returns the number
+// of invalid samples it found (0: nothing was done).  `thresh`, s_alpha / s_pos are the caller's
+__device__ inline int ss_iteration(const FieldDev& f, const SamplerArgs& a, unsigned long long* winners, int epoch, int it, int wg_id, int wgs,
+                                   float thresh, int* s_list, const float* s_pos, int* s_tot, int& m_out) {
+    const int K = ss_build_list(winners, (int)a.P, it, s_list, s_tot);
+    if (K == 0) return 0;
+    ss_candidates(f, a, winners, epoch, it, wg_id, wgs, thresh, K, s_list, s_pos, m_out);
     return K;
 }
 
@@ -545,14 +580,52 @@ __global__ void __launch_bounds__(256) k_ss_iter(FieldDev f, SamplerArgs a, int 
     __shared__ int s_done;
     const SsRun r = ss_resolve(a, wgs_per_run);
     const int P = (int)a.P, tid = threadIdx.x;
-    // this run's epoch has converged already?  ONE read per workgroup: workgroup 0 of this very launch may be setting the flag, and
-    // threads of one workgroup that read it at different times would part ways before a workgroup barrier
-    if (tid == 0) s_done = __hip_atomic_load(&r.ws->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_done == epoch + 1) return;
     unsigned long long* winners = r.winners_base + (size_t)(epoch & 1) * P;
     float* s_alpha = reinterpret_cast<float*>(s_list + P);
     float* s_pos = s_alpha + P;
+    // this run's epoch has converged already?  ONE read per workgroup: workgroup 0 of this very launch may be setting the flag, and
+    // threads of one workgroup that read it at different times would part ways before a workgroup barrier
+    constexpr int NW = 10;
+    if (!FINISH && a.cache_lds && P <= 256 * NW) {
+        // the short chain: winner slots, converged flag, positions (and alphas) requested together -- one memory round trip -- then the
+        // list from registers, then the candidates.  An iteration launch holds its slots for ~10 us next to the other steps' kernels
+        // (752 workgroups whose waves each block a fan-march or trunk wave meanwhile): every round trip less is throughput
+        const int lane = tid & 63, wave = tid >> 6, nch = (P + 255) / 256;
+        const int w0 = wave * nch * 64, w1 = min(P, w0 + nch * 64);
+        unsigned long long wv[NW];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            const int i = w0 + 64 * c + lane;
+            wv[c] = (c < nch && i < w1) ? __hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        if (tid == 0) s_done = __hip_atomic_load(&r.ws->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t = tid; t < P; t += 256) {
+            if (it0 == 0) s_alpha[t] = a.alpha[t];
+            s_pos[3 * t] = a.samples[3 * t]; s_pos[3 * t + 1] = a.samples[3 * t + 1]; s_pos[3 * t + 2] = a.samples[3 * t + 2];
+        }
+        __syncthreads();
+        if (s_done == epoch + 1) return;
+        float thresh;
+        if (it0 == 0) {
+            thresh = ss_threshold(s_alpha, P, hist);
+            if (r.wg_id == 0 && tid == 0) { r.ws->thresh = thresh; a.stats[epoch * 4 + 2] = __float_as_int(thresh); }
+        } else {
+            thresh = r.ws->thresh;
+        }
+        if (it0 >= a.max_iterations) return;
+        const int K = ss_build_list_regs<NW>(wv, nch, w0, w1, it0, s_list, s_tot);
+        if (K == 0) {
+            if (r.wg_id == 0 && tid == 0) __hip_atomic_store(&r.ws->done_epoch, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        int m = 0;
+        ss_candidates(f, a, winners, epoch, it0, r.wg_id, wgs_per_run, thresh, K, s_list, s_pos, m);
+        if (r.wg_id == 0 && tid == 0) { a.stats[epoch * 4 + 0] = it0 + 1; a.stats[epoch * 4 + 3] = m; }
+        return;
+    }
+    if (tid == 0) s_done = __hip_atomic_load(&r.ws->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_done == epoch + 1) return;
     if (a.cache_lds) {
         for (int t = tid; t < P; t += 256) {
             if (it0 == 0) s_alpha[t] = a.alpha[t];
@@ -689,7 +762,7 @@ static hipError_t launch_surface_sample_stepped(const FieldDev& f, SamplerArgs a
     a.wgs_per_query = wgs_it;
     hipLaunchKernelGGL(k_ss_seed, dim3((unsigned)(wgs_pts * B)), dim3(256), 0, s, f, a, wgs_pts);
     for (int epoch = 0; epoch < a.n_epochs; ++epoch) {
-        const int slots = a.max_iterations < SS_SLOTS ? a.max_iterations : SS_SLOTS;
+        const int slots = a.max_iterations < ss_slots(epoch) ? a.max_iterations : ss_slots(epoch);
         for (int it = 0; it < slots; ++it)
             hipLaunchKernelGGL((k_ss_iter<false>), dim3((unsigned)(wgs_it * B)), dim3(256), lds, s, f, a, wgs_it, epoch, it);
         if (a.max_iterations > slots)

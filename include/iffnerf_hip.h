@@ -222,7 +222,7 @@ int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t 
  * queries: run b draws with seed + b * IFF_SAMPLER_SEED_STRIDE (mod 2^64) and is bit-identical to the single call
  * with that seed.  samples [B,P,3], alpha [B,P], stats [B,n_epochs,4]; workspace B * iff_surface_sample_workspace(P). */
 #define IFF_SAMPLER_SEED_STRIDE 0x9E3779B97F4A7C15ull
-/* The sampler runs as a chain of short launches (seeds; per epoch 8 iteration launches, a finisher for the rare run that needs
+/* The sampler runs as a chain of short launches (seeds; per epoch 8 (first epoch) or 5 iteration launches, a finisher for the rare run that needs
  * more, the apply step), the kernel boundary being the grid barrier of sampling.py:143-213's loop: no workgroup waits for another
  * one and nothing has to be resident together -- device_capacity is then INT32_MAX and wgs_per_run the workgroups of one run's
  * iteration launch.  With IFF_SAMPLER_PERSISTENT=1 in the environment the sampler is ONE persistent launch whose workgroups meet
