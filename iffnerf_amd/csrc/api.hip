@@ -365,7 +365,7 @@ extern "C" int iff_surface_sample_residency(const iff_field* f, int32_t B, int64
     int w = 0, c = 0;
     IFF_HIP(sampler_residency(P, f->n_cus, sampler_lpc(f->dev, B), B, &w, &c));
     if (sampler_stepped()) {       // no workgroup waits for another one: nothing has to be resident together
-        const int64_t want = (5 * P * sampler_lpc(f->dev, B) + 255) / 256;
+        const int64_t want = (5 * P * (f->dev.density_lanes == 0 ? 1 : sampler_lpc(f->dev, B)) + 255) / 256;     // quad form: one lane per candidate
         w = (int)(want > 1024 ? 1024 : want);
         c = 0x7fffffff;
     }

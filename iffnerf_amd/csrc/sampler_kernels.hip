@@ -119,6 +119,36 @@ __device__ inline float alpha4(const FieldDev& f, const float p[3], int sub, boo
     return 1.0f - expf(-sigma * 1.0f);
 }
 
+// One candidate per lane for everything that is per candidate (random stream, position, occupancy test), and the density taps of
+// the four candidates of a quad gathered by the quad TOGETHER, candidate after candidate, each lane one 16-B texel quarter (the
+// positions go round the quad as DPP moves): the coalesced loads of the four-lane form (a quarter of the texture-path cycles of
+// the one-lane form) with a quarter of its waves and half its vector instructions.  Same bits as alpha4 / alpha1.
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {          // lane (l & ~3) + Q's value: quad_perm [Q,Q,Q,Q]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), Q * 0x55, 0xF, 0xF, true));
+}
+template <int Q>
+__device__ __forceinline__ void alpha_quad_step(const FieldDev& f, const float xn[3], bool valid, int sub, float& feat) {
+    const float xq[3] = {quad_bcast<Q>(xn[0]), quad_bcast<Q>(xn[1]), quad_bcast<Q>(xn[2])};
+    const bool vq = quad_bcast<Q>(valid ? 1.0f : 0.0f) != 0.0f;
+    const float fq = sum4(vq ? density_partial(f, xq, sub) : 0.0f);
+    if (sub == Q) feat = fq;
+}
+__device__ inline float alpha_quad(const FieldDev& f, const float p[3], bool live) {
+    float xn[3];
+    field_normalize(f, p, xn);
+    const float mv = f.mask ? mask_value(f, p) : 1.0f;
+    const bool valid = live && (mv > 0.0f);
+    const int sub = threadIdx.x & 3;
+    float feat = 0.0f;
+    alpha_quad_step<0>(f, xn, valid, sub, feat);
+    alpha_quad_step<1>(f, xn, valid, sub, feat);
+    alpha_quad_step<2>(f, xn, valid, sub, feat);
+    alpha_quad_step<3>(f, xn, valid, sub, feat);
+    const float sigma = valid ? feature2density(f, feat) : 0.0f;
+    return 1.0f - expf(-sigma * 1.0f);
+}
+
 struct SamplerArgs {
     int64_t P;
     int n_epochs, max_iterations;
@@ -135,6 +165,7 @@ struct SamplerArgs {
     size_t ws_stride;      // bytes between the queries' workspaces
     int lpc;               // lanes per candidate / point: 4 (one texel quarter each) or 1 (n_density == 16)
     int cache_lds;         // every workgroup keeps this epoch's alpha [P] and positions [P,3] in LDS (P <= SAMPLER_CACHE_POINTS)
+    int quad;              // lpc == 1 with the density taps gathered per quad (alpha_quad): the stepped form's default
 };
 
 // jittered candidate j of sample i (sampling.py:38-66): theta = 2 pi u, phi = arccos(1 - 2u), radius |N(0, rho)|
@@ -434,7 +465,7 @@ __global__ void __launch_bounds__(256) k_ss_seed(FieldDev f, SamplerArgs a, int 
 #pragma unroll
             for (int c = 0; c < 3; ++c) p[c] = u[c] * (f.aabb_hi[c] - f.aabb_lo[c]) + f.aabb_lo[c];
         }
-        float al = (lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live);
+        float al = a.quad ? alpha_quad(f, p, live) : ((lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live));
         if (live && sub == 0) {
             a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
             a.alpha[i] = al;
@@ -526,7 +557,7 @@ __device__ inline void ss_candidates(const FieldDev& f, const SamplerArgs& a, un
         float base[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]}, p[3];
         uint32_t prio;
         candidate_position(a, base, i, j, epoch, it, p, prio);
-        float al = (lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live);
+        float al = a.quad ? alpha_quad(f, p, live) : ((lpc == 1) ? alpha1(f, p, live) : alpha4(f, p, sub, live));
         if (live && sub == 0 && al > thresh) {
             unsigned long long key = ((unsigned long long)prio << 32) | ((unsigned long long)it << 20) | (unsigned long long)(unsigned)(j + 1);
             atomicMax(&winners[i], key);
@@ -673,7 +704,7 @@ __global__ void __launch_bounds__(256) k_ss_apply(FieldDev f, SamplerArgs a, int
         float base[3] = {a.samples[3 * i], a.samples[3 * i + 1], a.samples[3 * i + 2]}, p[3];
         uint32_t prio;
         candidate_position(a, base, i, moved ? j : 0, epoch, wit, p, prio);
-        float al = (lpc == 1) ? alpha1(f, p, live && moved) : alpha4(f, p, sub, live && moved);
+        float al = a.quad ? alpha_quad(f, p, live && moved) : ((lpc == 1) ? alpha1(f, p, live && moved) : alpha4(f, p, sub, live && moved));
         if (live && sub == 0) {
             if (moved) {
                 a.samples[3 * i] = p[0]; a.samples[3 * i + 1] = p[1]; a.samples[3 * i + 2] = p[2];
@@ -711,7 +742,7 @@ __global__ void k_zero_u64(unsigned long long* p, int64_t n) {
 int sampler_lpc(const FieldDev& f, int B) {
     if (f.n_density != 16 || f.density_lanes == 4) return 4;
     if (f.density_lanes == 1) return 1;
-    if (sampler_stepped()) return 4;          // no residency to economise on: the four-lane form needs a quarter of the texture-path cycles per candidate
+    if (sampler_stepped()) return 4;          // (the stepped form's default is the quad form: launch_surface_sample_occ; 4 = its footprint class)
     return B >= 8 ? 1 : 4;
 }
 
@@ -792,6 +823,8 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
         a.rho = rho; a.samples = samples; a.alpha = alpha; a.stats = stats; a.ws = (unsigned char*)ws;
         a.occ_list = occ_list; a.n_occ = n_occ;
         a.wgs_per_query = 0; a.ws_stride = per_query; a.lpc = sampler_lpc(f, B);
+        a.quad = f.density_lanes == 0 ? 1 : 0;           // iff_field_desc.density_lanes = 1 / 4 name the plain one- / four-lane forms
+        if (a.quad) a.lpc = 1;
         a.cache_lds = P <= SAMPLER_CACHE_POINTS ? 1 : 0;
         return launch_surface_sample_stepped(f, a, B, s);
     }
@@ -817,7 +850,7 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
     a.seed_dev = (const unsigned long long*)seed_dev;
     a.rho = rho; a.samples = samples; a.alpha = alpha; a.stats = stats; a.ws = (unsigned char*)ws;
     a.occ_list = occ_list; a.n_occ = n_occ;
-    a.wgs_per_query = wgs; a.ws_stride = per_query; a.lpc = lpc;
+    a.wgs_per_query = wgs; a.ws_stride = per_query; a.lpc = lpc; a.quad = 0;
     a.cache_lds = P <= SAMPLER_CACHE_POINTS ? 1 : 0;
     const size_t lds = (size_t)P * sizeof(int) * (a.cache_lds ? 5 : 1);
     if (lds > 48 * 1024) {

@@ -200,7 +200,7 @@ def test_batched_runs_large_point_counts_and_residency(small, dev):
     # the stepped form (default) has no co-residency requirement; the persistent form reports the device's capacity
     w1, cap = small.sampler_residency(593, 1)
     w16, cap16 = small.sampler_residency(593, 16)
-    assert cap == cap16 == 2 ** 31 - 1 and w1 == 47 and w16 == 47          # 4 lanes per candidate at P = 593 whatever the batch
+    assert cap == cap16 == 2 ** 31 - 1 and w1 == 12 and w16 == 12          # one lane per candidate at P = 593 (quad form) whatever the batch
     os.environ["IFF_SAMPLER_PERSISTENT"] = "1"
     try:
         w1, cap = small.sampler_residency(593, 1)
