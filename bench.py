@@ -193,8 +193,9 @@ def main():
     # issued eagerly between them (N > 1), replayed round-robin on their own streams, so the latency-bound surface sampler
     # of one step overlaps the throughput-bound stages of another.  Every replay bumps a device-side counter that is added
     # to the sampler seeds: no two steps draw the same rays.  At N > 1 all steps use the one default process group, so
-    # every rank issues the collectives in the same order.  The persistent samplers of all in-flight steps must be
-    # co-resident (their workgroups meet at in-kernel barriers): the count is clamped to what the device holds.
+    # every rank issues the collectives in the same order.  With the persistent form of the sampler (IFF_SAMPLER_PERSISTENT=1) the
+    # samplers of all in-flight steps must be co-resident (their workgroups meet at in-kernel barriers): the count is clamped to
+    # what the device holds; the default chain of short launches has no such limit.
     n_sampler_runs = 1 if shared else B
     in_flight = max(1, min(args.in_flight, pipe.max_steps_in_flight(gen_points, n_sampler_runs)))
     streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]

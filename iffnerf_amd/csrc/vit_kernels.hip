@@ -113,6 +113,19 @@ constexpr int GBN = 128, GBK = 64, GLD = GBK + 8;      // LDS rows padded to 144
 
 // GBM = 128 (a wave: 64 features x 64 tokens) or 64 (64 x 32: twice the workgroups for the N = 384 products, which would
 // otherwise occupy 99 of the 256 CUs)
+// erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26): the GELU output is rounded to bf16 (4e-3 relative) right after, and erff's
+// ~40 instructions per value were half of the MLP's first GEMM (32 values per thread against 48 MFMAs per wave)
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+
 template <int EPI, int GBM>
 __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt, int64_t M, int N, int K,
                                                      GemmEpi e) {
@@ -131,9 +144,11 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
         for (int b = 0; b < MB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    // a 128-row tile is 128 x 64 bf16 = 1024 chunks of 16 B: 4 per thread; the token tile 4 or 2
-    bf16x8 gw[4], gx[2 * MB];
-    auto fetch = [&](int k0) {
+    // a 128-row tile is 128 x 64 bf16 = 1024 chunks of 16 B: 4 per thread; the token tile 4 or 2.  TWO k tiles are in flight in
+    // registers (sets A and B, the k loop unrolled by two): a k step is 8-16 MFMAs per wave, a third of the latency of the tile
+    // that travels, and one tile ahead left every step waiting for it (K / GBK is even for every GEMM of the network: 6, 24, 10)
+    bf16x8 gwA[4], gxA[2 * MB], gwB[4], gxB[2 * MB];
+    auto fetch = [&](bf16x8 (&gw)[4], bf16x8 (&gx)[2 * MB], int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
@@ -146,8 +161,7 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
             gx[r] = *reinterpret_cast<const bf16x8*>(X + m * K + k0 + kc);
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += GBK) {
+    auto step = [&](bf16x8 (&gw)[4], bf16x8 (&gx)[2 * MB], int k_next) {
         __syncthreads();                       // the previous step's fragments have been read
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -160,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
             *reinterpret_cast<bf16x8*>(&sX[row][kc]) = gx[r];
         }
         __syncthreads();
-        if (k0 + GBK < K) fetch(k0 + GBK);     // the next tile travels while this one is multiplied
+        if (k_next < K) fetch(gw, gx, k_next);     // this set's next tile (two steps ahead) travels while two tiles are multiplied
 #pragma unroll
         for (int ks = 0; ks < GBK / 16; ++ks) {
             bf16x8 fa[2], fb[MB];
@@ -173,6 +187,12 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
 #pragma unroll
                 for (int b = 0; b < MB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
+    };
+    fetch(gwA, gxA, 0);
+    if (GBK < K) fetch(gwB, gxB, GBK);
+    for (int k0 = 0; k0 < K; k0 += 2 * GBK) {
+        step(gwA, gxA, k0 + 2 * GBK);
+        if (k0 + GBK < K) step(gwB, gxB, k0 + 3 * GBK);
     }
     // D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh: four consecutive n per reg group
 #pragma unroll
@@ -187,17 +207,18 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
                 const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
                 float v[4] = {acc[a][b][4 * g4] + bi.x, acc[a][b][4 * g4 + 1] + bi.y, acc[a][b][4 * g4 + 2] + bi.z, acc[a][b][4 * g4 + 3] + bi.w};
                 if (EPI == EPI_QKV) {
-                    const int D = N / 3, which = n / D, c = n - which * D, head = c >> 6, d = c & 63;
-                    const int64_t img = m / e.T;
-                    const int t = (int)(m - img * e.T);
-                    __bf16* dst = (which == 0 ? e.q : (which == 1 ? e.k : e.v)) + (((img * e.heads + head) * e.T + t) << 6) + d;
+                    // a 128-column tile lies inside one of q / k / v (D = 384 = 3 x 128): `which` is the workgroup's, not the element's
+                    const int D = N / 3, which = n0 / D, c = n - which * D, head = c >> 6, d = c & 63;
+                    const int img = (int)m / e.T;
+                    const int t = (int)m - img * e.T;
+                    __bf16* dst = (which == 0 ? e.q : (which == 1 ? e.k : e.v)) + (((int64_t)(img * e.heads + head) * e.T + t) << 6) + d;
                     const float sc = which == 0 ? e.qscale : 1.0f;
                     bf16x4 o = {(__bf16)(v[0] * sc), (__bf16)(v[1] * sc), (__bf16)(v[2] * sc), (__bf16)(v[3] * sc)};
                     *reinterpret_cast<bf16x4*>(dst) = o;
                 } else if (EPI == EPI_GELU) {
                     bf16x4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f)));
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752440f)));
                     *reinterpret_cast<bf16x4*>(e.out + m * N + n) = o;
                 } else if (EPI == EPI_RESID) {
                     const float4 ls = *reinterpret_cast<const float4*>(e.ls + n);

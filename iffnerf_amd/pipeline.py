@@ -178,8 +178,9 @@ class PosePipeline:
         return c2w, idx, val
 
     def max_steps_in_flight(self, gen_points: int, batch: int = 1) -> int:
-        """How many query graphs (each running ``batch`` samplers) may be in flight at once: the persistent sampler's
-        workgroups meet at in-kernel barriers, so the samplers of ALL in-flight graphs must fit on the device together."""
+        """How many query graphs (each running ``batch`` samplers) may be in flight at once.  The default sampler (a chain of short
+        launches) sets no limit; the persistent form's workgroups (IFF_SAMPLER_PERSISTENT=1) meet at in-kernel barriers, so the
+        samplers of ALL in-flight graphs must then fit on the device together (iff_surface_sample_residency)."""
         wgs, capacity = self.field.sampler_residency(gen_points, batch)
         return max(1, capacity // max(1, wgs * batch))
 

@@ -217,7 +217,7 @@ WORKLOADS = {
         field=dict(grid=(640, 640, 640), aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), mask_res=(256, 256, 256), seed=777,
                    step_ratio=0.5, peak=20.0, near_far=(0.01, 1.4), contraction_type="unisphere", density_shift=0.0,
                    density_offset=-10.0, blob_sigma=0.30, mask_radius=0.62),
-        gen_points=2371, queries=8, shared_rays=False,      # 8 x 47 sampler workgroups: two steps' samplers fit the device together
+        gen_points=2371, queries=8, shared_rays=False,
         describe="bicycle-shaped TensorVMSplit 640^3, unisphere contraction, density_shift 0, gen_points=2371 -> 64017 rays"),
     # the reference's DEFAULT operating point: explore_model(model, gen_points=20000) (pose_estimation/model_utils.py:22-24) ->
     # 540 000 rays on the lego-shaped model; 553 MB of logits per query image (identification_module.py:165)
