@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--config", default="lego16k", choices=("lego16k", "truck32k", "bicycle64k", "lego_b64", "lego540k"),
                     help="BASELINE.json workload (default: configs[1], the one the metric is quoted on)")
     ap.add_argument("--in-flight", type=int, default=4, help="steps kept in flight on separate streams")
-    ap.add_argument("--batch", type=int, default=0, help="queries per step and rank (default: the workload's: 16, bicycle64k: 8, lego_b64: 64)")
+    ap.add_argument("--batch", type=int, default=0, help="queries per step and rank (default: the workload's: lego16k 32, truck32k 16, bicycle64k 8, lego540k 2, lego_b64 64)")
     ap.add_argument("--gemm", default="auto", choices=("auto", "bf16x3", "f16x2"),
                     help="matrix-product arithmetic of the encoder / logits (both fp32-accurate; DESIGN.md section 4)")
     ap.add_argument("--trunk-variant", type=int, default=0, help="work split of the fused F16X2 launch (0 = default; tuning)")
