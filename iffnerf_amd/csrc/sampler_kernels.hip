@@ -48,11 +48,13 @@ struct SamplerWs {
     unsigned abort_flag;
     float thresh;               // stepped form: this epoch's threshold, written by the epoch's first iteration launch
     int done_epoch;             // stepped form: epoch + 1 once an iteration launch found no invalid sample left in `epoch`
-    unsigned pad[60];
+    int K_list;                 // stepped form, large P: entries of list[] (k_ss_list -> k_ss_cand)
+    unsigned pad[59];
     // followed by: winners[2][P] (u64, double-buffered by epoch parity)
 };
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-size_t sampler_workspace_bytes(int64_t P) { return align_up(sizeof(SamplerWs), 256) + align_up((size_t)P * 16, 256); }
+// header | winners[2][P] u64 | list[P] i32 (the stepped form's invalid list of a run when P is large: k_ss_list)
+size_t sampler_workspace_bytes(int64_t P) { return align_up(sizeof(SamplerWs), 256) + align_up((size_t)P * 16, 256) + align_up((size_t)P * 4, 256); }
 
 // ------------------------------------------------------------------------------------------------ grid barriers
 // Placement-independent (cdna guide, Guideline 16).  FENCED: every wave drains its stores, workgroup barrier, lane 0
@@ -412,6 +414,7 @@ __global__ void __launch_bounds__(256) k_surface_sample(FieldDev f, SamplerArgs 
 // static iteration launches per epoch: the first epoch moves every sample (5-6 iterations on the bench models), the later ones only
 // the 40 % below the new quantile (3); a run that needs more continues in the finisher.  An idle launch costs 4.6 us of the chain
 __host__ __device__ inline int ss_slots(int epoch) { return epoch == 0 ? 8 : 5; }
+constexpr int SS_SMALL_P = 2560;         // up to here an iteration is ONE launch whose workgroups each rebuild the run's list (k_ss_iter)
 
 struct SsRun {                           // one run's views, resolved from blockIdx
     int q_id, wg_id;
@@ -475,7 +478,8 @@ __global__ void __launch_bounds__(256) k_ss_seed(FieldDev f, SamplerArgs a, int 
 
 // threshold = torch.quantile(alpha, 0.6), linear interpolation (the persistent form's code): every thread of the workgroup returns it
 __device__ inline float ss_threshold(const float* alpha_src, int P, int* hist) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_red[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     float pos = 0.6f * (float)(P - 1);
     int lo = (int)floorf(pos);
     int hi = min(lo + 1, P - 1);
@@ -483,7 +487,7 @@ __device__ inline float ss_threshold(const float* alpha_src, int P, int* hist) {
     const uint32_t klo = iff_wg_select_key<false>(alpha_src, P, lo + 1, hist);
     int cnt_le = 0;
     uint32_t kmin = 0xffffffffu;
-    for (int t = tid; t < P; t += 256) {
+    for (int t = tid; t < P; t += (int)blockDim.x) {
         uint32_t key = iff_order_key(alpha_src[t]);
         cnt_le += (key <= klo) ? 1 : 0;
         kmin = (key > klo && key < kmin) ? key : kmin;
@@ -494,12 +498,14 @@ __device__ inline float ss_threshold(const float* alpha_src, int P, int* hist) {
         uint32_t o = (uint32_t)__shfl_xor((int)kmin, off, 64);
         kmin = o < kmin ? o : kmin;
     }
-    if (lane == 0) { hist[wave] = cnt_le; hist[4 + wave] = (int)kmin; }
+    if (lane == 0) { s_red[wave] = cnt_le; s_red[16 + wave] = (int)kmin; }
     __syncthreads();
-    cnt_le = hist[0] + hist[1] + hist[2] + hist[3];
-    kmin = (uint32_t)hist[4];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) kmin = (uint32_t)hist[4 + w] < kmin ? (uint32_t)hist[4 + w] : kmin;
+    cnt_le = 0;
+    kmin = 0xffffffffu;
+    for (int w = 0; w < nwave; ++w) {
+        cnt_le += s_red[w];
+        kmin = (uint32_t)s_red[16 + w] < kmin ? (uint32_t)s_red[16 + w] : kmin;
+    }
     __syncthreads();
     const uint32_t khi = (hi == lo || cnt_le >= hi + 1) ? klo : kmin;
     float vlo = iff_order_key_inv(klo);
@@ -616,8 +622,8 @@ __global__ void __launch_bounds__(256) k_ss_iter(FieldDev f, SamplerArgs a, int 
     float* s_pos = s_alpha + P;
     // this run's epoch has converged already?  ONE read per workgroup: workgroup 0 of this very launch may be setting the flag, and
     // threads of one workgroup that read it at different times would part ways before a workgroup barrier
-    constexpr int NW = 10;
-    if (!FINISH && a.cache_lds && P <= 256 * NW) {
+    constexpr int NW = SS_SMALL_P / 256;
+    if (!FINISH && a.cache_lds && P <= SS_SMALL_P) {
         // the short chain: winner slots, converged flag, positions (and alphas) requested together -- one memory round trip -- then the
         // list from registers, then the candidates.  An iteration launch holds its slots for ~10 us next to the other steps' kernels
         // (752 workgroups whose waves each block a fan-march or trunk wave meanwhile): every round trip less is throughput
@@ -683,6 +689,68 @@ __global__ void __launch_bounds__(256) k_ss_iter(FieldDev f, SamplerArgs a, int 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's atomics have reached the memory side
         __syncthreads();
     }
+}
+
+// ---- large P (> 2560): an iteration is TWO launches.  k_ss_list: one 1024-thread workgroup per run writes the run's list of invalid
+// samples (and, in the epoch's first iteration, the threshold) to the workspace -- with thousands of samples, every one of a run's
+// ~400 candidate workgroups rebuilding the list for itself reads the winner slots 400 times over (measured on the reference's
+// default P = 20 000: 316 poses/s against 369 with the persistent form).  k_ss_cand: the candidates, list entries read from there.
+constexpr int SS_LIST_THREADS = 1024;
+__global__ void __launch_bounds__(SS_LIST_THREADS) k_ss_list(FieldDev f, SamplerArgs a, int epoch, int it) {
+    __shared__ int hist[264];
+    __shared__ int s_tot16[16];
+    __shared__ int s_done;
+    const SsRun r = ss_resolve(a, 1);
+    const int P = (int)a.P, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_done = __hip_atomic_load(&r.ws->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_done == epoch + 1) return;
+    unsigned long long* winners = r.winners_base + (size_t)(epoch & 1) * P;
+    int* list = reinterpret_cast<int*>(a.ws + align_up(sizeof(SamplerWs), 256) + align_up((size_t)P * 16, 256));
+    if (it == 0) {
+        const float thresh = ss_threshold(a.alpha, P, hist);
+        if (tid == 0) { r.ws->thresh = thresh; a.stats[epoch * 4 + 2] = __float_as_int(thresh); }
+    }
+    // each of the 16 waves owns a contiguous sixteenth of the samples: count, wave totals through LDS, write
+    const int per_wave = ((P + SS_LIST_THREADS - 1) / SS_LIST_THREADS) * 64;
+    const int w0 = wave * per_wave, w1 = min(P, w0 + per_wave);
+    int cnt = 0;
+    for (int c0 = w0; c0 < w1; c0 += 64) {
+        const int i = c0 + lane;
+        const bool stay = i < w1 && ss_still_invalid(__hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), it);
+        cnt += __popcll(__ballot(stay));
+    }
+    if (lane == 0) s_tot16[wave] = cnt;
+    __syncthreads();
+    int base = 0, K = 0;
+    for (int w = 0; w < SS_LIST_THREADS / 64; ++w) { base += w < wave ? s_tot16[w] : 0; K += s_tot16[w]; }
+    for (int c0 = w0; c0 < w1; c0 += 64) {
+        const int i = c0 + lane;
+        const bool stay = i < w1 && ss_still_invalid(__hip_atomic_load(&winners[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), it);
+        const unsigned long long bal = __ballot(stay);
+        if (stay) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        base += __popcll(bal);
+    }
+    if (tid == 0) {
+        r.ws->K_list = K;
+        if (K == 0) __hip_atomic_store(&r.ws->done_epoch, epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else { a.stats[epoch * 4 + 0] = it + 1; a.stats[epoch * 4 + 3] = (5 * P) / K; }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ss_cand(FieldDev f, SamplerArgs a, int wgs_per_run, int epoch, int it) {
+    const SsRun r = ss_resolve(a, wgs_per_run);
+    const int P = (int)a.P;
+    // written by k_ss_list of this iteration (an earlier launch): every thread reads the same values
+    const int K = r.ws->K_list;
+    if (r.ws->done_epoch == epoch + 1 || K == 0) return;
+    const float thresh = r.ws->thresh;
+    unsigned long long* winners = r.winners_base + (size_t)(epoch & 1) * P;
+    const int* list = reinterpret_cast<const int*>(a.ws + align_up(sizeof(SamplerWs), 256) + align_up((size_t)P * 16, 256));
+    SamplerArgs b = a;
+    b.cache_lds = 0;                               // base positions straight from a.samples
+    int m = 0;
+    ss_candidates(f, b, winners, epoch, it, r.wg_id, wgs_per_run, thresh, K, list, nullptr, m);
 }
 
 __global__ void __launch_bounds__(256) k_ss_apply(FieldDev f, SamplerArgs a, int wgs_per_run, int epoch) {
@@ -794,8 +862,14 @@ static hipError_t launch_surface_sample_stepped(const FieldDev& f, SamplerArgs a
     hipLaunchKernelGGL(k_ss_seed, dim3((unsigned)(wgs_pts * B)), dim3(256), 0, s, f, a, wgs_pts);
     for (int epoch = 0; epoch < a.n_epochs; ++epoch) {
         const int slots = a.max_iterations < ss_slots(epoch) ? a.max_iterations : ss_slots(epoch);
-        for (int it = 0; it < slots; ++it)
-            hipLaunchKernelGGL((k_ss_iter<false>), dim3((unsigned)(wgs_it * B)), dim3(256), lds, s, f, a, wgs_it, epoch, it);
+        for (int it = 0; it < slots; ++it) {
+            if (P > SS_SMALL_P) {
+                hipLaunchKernelGGL(k_ss_list, dim3((unsigned)B), dim3(SS_LIST_THREADS), 0, s, f, a, epoch, it);
+                hipLaunchKernelGGL(k_ss_cand, dim3((unsigned)(wgs_it * B)), dim3(256), 0, s, f, a, wgs_it, epoch, it);
+            } else {
+                hipLaunchKernelGGL((k_ss_iter<false>), dim3((unsigned)(wgs_it * B)), dim3(256), lds, s, f, a, wgs_it, epoch, it);
+            }
+        }
         if (a.max_iterations > slots)
             hipLaunchKernelGGL((k_ss_iter<true>), dim3((unsigned)B), dim3(256), lds, s, f, a, 1, epoch, slots);
         hipLaunchKernelGGL(k_ss_apply, dim3((unsigned)(wgs_pts * B)), dim3(256), 0, s, f, a, wgs_pts, epoch);

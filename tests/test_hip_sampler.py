@@ -220,7 +220,7 @@ def test_stepped_launches_equal_the_persistent_launch(small, dev):
     iteration launches (the finisher's loop)."""
     rho = rho_of(util.ckpt("small"))
     cases = [(1, 593, rho, 4, 200), (16, 593, rho, 4, 200), (3, 5000, rho, 3, 200), (8, 300, rho, 2, 3), (2, 700, rho * 0.02, 2, 200),
-             (9, 400, rho * 0.02, 2, 12)]
+             (9, 400, rho * 0.02, 2, 12), (2, 3000, rho * 0.02, 2, 200), (2, 20000, rho, 2, 200)]     # > 2560 points: list + candidate launches
     long_epochs = 0
     for B, P, r, E, mi in cases:
         got = small.surface_sample_batched(B, P, r, n_epochs=E, max_iterations=mi, seed=4321)
