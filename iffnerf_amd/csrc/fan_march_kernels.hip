@@ -50,6 +50,13 @@ typedef uint32_t u32q __attribute__((ext_vector_type(4)));
 #else
 #define STAMP(k) do { } while (0)
 #endif
+// FAN_EXIT_AFTER=k (timing / counter builds only): every tile stops after the phase that ends at stamp k -- the vector-instruction count
+// of a phase is the difference of two such builds' SQ_INSTS_VALU (scripts/pmc_fan_phases.sh)
+#ifdef FAN_EXIT_AFTER
+#define FAN_EXIT(k) do { if (FAN_EXIT_AFTER == (k)) return; } while (0)
+#else
+#define FAN_EXIT(k) do { } while (0)
+#endif
 #if defined(FAN_STAMPS) && FAN_STAMPS == 2
 #define ESTAMP(k) STAMP(k)
 #else
@@ -376,7 +383,10 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
+    FAN_EXIT(1);
     // ---------------------------------------------------------------------------------------------------- phase A: records
+    // (the 540 samples flat over the 256 threads -- two rounds for three of the four waves instead of three -- measured 1.3 % SLOWER
+    // than this ray-major split, same box: the integer division and the per-sample ray reads cost more than the idle round)
     if (grp_on) {
         const float* sr = s_ray + g * 8;
         const bool live = g < n_live;
@@ -422,6 +432,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
         }
     }
     STAMP(2);
+    FAN_EXIT(2);
     if (MODE >= 2 && fits) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -449,6 +460,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     if (fits) fetch_app(0);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(3);
+    FAN_EXIT(3);
     // ---------------------------------------------------------------------------------------------------- phase B: density
     const float* sr = s_ray + gg * 8;
     const int64_t r_glob = ray0 + g;
@@ -565,6 +577,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
         for (int s = 0; s < FS; ++s) shmask |= (__uint_as_float(recs[s * REC]) > f.weight_thres ? 1u : 0u) << s;
     }
     STAMP(5);
+    FAN_EXIT(5);
     if (!live) shmask = 0u;
     const bool any = shmask != 0u;
     const unsigned mymask = shmask & (h ? 0xAAAAAu : 0x55555u);       // this sub-group's shaded samples
@@ -620,6 +633,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
                 }
             }
             STAMP(7 + 2 * i);
+            FAN_EXIT(7 + 2 * i);
         }
     } else {
         // the gather path: a tile whose samples do not fit one patch reads its taps where the general kernels do
@@ -691,6 +705,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     }
     __syncthreads();
     STAMP(12);
+    FAN_EXIT(12);
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     f32x16 dacc;
 #pragma unroll
@@ -715,6 +730,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     if ((tid & 7) == 0 && grp_on) s_feat[g * 28 + 27] = any ? 1.0f : 0.0f;
     if (MODE == 3 && tid < 5 * 28) s_feat[FR * 28 + tid] = 0.0f;             // rows 27..31 of the matrix operand
     STAMP(13);
+    FAN_EXIT(13);
     __syncthreads();
     if (MODE != 3) {
         if (tid < n_live * 7)
