@@ -100,6 +100,25 @@ def source_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
+def top100_spot_check(pipe, idw, tokens, gen_points, n_queries=8):
+    """Bounded live parity check next to the CPU baseline (the oracle as the checker): one GPU emission, `n_queries` query images
+    identified by the library and by the oracle on the SAME rays -> how many top-100 ray lists are identical (order included) and
+    how many hold the same 100 rays.  Lists that differ do so by near-tie pairs at fp32 rounding level."""
+    import torch
+    from oracle import identify as oid
+    ori, dirs, rgb = pipe.emit(gen_points, seed=424242)
+    o, d, c = ori.cpu(), dirs.cpu(), rgb.cpu()
+    n = min(n_queries, tokens.shape[0])
+    same_list = same_set = 0
+    for q in range(n):
+        _, idx, _ = pipe.identify(tokens[q], ori, dirs, rgb, k=TOPK, materialize_map=False)
+        idx_o = oid.test_image(idw, tokens[q].cpu(), o, d, c, TOPK)[0]
+        a, b = idx.cpu().reshape(-1).long(), torch.as_tensor(idx_o).reshape(-1).long()
+        same_list += int(torch.equal(a, b))
+        same_set += int(torch.equal(a.sort().values, b.sort().values))
+    return {"top100_identical": f"{same_list}/{n}", "top100_same_rays": f"{same_set}/{n}"}
+
+
 def cpu_baseline(ck, idw, tokens_cpu, gen_points, shared_queries, max_seconds=45.0):
     """Reference CPU path (oracle = the reference's op chain on torch-CPU) on cold poses of the same workload: 3 warm-ups +
     median of up to 10 timed poses, bounded to ~max_seconds of CPU work."""
@@ -283,6 +302,7 @@ def main():
         if not args.no_instrument:
             instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, rank, device)
         if world_size == 1 and not args.no_cpu_baseline:
+            result.update(top100_spot_check(pipe, idw, tokens, gen_points))
             result["cpu_baseline"] = cpu_baseline(ck, idw, tokens[:4].cpu(), gen_points, B if shared else 1)
         else:
             result["cpu_baseline"] = None
