@@ -17,7 +17,7 @@
 //   phase D   basis_mat (tensoRF.py:158) once per ray on the weighted sums, from an LDS copy (sub-group h: outputs h mod 2)
 //
 // The next patch is fetched into registers while the current phase computes.  A tile is ANY 27 consecutive rays: when its box
-// does not fit the patch (arbitrary rays, unisphere contraction) the same workgroup gathers from global memory with the lookup
+// does not fit the patch (arbitrary rays) the same workgroup gathers from global memory with the lookup
 // functions of iff_device.h -- same arithmetic, same bits, no LDS staging.  Every per-sample operation is the one the general
 // kernels perform (shared lerp order), so alpha / acc / depth / counters are bit-identical to theirs; the weighted feature
 // sums are added in this kernel's own fixed order (even samples, odd samples, then the 12 quarter sums of basis_mat).
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     }
     __syncthreads();
     int lo[3];
-    bool fits = !f.unisphere, inner = true;
+    bool fits = true, inner = true;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         lo[ax] = __builtin_amdgcn_readfirstlane(s_box[ax]);
@@ -801,13 +801,15 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
 }  // namespace
 
 // The fused fan kernel serves the point-centred sampler with its 20 samples (the emission path) on tables of the reference's
-// shapes; a field under unisphere contraction, or one whose ten steps cover many more than 5 texels of an axis (the reference's
-// step_ratio 0.5 gives 5), would send most tiles down the gather path, so those keep the general kernels.  A performance
-// choice only: the per-tile box test decides what the kernel does.
+// shapes; a field whose ten steps cover many more than 5 texels of an axis (the reference's step_ratio 0.5 gives 5) would send
+// most tiles down the gather path, so it keeps the general kernels.  A performance choice only: the per-tile box test decides what
+// the kernel does.  Unisphere contraction (utils.py:139-146, applied per axis) is monotone with slope <= 1, so a fan's box is at
+// most that of the uncontracted step and the end-point argument of phase 0 holds unchanged.
 bool fan_march_eligible(const FieldDev& f, int mode, int S) {
-    if (mode != 0 || S != FS || f.unisphere || f.n_density != 16 || f.n_app != 48 || f.app_dim != 27) return false;
+    if (mode != 0 || S != FS || f.n_density != 16 || f.n_app != 48 || f.app_dim != 27) return false;
     for (int ax = 0; ax < 3; ++ax) {
-        const float texels = 10.0f * f.step_size * f.inv_aabb[ax] * 0.5f * (float)(f.grid[ax] - 1);
+        const float scale = f.unisphere ? 1.0f : f.inv_aabb[ax];            // d(normalised coordinate) / d(world coordinate), at most
+        const float texels = 10.0f * f.step_size * scale * 0.5f * (float)(f.grid[ax] - 1);
         if (!(texels <= 6.5f)) return false;
     }
     return true;

@@ -188,7 +188,10 @@ def test_fan_march_equals_the_general_kernels(dev):
     import os
     if os.environ.get("IFF_MARCH_FAN", "2") == "0":
         pytest.skip("the fan kernel is switched off (IFF_MARCH_FAN=0)")
-    for which, over in (("small", {}), ("tiny", {}), ("small", dict(grid=(300, 280, 260), mask_res=(60, 56, 52)))):
+    for which, over in (("small", {}), ("tiny", {}), ("small", dict(grid=(300, 280, 260), mask_res=(60, 56, 52))),
+                        ("small", dict(contraction_type="unisphere", density_shift=0.0, density_offset=-10.0, peak=20.0,
+                                       aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), near_far=(0.01, 1.4), blob_sigma=0.30, mask_radius=0.62,
+                                       step_ratio=0.25))):      # unisphere halves the grid in the step (tensorBase.py:361): 0.25 keeps 5 texels per 10 steps
         ck = util.ckpt(which, **over)
         pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev)
         fan, gen = field_handle_from_ckpt(ck, dev), field_handle_from_ckpt(ck, dev, density_lanes=1)
