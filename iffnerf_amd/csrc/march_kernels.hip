@@ -332,6 +332,19 @@ __global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance12(FieldDev f, M
         }
         if (!grp_on) mask = 0ull;
         const bool any = mask != 0ull;
+        // Under unisphere contraction a normalised coordinate is three powf (utils.py:139-146): ~300 of the ~750 vector instructions
+        // a wave spends per shaded sample when all 12 lanes of a ray evaluate it for the ray's current sample.  Lane c evaluates it
+        // ONCE for the samples whose weights it holds (c, c + 12, c + 24) and the ray's lanes fetch the current sample's from there
+        // -- the same function of the same point: the same bits.
+        float xs[NW][3];
+        if (f.unisphere) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const float zj = z_of(f, 0, S, 0.0f, c0 + NL * j);
+                const float pj[3] = {o[0] + d[0] * zj, o[1] + d[1] * zj, o[2] + d[2] * zj};
+                field_normalize(f, pj, xs[j]);
+            }
+        }
         while (mask) {
             const int sidx = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
@@ -343,9 +356,21 @@ __global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance12(FieldDev f, M
                 const float vj = __shfl(wreg[jj], src, 64);
                 w = (j == jj) ? vj : w;
             }
-            const float z = z_of(f, 0, S, 0.0f, sidx);
-            float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z}, xn[3];
-            field_normalize(f, p, xn);
+            float xn[3];
+            if (f.unisphere) {
+                xn[0] = xn[1] = xn[2] = 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < NW; ++jj)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const float vj = __shfl(xs[jj][ax], src, 64);
+                        xn[ax] = (j == jj) ? vj : xn[ax];
+                    }
+            } else {
+                const float z = z_of(f, 0, S, 0.0f, sidx);
+                const float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z};
+                field_normalize(f, p, xn);
+            }
             float prod[12];
             app_products_lane(f, xn, c0, prod);
 #pragma unroll
