@@ -63,7 +63,8 @@ def test_traffic_figure_is_keyed_on_the_kernel_sources():
     import summarize_pmc
     fp = bench.source_fingerprint()
     assert fp == summarize_pmc.source_fingerprint() and len(fp) == 16
-    for cfg, march in (("lego16k", "k4f_fan_march<3>"), ("truck32k", "k4f_fan_march<3>"), ("bicycle64k", "k4b_appearance12<27>")):
+    for cfg, march in (("lego16k", "k4f_fan_march<3>"), ("truck32k", "k4f_fan_march<3>"), ("bicycle64k", "k4b_appearance12<27>"),
+                       ("lego_b64", "k4f_fan_march<3>"), ("lego540k", "k4f_fan_march<3>")):
         j = json.load(open(os.path.join(ROOT, "profiles", f"r03_hbm_traffic_{cfg}.json")))
         assert j["config"] == cfg and len(j["source_sha16"]) == 16
         for k in ("k5_trunk_h<1, 1, 2>", march):
