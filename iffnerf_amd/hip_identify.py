@@ -307,6 +307,9 @@ def topk(score: torch.Tensor, k: int):
     N = s.shape[0]
     if k > N:
         raise RuntimeError(f"selected index k out of range (k={k}, N={N})")   # torch.topk raises RuntimeError too
+    if N >= TOPK_TWO_LEVEL_N and _shards_for(N, k) > 1:
+        idx, val = topk_batched(s.view(1, N), k)
+        return idx[0], val[0]
     idx = torch.empty(k, dtype=torch.int64, device=s.device)
     val = s.new_empty(k)
     with torch.cuda.device(s.device):
@@ -346,14 +349,35 @@ def attn_colsum_batched(logits: torch.Tensor, row_max: torch.Tensor, row_sumexp:
     return score
 
 
+TOPK_TWO_LEVEL_N = 131072          # from here on a row is selected in column shards first (iff_topk_batched serves a row with ONE workgroup)
+
+
+def _shards_for(N: int, k: int) -> int:
+    for G in (32, 27, 16, 9, 8, 4, 3, 2):
+        if N % G == 0 and N // G >= 4 * k:
+            return G
+    return 1
+
+
 def topk_batched(score: torch.Tensor, k: int):
-    """score [Q, N] -> (idx [Q, k] int64, val [Q, k]), each row as ``topk``."""
+    """score [Q, N] -> (idx [Q, k] int64, val [Q, k]), each row as ``topk``.
+
+    Rows of 131 072 scores and more (the reference's default 540 000 rays: one workgroup spends 0.6 ms on such a row) are selected
+    in two levels of the same kernel: the top k of each of G contiguous column shards ([Q*G, N/G] is a view of the same memory),
+    then the top k of the Q x (G k) candidates.  Exactly the one-level result, ties included: the candidates of a row are ordered
+    (shard, value descending, index ascending), so "lowest position first" among equal values is "lowest ray index first"."""
     s = _gpu(score, "scores")
     if s.dim() != 2:
         raise RuntimeError("topk_batched expects scores [Q, N]")
     Q, N = s.shape
     if k > N:
         raise RuntimeError(f"selected index k out of range (k={k}, N={N})")
+    G = _shards_for(N, k) if N >= TOPK_TWO_LEVEL_N else 1
+    if G > 1:
+        idx1, val1 = topk_batched(s.view(Q * G, N // G), k)
+        pos, val = topk_batched(val1.view(Q, G * k), k)
+        base = (torch.arange(G, device=s.device, dtype=torch.int64) * (N // G)).repeat_interleave(k)
+        return torch.gather(idx1.view(Q, G * k) + base, 1, pos), val
     idx = torch.empty(Q, k, dtype=torch.int64, device=s.device)
     val = s.new_empty(Q, k)
     with torch.cuda.device(s.device):

@@ -78,6 +78,20 @@ def test_topk_properties(dev):
         # ties resolve to the lowest indices: the selected multiset of (value, index) is the lexicographic best
         order = sorted(range(n), key=lambda i: (-float(s[i]), i))[:k]
         assert idx.cpu().tolist() == order, (n, k)
+    # rows of 131 072 scores and more go through the two-level selection (column shards, then their candidates): the same list,
+    # ties across shard borders included (the reference's default 540 000 rays; a length no shard count divides stays one-level)
+    for n, k in ((540000, 100), (27 * 5000, 100), (131072, 7), (131101, 100)):
+        s = torch.rand(3, n, generator=g)
+        s[:, ::4099] = s[:, 11:12]       # exact ties spread over every shard
+        s[1, : n // 2] = 0.25            # a row whose top k is decided by ties alone in its upper half
+        idx, val = H.topk_batched(s.to(dev), k)
+        for q in range(3):
+            wv, wi = torch.topk(s[q], k)
+            assert torch.equal(val[q].cpu(), wv), (n, k, q)
+            top = torch.argsort(s[q], descending=True, stable=True)[:k]
+            assert idx[q].cpu().tolist() == top.tolist(), (n, k, q)
+        i1, v1 = H.topk(s[0].to(dev), k)
+        assert torch.equal(i1, idx[0]) and torch.equal(v1, val[0])
     with pytest.raises(RuntimeError):
         H.topk(torch.rand(10, device=dev), 11)
     with pytest.raises(RuntimeError):
