@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from iffnerf_amd import synthetic, hip_identify as H
 dev = torch.device("cuda:0")
-net = H.IdNetHandle(synthetic.make_id_weights(seed=99), dev, gemm_mode=H.GEMM_F16X2)
+net = H.IdNetHandle(synthetic.make_id_weights(seed=99), dev, gemm_mode=H.GEMM_F16X2, trunk_variant=int(os.environ.get("TV", "0")))
 g = torch.Generator().manual_seed(3)
 Q, N, M = int(os.environ.get("Q", "16")), 16011, 256
 o = (torch.rand(N, 3, generator=g) * 2 - 1).to(dev)
