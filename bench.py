@@ -102,7 +102,7 @@ def source_fingerprint() -> str:
 
 def top100_spot_check(pipe, idw, tokens, gen_points, n_queries=8):
     """Bounded live parity check next to the CPU baseline (the oracle as the checker): one GPU emission, `n_queries` query images
-    identified by the library and by the oracle on the SAME rays -> how many top-100 ray lists are identical (order included) and
+    identified by the library (as one batch, like the timed step) and by the oracle on the SAME rays -> how many top-100 ray lists are identical (order included) and
     how many hold the same 100 rays.  Lists that differ do so by near-tie pairs at fp32 rounding level."""
     import torch
     from oracle import identify as oid
@@ -110,10 +110,12 @@ def top100_spot_check(pipe, idw, tokens, gen_points, n_queries=8):
     o, d, c = ori.cpu(), dirs.cpu(), rgb.cpu()
     n = min(n_queries, tokens.shape[0])
     same_list = same_set = 0
+    # the WHOLE batch of the timed step through the batched launches (the kernels a step runs: their forms depend on the number of
+    # token rows), the first n queries compared
+    idx_all = pipe.identify_batch(tokens, ori, dirs, rgb, k=TOPK)[1].cpu()
     for q in range(n):
-        _, idx, _ = pipe.identify(tokens[q], ori, dirs, rgb, k=TOPK, materialize_map=False)
         idx_o = oid.test_image(idw, tokens[q].cpu(), o, d, c, TOPK)[0]
-        a, b = idx.cpu().reshape(-1).long(), torch.as_tensor(idx_o).reshape(-1).long()
+        a, b = idx_all[q].reshape(-1).long(), torch.as_tensor(idx_o).reshape(-1).long()
         same_list += int(torch.equal(a, b))
         same_set += int(torch.equal(a.sort().values, b.sort().values))
     return {"top100_identical": f"{same_list}/{n}", "top100_same_rays": f"{same_set}/{n}"}

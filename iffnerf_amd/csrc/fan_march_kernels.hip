@@ -798,6 +798,90 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     STAMP(14);
 }
 
+// Ref.forward (models/ref.py:103-152) of n rays with given feature rows and view directions -- the march's shade + blend step on
+// tiles the fused kernel does not take, renderer.evaluation's rows, iff_ref_shade -- in the form of the fused kernel's phase E:
+// 32 rays per tile, the bottleneck on the fp32 matrix cores (one 32-row block per wave, its weights held in registers over the
+// workgroup's tiles), eight lanes per ray for the rest (ref_head_oct).  Same bits as k_ref_shade (field_kernels.hip), which spends
+// 16 lanes per ray and the vector ALU on the bottleneck.
+template <bool BLEND>
+__global__ void __launch_bounds__(NT) k_ref_shade_oct(FieldDev f, const float* __restrict__ dirs, int dir_stride, const float* __restrict__ feat,
+                                                      int feat_stride, const float* __restrict__ acc, float bg0, float bg1, float bg2,
+                                                      int64_t n, float* __restrict__ rgb, int64_t n_tiles) {
+    constexpr int BLD = 164;
+    __shared__ __align__(16) float s_F[32 * 28];
+    __shared__ __align__(16) float s_b[32 * BLD];
+    __shared__ __align__(16) float s_tail[680];
+    __shared__ __align__(16) float s_small[296];
+    __shared__ float s_flag[32];
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
+    const int fc = f.feature_c;
+    {
+        const int n_tail4 = (ho.total - ho.spec_w) / 4, n_small4 = ho.bott_w / 4;         // <= 170 + 74 <= NT (fan_head_fusable)
+        if (tid < n_tail4) *reinterpret_cast<f32q*>(s_tail + 4 * tid) = *reinterpret_cast<const f32q*>(f.head + ho.spec_w + 4 * tid);
+        else if (tid < n_tail4 + n_small4) *reinterpret_cast<f32q*>(s_small + 4 * (tid - n_tail4)) = *reinterpret_cast<const f32q*>(f.head + 4 * (tid - n_tail4));
+    }
+    const bool has_block = 32 * wave < fc;
+    f32q w[7], bias_q[4];
+    if (has_block) {
+        const float* wr = f.head + ho.bott_w + (32 * wave + lr) * 28;
+#pragma unroll
+        for (int k4 = 0; k4 < 7; ++k4) w[k4] = *reinterpret_cast<const f32q*>(wr + 4 * k4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_q[q] = *reinterpret_cast<const f32q*>(f.head + ho.bott_b + 32 * wave + 8 * q + 4 * lh);
+    }
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t ray0 = tile * 32;
+        const int n_live = (int)(n - ray0 < 32 ? n - ray0 : 32);
+        __syncthreads();                               // the staged head is in place / the previous tile has been read
+        for (int idx = tid; idx < 32 * 28; idx += NT) {
+            const int r = idx / 28, k = idx - r * 28;
+            float v = 0.0f;
+            if (r < n_live) {
+                const float* fp = feat + (ray0 + r) * feat_stride;
+                if (k < 27) v = fp[k];
+                else if (BLEND) s_flag[r] = fp[27];    // the shaded flag of the march's 28-float rows
+            }
+            s_F[idx] = v;                              // column 27 and the rows past n are zero
+        }
+        __syncthreads();
+        if (has_block) {
+            f32x16 e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 14; ++ks) {
+                const float av = lh ? w[ks >> 1][2 * (ks & 1) + 1] : w[ks >> 1][2 * (ks & 1)];
+                e = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_F[lr * 28 + 2 * ks + lh], e, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {              // rows 32 wave + 8 q + 4 lh + i (register 4 q + i) of ray lr, plus the bias
+                const f32q b4 = bias_q[q];
+                f32q o4 = {e[4 * q] + b4[0], e[4 * q + 1] + b4[1], e[4 * q + 2] + b4[2], e[4 * q + 3] + b4[3]};
+                *reinterpret_cast<f32q*>(s_b + lr * BLD + 32 * wave + 8 * q + 4 * lh) = o4;
+            }
+        }
+        __syncthreads();
+        const int g = tid >> 3, sub = tid & 7;
+        const bool live = g < n_live;
+        const float* dp = dirs + (live ? ray0 + g : 0) * dir_stride;
+        const float d[3] = {dp[0], dp[1], dp[2]};
+        const float cch = ref_head_oct(s_small, ho, fc, s_b + g * BLD, s_F + g * 28, s_tail, d, sub);
+        if (sub < 3 && live) {
+            if (BLEND) {
+                const float ac = acc[ray0 + g];
+                float v = s_flag[g] != 0.0f ? cch : 0.0f;
+                v = v * ac + (sub == 0 ? bg0 : (sub == 1 ? bg1 : bg2)) * (1.0f - ac);
+                rgb[3 * (ray0 + g) + sub] = fminf(fmaxf(v, 0.0f), 1.0f);
+            } else {
+                rgb[3 * (ray0 + g) + sub] = cch;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // The fused fan kernel serves the point-centred sampler with its 20 samples (the emission path) on tables of the reference's
@@ -818,6 +902,19 @@ bool fan_march_eligible(const FieldDev& f, int mode, int S) {
 // the fused Ref head (phase E) is laid out for the reference's head: 27 features in rows of 28, a bottleneck of at most 128 rows
 bool fan_head_fusable(const FieldDev& f) {
     return f.app_dim == 27 && f.feature_c >= 32 && f.feature_c <= 128 && f.feature_c % 32 == 0 && f.head != nullptr;
+}
+
+// k_ref_shade's work in the 8-lanes-per-ray form (acc == nullptr: plain Ref.forward; otherwise the march's shade + blend)
+hipError_t launch_ref_shade_oct(const FieldDev& f, const float* dirs, int dir_stride, const float* feat, int feat_stride,
+                                const float* acc, const float* bg, int64_t n, float* rgb, hipStream_t s) {
+    const int64_t n_tiles = (n + 31) / 32;
+    if (n_tiles == 0) return hipSuccess;
+    const int64_t grid = n_tiles < 256 * 4 ? n_tiles : 256 * 4;
+    if (acc) hipLaunchKernelGGL((k_ref_shade_oct<true>), dim3((unsigned)grid), dim3(NT), 0, s, f, dirs, dir_stride, feat, feat_stride, acc,
+                                bg[0], bg[1], bg[2], n, rgb, n_tiles);
+    else hipLaunchKernelGGL((k_ref_shade_oct<false>), dim3((unsigned)grid), dim3(NT), 0, s, f, dirs, dir_stride, feat, feat_stride, acc,
+                            0.0f, 0.0f, 0.0f, n, rgb, n_tiles);
+    return hipGetLastError();
 }
 
 hipError_t launch_fan_march(const FieldDev& f, const MarchArgs& a, int variant, hipStream_t s) {

@@ -933,32 +933,35 @@ __global__ void __launch_bounds__(256) k_gemm_small(const float* __restrict__ A,
 // once and read by the four waves (row half x column half), instead of every 16 x 16 output tile streaming its own 51 KB
 // of operands from L2 as k_gemm_small does -- that kernel stays for a single image's <= 256 rows, where it has 4x the
 // workgroups.  NTW = 16-column tiles per wave (ceil(Nout / 32)).
-template <int NTW>
+// RW = token rows per workgroup: 32 (waves = row half x column half) or 16 (waves = column quarters): a batch of 16-32 images is
+// 128-256 workgroups of 32 rows -- one wave per SIMD with nothing to run while it waits for LDS -- so up to 16 384 rows take 16.
+template <int NTW, int RW>
 __global__ void __launch_bounds__(256) k_gemm_tokens(const float* __restrict__ A, int K, int K_pad, const float* __restrict__ Wt,
                                                      int Nout, const float* __restrict__ bias, float* __restrict__ Y, int M) {
-    constexpr int BK = 16, A_LD = 33;
+    constexpr int BK = 16, A_LD = RW + 1, NCH = 64 / RW;        // NCH = column shares (2 or 4)
     extern __shared__ float smem_tok[];
     float* As = smem_tok;                        // [BK][A_LD]   (k-major: As[k][row])
     float* Bs = smem_tok + BK * A_LD;            // [BK][Nout]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rh = wave & 1, ch = wave >> 1;
+    const int rh = RW == 32 ? (wave & 1) : 0, ch = RW == 32 ? (wave >> 1) : wave;
     const int r = lane & 15, kk = lane >> 4;
-    const int m0 = blockIdx.x * 32;
-    const int NT = Nout / 16, t0 = ch == 0 ? 0 : (NT + 1) / 2, nt = ch == 0 ? (NT + 1) / 2 : NT - (NT + 1) / 2;
+    const int m0 = blockIdx.x * RW;
+    const int NT = Nout / 16, per = (NT + NCH - 1) / NCH, t0 = ch * per, nt = max(0, min(per, NT - t0));
     // two accumulators per tile, by parity of the 4-deep k-step, added at the end: k_gemm_small's association, so a token row
     // gets the same bits whichever of the two kernels serves it (batched and per-image calls stay bit-identical)
     f32x4 acc[NTW][2];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int n4 = Nout / 4, nb4 = BK * n4;      // float4s of one Wt k-tile
-    // staging registers: A 32 rows x 16 k = 512 floats -> 2 per thread; Wt k-tile: ceil(nb4 / 256) float4 per thread (<= 7)
-    const int arow = tid >> 3, ak = (tid & 7) * 2;
-    float a_reg[2];
+    // staging registers: A RW rows x 16 k = 512 / 256 floats -> AE = 2 / 1 per thread; Wt k-tile: ceil(nb4 / 256) float4 per thread (<= 7)
+    constexpr int AE = RW / 16;
+    const int arow = RW == 32 ? tid >> 3 : tid >> 4, ak = RW == 32 ? (tid & 7) * 2 : (tid & 15);
+    float a_reg[AE];
     float4 b_reg[7];
     auto load_tile = [&](int k0) {
         const int gr = m0 + arow;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) a_reg[e] = (gr < M && k0 + ak + e < K) ? A[(size_t)gr * K + k0 + ak + e] : 0.0f;
+        for (int e = 0; e < AE; ++e) a_reg[e] = (gr < M && k0 + ak + e < K) ? A[(size_t)gr * K + k0 + ak + e] : 0.0f;
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const int f = tid + u * 256;
@@ -966,8 +969,8 @@ __global__ void __launch_bounds__(256) k_gemm_tokens(const float* __restrict__ A
         }
     };
     auto store_tile = [&]() {
-        As[(ak + 0) * A_LD + arow] = a_reg[0];
-        As[(ak + 1) * A_LD + arow] = a_reg[1];
+#pragma unroll
+        for (int e = 0; e < AE; ++e) As[(ak + e) * A_LD + arow] = a_reg[e];
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const int f = tid + u * 256;
@@ -1009,9 +1012,15 @@ static hipError_t gemm_tokens(const float* A, int K, int K_pad, const float* Wt,
     const int NT = Nout / 16;
     if (M > 512 && Nout % 16 == 0 && Nout / 4 * 16 <= 7 * 256 && (NT + 1) / 2 <= 12) {
         const size_t lds = (size_t)(16 * 33 + 16 * Nout) * sizeof(float);
+        if (M <= 16384) {                        // 16-row workgroups: twice as many, two or more per CU
+            dim3 grid((unsigned)((M + 15) / 16));
+            if ((NT + 3) / 4 <= 5) hipLaunchKernelGGL((k_gemm_tokens<5, 16>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+            else hipLaunchKernelGGL((k_gemm_tokens<6, 16>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+            return hipGetLastError();
+        }
         dim3 grid((unsigned)((M + 31) / 32));
-        if ((NT + 1) / 2 <= 9) hipLaunchKernelGGL((k_gemm_tokens<9>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
-        else hipLaunchKernelGGL((k_gemm_tokens<12>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+        if ((NT + 1) / 2 <= 9) hipLaunchKernelGGL((k_gemm_tokens<9, 32>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
+        else hipLaunchKernelGGL((k_gemm_tokens<12, 32>), grid, dim3(256), lds, s, A, K, K_pad, Wt, Nout, bias, Y, M);
         return hipGetLastError();
     }
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)((Nout + 63) / 64));

@@ -31,6 +31,8 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
 // fan_march_kernels.hip (the fused form of the point-centred march for 27-ray fans; MarchArgs: march_common.h)
 struct MarchArgs;
 bool fan_head_fusable(const FieldDev& f);
+hipError_t launch_ref_shade_oct(const FieldDev& f, const float* dirs, int dir_stride, const float* feat, int feat_stride,
+                                const float* acc, const float* bg, int64_t n, float* rgb, hipStream_t s);
 bool march_head_fused(const FieldDev& f);
 bool fan_march_eligible(const FieldDev& f, int mode, int S);
 hipError_t launch_fan_march(const FieldDev& f, const MarchArgs& a, int variant, hipStream_t s);

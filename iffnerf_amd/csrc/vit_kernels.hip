@@ -373,37 +373,69 @@ struct ResizeArgs {
     float mean[4], inv_std[4];
     float* dst;                                  // [Q,C,ch,cw]
 };
-// One workgroup = a 16 x 16 tile of the output.  Separable inside the tile: every input row the tile's 16 output rows touch is
+// One workgroup = a tile of 16 columns x `tr` rows of the output (tr = 16; 1 when 16-row tiles would leave most CUs without a
+// workgroup -- the 16 x 16 token-grid mask of a batch is one such tile per image).  Separable inside the tile: every input row the tile's 16 output rows touch is
 // filtered horizontally once for the tile's 16 columns (LDS), then the columns are filtered vertically -- the order of ATen's
 // kernel (horizontal sum per row, then the weighted sum of rows), ~3x fewer multiply-adds than a 2-D sum per output pixel.
-__global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows) {
-    extern __shared__ float s_tmp[];            // [rows][16][C]
+// The input rows pass through LDS in chunks of `rch` rows, each row's segment (the tile's columns with their filter support:
+// contiguous in a channels-last image) loaded by consecutive lanes: read straight from global memory the horizontal pass had 16
+// lanes walking 16 different pixel runs and was bound by the texture-address path (the kernel took 400 us for 32 images).
+__global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows, int max_cols, int rch, int tr) {
+    extern __shared__ float s_dyn[];            // [max_rows][16][C] horizontally filtered rows, then [rch][max_cols * C] input rows
     __shared__ float s_wx[16][RS_TAPS], s_wy[16][RS_TAPS];
     __shared__ int s_fx[16], s_nx[16], s_fy[16], s_ny[16];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16, q = blockIdx.z;
+    const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * tr, q = blockIdx.z;
     if (threadIdx.x < 16) aa_weights(a.left + min(ox0 + tx, a.cw - 1), a.W, a.rw, a.cubic, s_wx[tx], s_fx[tx], s_nx[tx]);
-    else if (threadIdx.x < 32) aa_weights(a.top + min(oy0 + tx, a.ch - 1), a.H, a.rh, a.cubic, s_wy[tx], s_fy[tx], s_ny[tx]);
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + tr)        // in another wave than the columns' weights: the two run side by side
+        aa_weights(a.top + min(oy0 + tx, a.ch - 1), a.H, a.rh, a.cubic, s_wy[tx], s_fy[tx], s_ny[tx]);
     __syncthreads();
-    const int ry0 = s_fy[0];
-    int ry1 = ry0;
-    for (int i = 0; i < 16; ++i) ry1 = max(ry1, s_fy[i] + s_ny[i]);
-    const int n_rows = min(ry1 - ry0, max_rows);
     const int C = a.C;
+    float* const s_tmp = s_dyn;
+    float* const s_in = s_dyn + max_rows * 16 * C;
+    const int ry0 = s_fy[0], fx0 = s_fx[0];
+    int ry1 = ry0, fx1 = fx0;
+    for (int i = 0; i < 16; ++i) fx1 = max(fx1, s_fx[i] + s_nx[i]);
+    for (int i = 0; i < tr; ++i) ry1 = max(ry1, s_fy[i] + s_ny[i]);
+    const int n_rows = min(ry1 - ry0, max_rows);
+    const int seg = min(fx1 - fx0, max_cols) * C, ld = max_cols * C;          // floats of a row this tile reads
     const float* img = a.src + (int64_t)q * a.H * a.W * C;
-    for (int item = threadIdx.x; item < n_rows * 16; item += 256) {
-        const int r = item >> 4, ox = item & 15;
-        const float* row = img + ((int64_t)(ry0 + r) * a.W + s_fx[ox]) * C;
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = 0; i < s_nx[ox]; ++i) {
-            const float w = s_wx[ox][i];
-            for (int c = 0; c < C; ++c) acc[c] = fmaf(w, row[i * C + c], acc[c]);
+    for (int r0 = 0; r0 < n_rows; r0 += rch) {
+        const int nr = min(rch, n_rows - r0);
+        if (r0) __syncthreads();                // the previous chunk has been filtered
+        // a wave per row, its lanes along the row's segment; twelve loads (4 rows x 3 pieces of 64 floats) in flight per lane
+        // before the first is stored -- one at a time, a chunk cost twelve memory latencies in a row
+        for (int rb = threadIdx.x >> 6; rb < nr; rb += 16)
+            for (int kb = threadIdx.x & 63; kb < seg; kb += 192) {
+                float v[4][3];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = rb + 4 * rr;
+                    const float* src = img + ((int64_t)(ry0 + r0 + min(r, nr - 1)) * a.W + fx0) * C;
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) v[rr][kk] = src[min(kb + 64 * kk, seg - 1)];
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk)
+                        if (rb + 4 * rr < nr && kb + 64 * kk < seg) s_in[(rb + 4 * rr) * ld + kb + 64 * kk] = v[rr][kk];
+            }
+        __syncthreads();
+        for (int item = threadIdx.x; item < nr * 16; item += 256) {
+            const int r = item >> 4, ox = item & 15;
+            const float* row = s_in + r * ld + (s_fx[ox] - fx0) * C;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int i = 0; i < s_nx[ox]; ++i) {
+                const float w = s_wx[ox][i];
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(w, row[i * C + c], acc[c]);
+            }
+            for (int c = 0; c < C; ++c) s_tmp[((r0 + r) * 16 + ox) * C + c] = acc[c];
         }
-        for (int c = 0; c < C; ++c) s_tmp[item * C + c] = acc[c];
     }
     __syncthreads();
     const int ox = ox0 + tx, oy = oy0 + ty;
-    if (ox >= a.cw || oy >= a.ch) return;
+    if (ty >= tr || ox >= a.cw || oy >= a.ch) return;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rbase = s_fy[ty] - ry0;
     for (int j = 0; j < s_ny[ty]; ++j) {
@@ -435,7 +467,11 @@ template <int EPI>
 hipError_t gemm(const __bf16* X, const __bf16* W, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
     if (N % GBN != 0 || K % GBK != 0 || M < 1) return hipErrorInvalidValue;
     static const int force = [] { const char* e = getenv("IFF_VIT_TILE"); return e ? atoi(e) : 0; }();      // tuning aid
-    if (force != 128)       // 64-token tiles: with 128 the 4112-token batch leaves CUs idle or a single workgroup per CU
+    // 64-token tiles for small batches (with 128 a 4112-token batch -- 16 images -- leaves CUs idle or a single workgroup per CU);
+    // from 24 images on 128-token tiles: each launch alone is 5-15 % slower, but the workgroups read 1/3 fewer operand bytes per flop
+    // and with several batches in flight (the bench's four graphs) the total is 5 % faster (17 700 -> 18 700 images/s at 32 images)
+    const bool wide = force ? force == 128 : M >= 6144;
+    if (!wide)
         hipLaunchKernelGGL((k_vit_gemm<EPI, 64>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, W, M, N, K, e);
     else
         hipLaunchKernelGGL((k_vit_gemm<EPI, 128>), dim3((unsigned)(N / GBN), (unsigned)((M + 127) / 128)), dim3(256), 0, s, X, W, M, N, K, e);
@@ -451,12 +487,20 @@ hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int 
     a.src = src; a.Q = Q; a.H = H; a.W = W; a.C = C; a.rh = rh; a.rw = rw; a.top = top; a.left = left; a.ch = ch; a.cw = cw; a.cubic = cubic;
     for (int c = 0; c < 4; ++c) { a.mean[c] = (mean && c < C) ? mean[c] : 0.0f; a.inv_std[c] = (std && c < C) ? 1.0f / std[c] : 1.0f; }
     a.dst = dst;
-    // input rows one tile can touch: 16 output rows apart by the scale factor, plus the filter support on both sides
+    // input rows one tile can touch: tr output rows apart by the scale factor, plus the filter support on both sides
     const float sy = (float)H / (float)rh, sup = (cubic ? 2.0f : 1.0f) * (sy >= 1.0f ? sy : 1.0f);
-    const int max_rows = (int)(15.0f * sy + 2.0f * sup) + 4;
-    const size_t lds = (size_t)max_rows * 16 * C * sizeof(float);
+    const int tiles16 = ((cw + 15) / 16) * ((ch + 15) / 16);
+    const int tr = (int64_t)tiles16 * Q < 256 ? 1 : 16;
+    const int max_rows = (int)((float)(tr - 1) * sy + 2.0f * sup) + 4;
+    // ... and input columns likewise; the rows are staged `rch` at a time (about 12 KB of LDS)
+    const float sx = (float)W / (float)rw, supx = (cubic ? 2.0f : 1.0f) * (sx >= 1.0f ? sx : 1.0f);
+    const int max_cols = (int)(15.0f * sx + 2.0f * supx) + 4;
+    int rch = 3072 / (max_cols * C);
+    rch = rch < 1 ? 1 : (rch > max_rows ? max_rows : rch);
+    const size_t lds = ((size_t)max_rows * 16 * C + (size_t)rch * max_cols * C) * sizeof(float);
     if (lds > 60 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_resize_crop, dim3((unsigned)((cw + 15) / 16), (unsigned)((ch + 15) / 16), (unsigned)Q), dim3(256), lds, s, a, max_rows);
+    hipLaunchKernelGGL(k_resize_crop, dim3((unsigned)((cw + 15) / 16), (unsigned)((ch + tr - 1) / tr), (unsigned)Q), dim3(256), lds, s, a, max_rows,
+                       max_cols, rch, tr);
     return hipGetLastError();
 }
 

@@ -119,7 +119,7 @@ class ImageFrontEnd:
         mg = None
         if masks is not None:
             if self.native_preprocess:
-                m = resize_crop(masks[..., None] * 1.0, self.resize_size, self.crop_size, False)             # [Q,1,224,224]
+                m = resize_crop(masks[..., None], self.resize_size, self.crop_size, False)                   # [Q,1,224,224] (converted to fp32 inside)
                 mg = resize_crop(m.permute(0, 2, 3, 1), self.grid[0], None, False).reshape(masks.shape[0], -1)
             else:
                 m = _center_crop(_resize_short_edge(masks[:, None] * 1.0, self.resize_size, "bilinear"), self.crop_size)

@@ -15,5 +15,6 @@ for cfg in "${CFGS[@]}"; do
   cp "$(ls $P/stats/*/*kernel_stats.csv $P/stats/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/r03_bench_kernel_stats_$cfg.csv
   cp "$(ls $P/stats_if1/*/*kernel_stats.csv $P/stats_if1/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/r03_bench_kernel_stats_inflight1_$cfg.csv
   tail -12 gpurun_out/r03_${cfg}_summary.txt | cut -c1-400
+  rm -rf "$P"        # the raw traces (20 MB per config): gpurun copies back at most 64 MiB
 done
 ls -la gpurun_out/r03_*

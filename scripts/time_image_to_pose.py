@@ -1,4 +1,4 @@
-"""Image in -> pose out with the native backbone: Q 800x800 RGBA queries per captured graph, 4 graphs in flight.  Dev aid."""
+"""Image in -> pose out with the native backbone: Q 800x800 RGBA queries per captured graph (QS=16,32), INFLIGHT graphs in flight (4).  Dev aid."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,19 +15,20 @@ resident = pipe.make_resident(ori, dirs, rgb)
 net, grid, _ = create_standin_backbone(seed=0)
 fe = ImageFrontEnd(NativeViT(net.to(dev), grid), grid)
 gen = torch.Generator().manual_seed(11)
+NF = int(os.environ.get("INFLIGHT", "4"))
 for Q in [int(x) for x in os.environ.get("QS", "16,32").split(",")]:
     imgs = torch.rand(Q, 800, 800, 3, generator=gen).to(dev)
     masks = (torch.rand(Q, 800, 800, generator=gen) > 0.2).float().to(dev)
     print("capturing", Q, flush=True)
-    graphs = [CapturedImageQuery(pipe, fe, imgs.shape, resident, 100) for _ in range(4)]
+    graphs = [CapturedImageQuery(pipe, fe, imgs.shape, resident, 100) for _ in range(NF)]
     for g in graphs:
         g.imgs.copy_(imgs), g.masks.copy_(masks)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
     torch.cuda.synchronize()
     def run(n):
         for i in range(n):
-            with torch.cuda.stream(streams[i % 4]):
-                graphs[i % 4].replay()
+            with torch.cuda.stream(streams[i % NF]):
+                graphs[i % NF].replay()
     run(8); torch.cuda.synchronize()
     n = 40
     t0 = time.perf_counter(); run(n); torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -176,7 +176,33 @@ def test_one_lane_density_gather_is_bit_identical_to_the_four_lane_form(dev):
                 assert torch.equal(x, y), (P, mode)
 
 
-def test_fan_march_equals_the_general_kernels(dev):
+def test_ref_head_forms_return_the_same_bits(small, dev, monkeypatch):
+    """Ref.forward in the 8-lanes-per-ray form (bottleneck on the fp32 matrix cores: k_ref_shade_oct, the default for the reference's
+    head shape) against the 16-lanes-per-ray vector form (k_ref_shade, IFF_REF_SHADE_GROUP16=1), plain and as the march's shade +
+    blend step: EQUAL bits, on full, ragged and looped tile counts."""
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 31, 32, 33, 1000, 40007):                                  # 40007 rays = 1251 tiles > the grid's 1024 workgroups
+        d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        feat = (torch.randn(n, 27, generator=g) * 2.0).to(dev)
+        monkeypatch.setenv("IFF_REF_SHADE_GROUP16", "1")
+        want = small.ref_shade(d, feat)
+        monkeypatch.delenv("IFF_REF_SHADE_GROUP16")
+        got = small.ref_shade(d, feat)
+        assert torch.equal(got, want), (n, float((got - want).abs().max()))
+    gen = field_handle_from_ckpt(util.ckpt("small"), dev, density_lanes=1)   # the general march: K4a, K4b, shade + blend
+    assert gen.march_plan(0, 20) == 0
+    for R in (540, 37):
+        o = (torch.rand(R, 3, generator=g) - 0.5) * 2.0
+        rays = torch.cat((o, torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)), -1).to(dev)
+        for bg in ((0.0, 0.0, 0.0), (1.0, 0.5, 0.25)):
+            monkeypatch.setenv("IFF_REF_SHADE_GROUP16", "1")
+            want = gen.march(rays, 0, 20, bg=bg)[0]
+            monkeypatch.delenv("IFF_REF_SHADE_GROUP16")
+            assert torch.equal(gen.march(rays, 0, 20, bg=bg)[0], want), (R, bg)
+
+
+def test_fan_march_equals_the_general_kernels(dev, monkeypatch):
     """The fused fan kernel (k4f_fan_march: LDS-staged table patches per 27-ray tile, or its in-kernel gather path when a tile's
     samples do not fit one patch) against the general kernels K4a / K4b (iff_field_desc.density_lanes = 1 keeps those): the
     per-sample arithmetic is shared, so alpha, acc, depth and the (valid, shaded) counters must be EQUAL; the colours differ
@@ -219,7 +245,9 @@ def test_fan_march_equals_the_general_kernels(dev):
             assert fan.march_plan(0, 20) == (3 if os.environ.get("IFF_MARCH_FAN_HEAD", "1") != "0" else 2) and gen.march_plan(0, 20) == 0
             for bg in ((0.0, 0.0, 0.0), (1.0, 0.5, 0.25)):
                 fused = fan.march(rays, 0, 20, bg=bg)
+                monkeypatch.setenv("IFF_REF_SHADE_GROUP16", "1")
                 c = fan.ref_shade(rays[:, 3:6].contiguous(), fa[:, :27].contiguous())
+                monkeypatch.delenv("IFF_REF_SHADE_GROUP16")
                 c = torch.where(fa[:, 27:28] != 0, c, torch.zeros_like(c))
                 acc = fused[2].reshape(-1, 1)
                 want = (c * acc + torch.tensor(bg, device=c.device) * (1.0 - acc)).clamp(0.0, 1.0)

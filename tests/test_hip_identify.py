@@ -424,6 +424,24 @@ def test_near_tie_stress(golden, dev, mode):
     util.assert_topk_matches(idx.cpu(), score_ref, 100, rel_tie=2e-5)
 
 
+def test_token_side_products_agree_across_row_counts(net, dev):
+    """q_proj / q_fold of many token rows (k_gemm_tokens: 16-row workgroups up to 16 384 rows, 32-row ones beyond; output widths
+    384 and 272 = a different column split per wave) against the one-image form (k_gemm_small, <= 512 rows): the SAME bits row by
+    row -- a batched step must see the tokens a single query sees -- and q_proj within fp32 rounding of a float64 product."""
+    w = synthetic.make_id_weights(seed=99)
+    W, b = w["attention.q_proj.weight"].double().to(dev), w["attention.q_proj.bias"].double().to(dev)
+    g = torch.Generator().manual_seed(3)
+    for rows in (16, 500, 513, 768, 2048 + 7, 8192, 16384 + 40):
+        tok = torch.randn(rows, net.img_fea, generator=g).to(dev)
+        q, qf = net.q_proj(tok), net.q_fold(tok)
+        ref = tok.double() @ W.T + b
+        assert float((q.double() - ref).abs().max()) < 1e-4, rows
+        for lo in range(0, rows, 256):                 # pieces of <= 256 rows: the single-image kernel
+            hi = min(rows, lo + 256)
+            assert torch.equal(net.q_proj(tok[lo:hi].contiguous()), q[lo:hi]), (rows, lo)
+            assert torch.equal(net.q_fold(tok[lo:hi].contiguous()), qf[lo:hi]), (rows, lo)
+
+
 def test_two_tile_trunk_form_is_bit_identical(dev):
     """iff_idnet_desc.trunk_variant = 4 (k5_trunk_h2: sixteen waves, two 64-ray tiles one stage apart -- the matrix-core and the
     vector stages of a CU side by side) against the default eight-wave form: logits, softmax row statistics and the cached-encoder
