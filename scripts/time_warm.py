@@ -1,15 +1,17 @@
-"""Warm path (rays resident, encoder cached): Q query images per captured graph, 4 graphs in flight -> poses/s.  Dev aid."""
+"""Warm path (rays resident, encoder cached): Q query images per captured graph (QS=16,32,64), 4 graphs in flight -> poses/s, on
+the workload CONFIG (lego16k).  Dev aid."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from iffnerf_amd import synthetic
 from iffnerf_amd.pipeline import PosePipeline
 dev = torch.device("cuda:0")
-wl = synthetic.WORKLOADS["lego16k"]
-pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt("lego16k"), synthetic.make_id_weights(seed=99), dev)
+CFG = os.environ.get("CONFIG", "lego16k")
+wl = synthetic.WORKLOADS[CFG]
+pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(CFG), synthetic.make_id_weights(seed=99), dev)
 ori, dirs, rgb = pipe.emit(wl["gen_points"], seed=42)
 resident = pipe.make_resident(ori, dirs, rgb)
-for Q in (16, 32, 64):
+for Q in [int(x) for x in os.environ.get("QS", "16,32,64").split(",")]:
     tok = torch.stack([synthetic.make_tokens(256, 384, seed=100 + q) for q in range(Q)]).to(dev)
     for _ in range(2):
         pipe.identify_resident(tok, resident, 100)
