@@ -97,9 +97,11 @@ __global__ void __launch_bounds__(256) k_vit_layernorm(const float* __restrict__
 // ------------------------------------------------------------------------------------------------ GEMM
 // C[m][n] = sum_k X[m][k] W[n][k]   (X [M][K] bf16 activations, W [N][K] bf16 = nn.Linear weight), fp32 accumulation.
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_EMBED = 3 };
+constexpr int AT_TP = 288;          // attention: keys padded to 9 blocks of 32 (T = 257 tokens); also the row length of V^T
 struct GemmEpi {
     const float* bias;        // [N]
-    // EPI_QKV: q (times `qscale`), k, v as [img][head][T][64] bf16
+    // EPI_QKV: q (times `qscale`) and k as [img][head][T][64] bf16, v TRANSPOSED as [img][head][64][AT_TP] (the attention kernel's
+    // P V product needs its keys contiguous per feature; columns T .. AT_TP - 1 are never written and are masked by the reader)
     __bf16* q; __bf16* k; __bf16* v; int T; int heads; float qscale;
     // EPI_GELU: out [M][N] bf16
     __bf16* out;
@@ -211,10 +213,16 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
                     const int D = N / 3, which = n0 / D, c = n - which * D, head = c >> 6, d = c & 63;
                     const int img = (int)m / e.T;
                     const int t = (int)m - img * e.T;
-                    __bf16* dst = (which == 0 ? e.q : (which == 1 ? e.k : e.v)) + (((int64_t)(img * e.heads + head) * e.T + t) << 6) + d;
-                    const float sc = which == 0 ? e.qscale : 1.0f;
-                    bf16x4 o = {(__bf16)(v[0] * sc), (__bf16)(v[1] * sc), (__bf16)(v[2] * sc), (__bf16)(v[3] * sc)};
-                    *reinterpret_cast<bf16x4*>(dst) = o;
+                    if (which == 2) {            // V^T: the 32 lanes of a half wave write 32 consecutive tokens of one feature row
+                        __bf16* dst = e.v + ((int64_t)(img * e.heads + head) * 64 + d) * AT_TP + t;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dst[i * AT_TP] = (__bf16)v[i];
+                    } else {
+                        __bf16* dst = (which == 0 ? e.q : e.k) + (((int64_t)(img * e.heads + head) * e.T + t) << 6) + d;
+                        const float sc = which == 0 ? e.qscale : 1.0f;
+                        bf16x4 o = {(__bf16)(v[0] * sc), (__bf16)(v[1] * sc), (__bf16)(v[2] * sc), (__bf16)(v[3] * sc)};
+                        *reinterpret_cast<bf16x4*>(dst) = o;
+                    }
                 } else if (EPI == EPI_GELU) {
                     bf16x4 o;
 #pragma unroll
@@ -237,8 +245,9 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ attention
-// One workgroup = (image, head, block of 128 queries); wave w serves queries 32 w .. 32 w + 31 of the block.
-constexpr int AT_TP = 288;          // keys padded to 9 blocks of 32 (T = 257 tokens)
+// One workgroup = (image, head, block of 128 queries); wave w serves queries 32 w .. 32 w + 31 of the block.  (Two workgroups per
+// (image, head) with a second pass for the 257th token in one wave -- 384 workgroups, one round of the chip's slots instead of 576 --
+// measured the same 20 us: the wave with two passes is the critical path.)
 constexpr int AT_KLD = 64 + 8;      // sK rows: 144 B
 constexpr int AT_VLD = AT_TP + 12;  // sVt rows: 600 B -> conflict-free ds_read_b64 down a column of d
 
@@ -249,19 +258,35 @@ __global__ void __launch_bounds__(256, 2) k_vit_attention(const __bf16* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int ih = blockIdx.y;                               // image * heads + head
     const int64_t base = (int64_t)ih * T * 64;
-    // K rows (zero beyond T) and V transposed
-    for (int chunk = tid; chunk < AT_TP * 8; chunk += 256) {
-        const int t = chunk >> 3, dc = (chunk & 7) * 8;
-        bf16x8 kv, vv;
+    // K rows (zero beyond T) and V^T rows (the QKV epilogue wrote V transposed; columns beyond T hold whatever the workspace held:
+    // zeroed here, P is 0 there but 0 x NaN is not): 2304 chunks of 16 B each = 9 per thread, all 18 loads in flight together
+    {
+        const __bf16* Vt = Vh + (int64_t)ih * 64 * AT_TP;
+        bf16x8 kv[9], vv[9];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { kv[i] = (__bf16)0.0f; vv[i] = (__bf16)0.0f; }
-        if (t < T) {
-            kv = *reinterpret_cast<const bf16x8*>(Kh + base + t * 64 + dc);
-            vv = *reinterpret_cast<const bf16x8*>(Vh + base + t * 64 + dc);
+        for (int r = 0; r < 9; ++r) {
+            const int chunk = tid + 256 * r;
+            const int t = chunk >> 3, dc = (chunk & 7) * 8;              // K: row t, features dc .. dc + 7
+            kv[r] = *reinterpret_cast<const bf16x8*>(Kh + base + min(t, T - 1) * 64 + dc);
+            vv[r] = *reinterpret_cast<const bf16x8*>(Vt + chunk * 8);     // V^T: 36 chunks per feature row
         }
-        *reinterpret_cast<bf16x8*>(&sK[t][dc]) = kv;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sVt[dc + i][t] = vv[i];
+        for (int r = 0; r < 9; ++r) {
+            const int chunk = tid + 256 * r;
+            const int t = chunk >> 3, dc = (chunk & 7) * 8;
+            if (t >= T) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kv[r][i] = (__bf16)0.0f;
+            }
+            *reinterpret_cast<bf16x8*>(&sK[t][dc]) = kv[r];
+            const int d = chunk / 36, t8 = (chunk - d * 36) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (t8 + i >= T) vv[r][i] = (__bf16)0.0f;
+            bf16x4 lo4 = {vv[r][0], vv[r][1], vv[r][2], vv[r][3]}, hi4 = {vv[r][4], vv[r][5], vv[r][6], vv[r][7]};
+            *reinterpret_cast<bf16x4*>(&sVt[d][t8]) = lo4;           // rows of 600 B: 8-byte aligned pieces
+            *reinterpret_cast<bf16x4*>(&sVt[d][t8 + 4]) = hi4;
+        }
     }
     const int q = blockIdx.x * 128 + wave * 32 + lr;         // this lane's query (column of every MFMA below)
     const int qc = min(q, T - 1);
@@ -284,19 +309,22 @@ __global__ void __launch_bounds__(256, 2) k_vit_attention(const __bf16* __restri
     // softmax over t for this lane's query: rows t = 32 b + (r & 3) + 8 (r >> 2) + 4 lh live in this lane and in lane ^ 32
     float mx = -INFINITY;
 #pragma unroll
-    for (int b = 0; b < AT_TP / 32; ++b)
+    for (int b = 0; b < AT_TP / 32; ++b) {
+        if (32 * b + 32 > T) {                               // only the last key block(s) hold padding: wave-uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (t >= T) S[b][r] = -INFINITY;
-            mx = fmaxf(mx, S[b][r]);
+            for (int r = 0; r < 16; ++r)
+                if (32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh >= T) S[b][r] = -INFINITY;
         }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, S[b][r]), S[b][r + 1]);      // v_max3_f32
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.0f;
-#pragma unroll
+    const float mxl = mx * 1.4426950408889634f;              // exp(s - mx) = exp2(s log2 e - mx log2 e): one fma + the hardware exp2;
+#pragma unroll                                               // P is rounded to bf16 next
     for (int b = 0; b < AT_TP / 32; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { S[b][r] = expf(S[b][r] - mx); sum += S[b][r]; }
+        for (int r = 0; r < 16; ++r) { S[b][r] = __builtin_amdgcn_exp2f(fmaf(S[b][r], 1.4426950408889634f, -mxl)); sum += S[b][r]; }
     sum += __shfl_xor(sum, 32, 64);
     // O^T[d][q] = sum_t V^T[d][t] P^T[t][q]: the accumulator registers 8 s .. 8 s + 7 of block b are the B fragment of k-step
     // (b, s); its element j is row 16 s + 8 (j >> 2) + 4 lh + (j & 3) of the block, so the V^T fragment is gathered in that order
@@ -404,7 +432,8 @@ __global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows,
         const int nr = min(rch, n_rows - r0);
         if (r0) __syncthreads();                // the previous chunk has been filtered
         // a wave per row, its lanes along the row's segment; twelve loads (4 rows x 3 pieces of 64 floats) in flight per lane
-        // before the first is stored -- one at a time, a chunk cost twelve memory latencies in a row
+        // before the first is stored -- one at a time, a chunk cost twelve memory latencies in a row.  (Requesting the NEXT chunk
+        // before this one is filtered changed nothing: 176 against 180 us for 32 images.)
         for (int rb = threadIdx.x >> 6; rb < nr; rb += 16)
             for (int kb = threadIdx.x & 63; kb < seg; kb += 192) {
                 float v[4][3];
@@ -470,7 +499,7 @@ hipError_t gemm(const __bf16* X, const __bf16* W, int64_t M, int N, int K, const
     // 64-token tiles for small batches (with 128 a 4112-token batch -- 16 images -- leaves CUs idle or a single workgroup per CU);
     // from 24 images on 128-token tiles: each launch alone is 5-15 % slower, but the workgroups read 1/3 fewer operand bytes per flop
     // and with several batches in flight (the bench's four graphs) the total is 5 % faster (17 700 -> 18 700 images/s at 32 images)
-    const bool wide = force ? force == 128 : M >= 6144;
+    const bool wide = force ? force == 128 : M >= 6144;       // (64-token tiles for the N = 384 products only: -1.7 % images/s)
     if (!wide)
         hipLaunchKernelGGL((k_vit_gemm<EPI, 64>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, W, M, N, K, e);
     else
@@ -519,7 +548,8 @@ size_t vit_workspace_bytes(const VitDev& v, int Q) {
     auto take = [&](size_t bytes) { b += (bytes + 255) / 256 * 256; };
     take(M * v.dim * 4);            // x      residual stream, fp32
     take(M * v.dim * 2);            // xn     LayerNorm output / attention output, bf16
-    take(M * v.dim * 2 * 3);        // q, k, v per head
+    take(M * v.dim * 2 * 2);        // q, k per head
+    take((size_t)Q * v.heads * 64 * AT_TP * 2);      // v per head, transposed, rows of AT_TP keys
     take(M * v.mlp * 2);            // MLP hidden
     take(G * v.kp * 2);             // im2col
     return b;
@@ -537,9 +567,9 @@ hipError_t launch_vit_forward(const VitDev& v, const float* images, int Q, int H
     auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
     float* x = (float*)take((size_t)M * D * 4);
     __bf16* xn = (__bf16*)take((size_t)M * D * 2);
-    __bf16* q = (__bf16*)take((size_t)M * D * 2 * 3);
+    __bf16* q = (__bf16*)take((size_t)M * D * 2 * 2);
     __bf16* k = q + M * D;
-    __bf16* vv = k + M * D;
+    __bf16* vv = (__bf16*)take((size_t)Q * v.heads * 64 * AT_TP * 2);
     __bf16* hid = (__bf16*)take((size_t)M * v.mlp * 2);
     __bf16* col = (__bf16*)take((size_t)G * v.kp * 2);
     hipError_t e;
