@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(256) k1_point_density(FieldDev f, const float*
         float xn[3];
         bool valid = live;
         if (MODE == 1) {
-            if (f.mask) valid = valid && (mask_value(f, p) > 0.0f);
             field_normalize(f, p, xn);
+            if (f.mask) valid = valid && (mask_value(f, p, xn) > 0.0f);
         } else {
             xn[0] = p[0]; xn[1] = p[1]; xn[2] = p[2];
         }

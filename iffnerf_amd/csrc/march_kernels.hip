@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
                 if (inside) {
                     float xn[3];
                     field_normalize(f, p, xn);
-                    if (f.mask) mv = mask_value(f, p);
+                    if (f.mask) mv = mask_value(f, p, xn);
                     part = (LPS == 4) ? density_partial(f, xn, lsub) : density_full(f, xn);
                 }
                 const bool valid = inside && (mv > 0.0f);

@@ -103,7 +103,7 @@ __device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation, unsigned n
 __device__ inline float alpha1(const FieldDev& f, const float p[3], bool live) {
     float xn[3];
     field_normalize(f, p, xn);
-    float mv = f.mask ? mask_value(f, p) : 1.0f;
+    float mv = f.mask ? mask_value(f, p, xn) : 1.0f;
     float part = density_full(f, xn);
     bool valid = live && (mv > 0.0f);
     float sigma = valid ? feature2density(f, valid ? part : 0.0f) : 0.0f;
@@ -113,7 +113,7 @@ __device__ inline float alpha1(const FieldDev& f, const float p[3], bool live) {
 __device__ inline float alpha4(const FieldDev& f, const float p[3], int sub, bool live) {
     float xn[3];
     field_normalize(f, p, xn);
-    float mv = f.mask ? mask_value(f, p) : 1.0f;
+    float mv = f.mask ? mask_value(f, p, xn) : 1.0f;
     float part = density_partial(f, xn, sub);
     bool valid = live && (mv > 0.0f);
     float feat = sum4(valid ? part : 0.0f);
@@ -139,7 +139,7 @@ __device__ __forceinline__ void alpha_quad_step(const FieldDev& f, const float x
 __device__ inline float alpha_quad(const FieldDev& f, const float p[3], bool live) {
     float xn[3];
     field_normalize(f, p, xn);
-    const float mv = f.mask ? mask_value(f, p) : 1.0f;
+    const float mv = f.mask ? mask_value(f, p, xn) : 1.0f;
     const bool valid = live && (mv > 0.0f);
     const int sub = threadIdx.x & 3;
     float feat = 0.0f;
