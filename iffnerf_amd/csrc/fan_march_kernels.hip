@@ -78,7 +78,32 @@ __device__ __forceinline__ float sum4_dpp(float v) {
 }
 // the value of lane (i xor 4): reverse inside the quad (quad_perm [3,2,1,0]), then mirror the 8-lane half row (row_half_mirror)
 __device__ __forceinline__ float xor4_dpp(float v) { return dpp_mov<0x141>(dpp_mov<0x1B>(v)); }
-// bilinear / linear combination in the operation order of lerp_plane4 / lerp_line4 (iff_device.h)
+// Bilinear / linear combination of tap quarters in the operation order of lerp_plane4 / lerp_line4 (iff_device.h).
+// NOT as packed fp32 instructions.  The natural form (v_pk_mul_f32 / v_pk_fma_f32 on register pairs, the weight broadcast by op_sel:
+// -DFAN_PACKED_LERP builds it) returned wrong sums for the LAST SIXTEEN LANES of a wave -- rays 6, 7 (+ 8 w) of a tile -- about once in
+// 30 launches of 19 000 tiles, and only while a workgroup of the encoder / logits kernel (k5_trunk_h: fp16 MFMA) shared the CU: with
+// four captured steps in flight the last tiles of a march run next to another step's trunk.  Nothing else changes the rate: extra
+// waits and barriers around every LDS and memory access of the phase, the cross-lane sums as ds_bpermute instead of DPP, two waves
+// per SIMD instead of three, the matrix-core rows of phase D permuted; evaluating phase C twice in the same workgroup and
+// comparing (-DFAN_CHECK_TWICE) catches every event, so it is a transient of the execution, not stale or overwritten LDS.  With
+// one v_mul / v_fma per component: 0 events in 1 600 launches (scripts/replay_vs_eager_stages.py, ONLY=trunk) where the packed form has
+// 30-40 (the packed instructions with every weight as a REAL register pair instead of the op_sel broadcast: also 0 in 1 000, and no
+// faster); the fan kernel is 5 % slower for it, a step 2-3 %.  The empty asm keeps the vectoriser from pairing them again.
+__device__ __forceinline__ float opq(float v) { asm volatile("" : "+v"(v)); return v; }
+#ifndef FAN_PACKED_LERP
+__device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
+    f32q r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = opq(fmaf(se[e], pw[3], opq(fmaf(sw[e], pw[2], opq(fmaf(ne[e], pw[1], opq(nw[e] * pw[0])))))));
+    return r;
+}
+__device__ __forceinline__ f32q lerp_line_q(f32q lo, f32q hi, const float lw[2]) {
+    f32q r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = opq(fmaf(hi[e], lw[1], opq(lo[e] * lw[0])));
+    return r;
+}
+#else
 __device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
     f32q r = nw * splat(pw[0]);
     r = __builtin_elementwise_fma(ne, splat(pw[1]), r);
@@ -90,6 +115,7 @@ __device__ __forceinline__ f32q lerp_line_q(f32q lo, f32q hi, const float lw[2])
     f32q r = lo * splat(lw[0]);
     return __builtin_elementwise_fma(hi, splat(lw[1]), r);
 }
+#endif
 
 // ---- coalesced patch fetch: chunk = one 16-B piece; a patch row (12 texels) is one contiguous run of the table.
 // `fast` = the patch lies inside the table (no clamping).  Byte offset of chunk `chunk` of a C-channel plane patch:
@@ -599,6 +625,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
             __builtin_amdgcn_sched_barrier(0);
             STAMP(6 + 2 * i);
             const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
+            auto accumulate = [&](float (&acc)[36]) {
             unsigned m = mymask;
             // the record of the next sample is read one trip ahead
             u32q na = {0u, 0u, 0u, 0u}, nb = {0u, 0u, 0u, 0u};
@@ -626,12 +653,28 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
                     const f32q sw = *reinterpret_cast<const f32q*>(P + 16 * j + db), se = *reinterpret_cast<const f32q*>(P + 16 * j + db + da);
                     const f32q ll = *reinterpret_cast<const f32q*>(L + 16 * j), lh = *reinterpret_cast<const f32q*>(L + 16 * j + dv);
                     const f32q pr = lerp_plane_q(nw, ne, sw, se, pw) * lerp_line_q(ll, lh, lw);
-                    accp[12 * j + 4 * i + 0] = fmaf(rv.w, pr.x, accp[12 * j + 4 * i + 0]);
-                    accp[12 * j + 4 * i + 1] = fmaf(rv.w, pr.y, accp[12 * j + 4 * i + 1]);
-                    accp[12 * j + 4 * i + 2] = fmaf(rv.w, pr.z, accp[12 * j + 4 * i + 2]);
-                    accp[12 * j + 4 * i + 3] = fmaf(rv.w, pr.w, accp[12 * j + 4 * i + 3]);
+                    acc[12 * j + 4 * i + 0] = fmaf(rv.w, pr.x, acc[12 * j + 4 * i + 0]);
+                    acc[12 * j + 4 * i + 1] = fmaf(rv.w, pr.y, acc[12 * j + 4 * i + 1]);
+                    acc[12 * j + 4 * i + 2] = fmaf(rv.w, pr.z, acc[12 * j + 4 * i + 2]);
+                    acc[12 * j + 4 * i + 3] = fmaf(rv.w, pr.w, acc[12 * j + 4 * i + 3]);
                 }
             }
+            };
+            accumulate(accp);
+#ifdef FAN_CHECK_TWICE
+            {
+                float accq[36];
+#pragma unroll
+                for (int q = 0; q < 36; ++q) accq[q] = 0.0f;
+                accumulate(accq);
+                bool bad = false;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) bad = bad || (accq[12 * j + 4 * i + e4] != accp[12 * j + 4 * i + e4]);
+                if (bad) accp[4 * i] = __builtin_nanf("");        // poison: the ray's features become NaN, its colour 0 (the final clamp)
+            }
+#endif
             STAMP(7 + 2 * i);
             FAN_EXIT(7 + 2 * i);
         }

@@ -210,6 +210,34 @@ def test_captured_query_replays_like_eager(dev):
     assert torch.equal(cq.c2w, eager[1][0]) and torch.equal(cq2.c2w, eager[3][0])
 
 
+def test_concurrent_captured_steps_reproduce_the_eager_path(dev):
+    """Four captured cold steps replayed concurrently on four streams (how bench.py and a serving loop run them) at a BASELINE
+    config's full size: every replay equals the eager path on the same seed counter bit for bit.  This is the case in which the fan
+    kernel's packed-fp32 tap combination returned wrong sums for sixteen lanes of a wave once in ~30 launches while a workgroup of
+    the trunk kernel shared the CU (fan_march_kernels.hip, lerp_plane_q): at that rate the 160 checks below hold 3-6 events."""
+    from iffnerf_amd.pipeline import PosePipeline, CapturedBatchQuery
+    wl = synthetic.WORKLOADS["truck32k"]
+    pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt("truck32k"), synthetic.make_id_weights(seed=99), dev)
+    B, P = wl["queries"], wl["gen_points"]
+    tokens = torch.stack([synthetic.make_tokens(256, 384, seed=7 + q) for q in range(B)]).to(dev)
+    seeds = [1000 + 7919 * i for i in range(4)]
+    graphs = [CapturedBatchQuery(pipe, tokens.shape, P, seed=seeds[i], k=100) for i in range(4)]
+    for g in graphs:
+        g.tokens.copy_(tokens)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    torch.cuda.synchronize(dev)
+    for r in range(40):
+        for _ in range(3):
+            for i, g in enumerate(graphs):
+                with torch.cuda.stream(streams[i]):
+                    g.replay()
+        torch.cuda.synchronize(dev)
+        for i, g in enumerate(graphs):
+            g.check()
+            c2w, idx, val = pipe.query_batch(tokens, P, seeds[i], 100, seed_offset=g.counter)
+            assert torch.equal(idx, g.idx) and torch.equal(val, g.val) and torch.equal(c2w, g.c2w), (r, i, float((val - g.val).abs().max()))
+
+
 def test_batched_cold_queries_equal_single_queries(dev):
     """query_batch: B cold queries per set of launches (batched sampler, grid.y = query in the encoder/logits launch).
     Query b must equal the single-query path with seed + b * SAMPLER_SEED_STRIDE bit for bit; also as a captured graph."""
