@@ -83,7 +83,8 @@ __device__ __forceinline__ float xor4_dpp(float v) { return dpp_mov<0x141>(dpp_m
 // -DFAN_PACKED_LERP builds it) returned wrong sums for the LAST SIXTEEN LANES of a wave -- rays 6, 7 (+ 8 w) of a tile -- about once in
 // 30 launches of 19 000 tiles, and only while a workgroup of the encoder / logits kernel (k5_trunk_h: fp16 MFMA) shared the CU: with
 // four captured steps in flight the last tiles of a march run next to another step's trunk.  Nothing else changes the rate: extra
-// waits and barriers around every LDS and memory access of the phase, the cross-lane sums as ds_bpermute instead of DPP, two waves
+// waits and barriers around every LDS and memory access of the phase (a full LDS wait and eight idle cycles before the packed
+// instructions included), the cross-lane sums as ds_bpermute instead of DPP, two waves
 // per SIMD instead of three, the matrix-core rows of phase D permuted; evaluating phase C twice in the same workgroup and
 // comparing (-DFAN_CHECK_TWICE) catches every event, so it is a transient of the execution, not stale or overwritten LDS.  With
 // one v_mul / v_fma per component: 0 events in 1 600 launches (scripts/replay_vs_eager_stages.py, ONLY=trunk) where the packed form has
