@@ -475,8 +475,12 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     result["roofline"]["selected_as"] = "the longest launch of a step by this run's hipEvent timings"
     others = {k["kernel"].split(" (")[0]: k for k in kernels[1:]}
     if plan != 3:
-        others["k_ref_shade<27, true>"] = {"avg_launch_ms": round(march_launch_ms[2], 4), "traffic": traffic("k_ref_shade<27, true>"),
-                                           "note": "Ref head per ray (ref.py:103-152): vector ALU from LDS-staged weights, no roofline"}
+        # the reference's head shape runs in the 8-lanes-per-ray form (k_ref_shade_oct); other shapes in the 16-lane vector form
+        shade_tr = traffic("k_ref_shade_oct<true>")
+        shade_name = "k_ref_shade_oct<true>" if shade_tr is not None or os.environ.get("IFF_REF_SHADE_GROUP16", "0") != "1" else "k_ref_shade<27, true>"
+        others[shade_name] = {"avg_launch_ms": round(march_launch_ms[2], 4),
+                              "traffic": shade_tr if shade_name.startswith("k_ref_shade_oct") else traffic("k_ref_shade<27, true>"),
+                              "note": "Ref head per ray (ref.py:103-152): bottleneck on the fp32 matrix cores, the rest vector ALU from LDS-staged weights, no roofline"}
     result["roofline"]["other_kernels"] = others
     if world_size == 1 and not shared:
         # warm path (rays resident: the reference's eval semantics, train_eval_pose_est.py:131-149): stage C only, 16 query
