@@ -238,6 +238,50 @@ def test_concurrent_captured_steps_reproduce_the_eager_path(dev):
             assert torch.equal(idx, g.idx) and torch.equal(val, g.val) and torch.equal(c2w, g.c2w), (r, i, float((val - g.val).abs().max()))
 
 
+def test_concurrent_warm_and_image_graphs_reproduce_the_eager_path(dev):
+    """The other two graph forms of the bench -- a batch of query images against resident rays, and image in -> pose out (resize /
+    crop, native ViT-S/14, token assembly, stage C) -- replayed four at a time: every replay equals the same call run eagerly."""
+    from iffnerf_amd.hip_vit import NativeViT
+    from iffnerf_amd.image_frontend import ImageFrontEnd
+    from iffnerf_amd.pipeline import PosePipeline, CapturedImageQuery
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    wl = synthetic.WORKLOADS["lego16k"]
+    pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt("lego16k"), synthetic.make_id_weights(seed=99), dev)
+    ori, dirs, rgb = pipe.emit(wl["gen_points"], seed=42)
+    resident = pipe.make_resident(ori, dirs, rgb)
+    net, grid, _ = create_standin_backbone(seed=0)
+    fe = ImageFrontEnd(NativeViT(net.to(dev), grid), grid)
+    gen = torch.Generator().manual_seed(3)
+    Q, forms = 16, []
+    for i in range(4):                                           # warm: tokens in
+        tok = torch.stack([synthetic.make_tokens(256, 384, seed=100 * i + q) for q in range(Q)]).to(dev)
+        for _ in range(2):
+            pipe.identify_resident(tok, resident, 100)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = pipe.identify_resident(tok, resident, 100)
+        forms.append((g, out, lambda tok=tok: pipe.identify_resident(tok, resident, 100), tok))
+    for i in range(4):                                           # image in -> pose out
+        imgs = torch.rand(Q, 800, 800, 3, generator=gen).to(dev)
+        masks = (torch.rand(Q, 800, 800, generator=gen) > 0.2).float().to(dev)
+        cq = CapturedImageQuery(pipe, fe, imgs.shape, resident, 100)
+        cq.imgs.copy_(imgs), cq.masks.copy_(masks)
+        forms.append((cq.graph, (cq.c2w, cq.idx, cq.val), lambda imgs=imgs, masks=masks: pipe.identify_images_resident(fe, imgs, masks, resident, 100), cq))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    torch.cuda.synchronize(dev)
+    for group in (forms[:4], forms[4:], forms[2:6]):             # four warm, four image, two of each together
+        for r in range(8):
+            for _ in range(3):
+                for i, f in enumerate(group):
+                    with torch.cuda.stream(streams[i]):
+                        f[0].replay()
+            torch.cuda.synchronize(dev)
+            for i, f in enumerate(group):
+                for a, b in zip(f[2](), f[1]):
+                    assert torch.equal(a, b), (r, i)
+
+
 def test_batched_cold_queries_equal_single_queries(dev):
     """query_batch: B cold queries per set of launches (batched sampler, grid.y = query in the encoder/logits launch).
     Query b must equal the single-query path with seed + b * SAMPLER_SEED_STRIDE bit for bit; also as a captured graph."""
