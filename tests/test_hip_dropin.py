@@ -210,14 +210,16 @@ def test_captured_query_replays_like_eager(dev):
     assert torch.equal(cq.c2w, eager[1][0]) and torch.equal(cq2.c2w, eager[3][0])
 
 
-def test_concurrent_captured_steps_reproduce_the_eager_path(dev):
+@pytest.mark.parametrize("config,rounds", [("truck32k", 40), ("bicycle64k", 15)])
+def test_concurrent_captured_steps_reproduce_the_eager_path(dev, config, rounds):
     """Four captured cold steps replayed concurrently on four streams (how bench.py and a serving loop run them) at a BASELINE
     config's full size: every replay equals the eager path on the same seed counter bit for bit.  This is the case in which the fan
     kernel's packed-fp32 tap combination returned wrong sums for sixteen lanes of a wave once in ~30 launches while a workgroup of
-    the trunk kernel shared the CU (fan_march_kernels.hip, lerp_plane_q): at that rate the 160 checks below hold 3-6 events."""
+    the trunk kernel shared the CU (fan_march_kernels.hip, lerp_plane_q): at that rate the 160 truck32k checks below hold 3-6 events.
+    bicycle64k runs the general march kernels (K4a / K4b / the Ref head launch) next to the trunk."""
     from iffnerf_amd.pipeline import PosePipeline, CapturedBatchQuery
-    wl = synthetic.WORKLOADS["truck32k"]
-    pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt("truck32k"), synthetic.make_id_weights(seed=99), dev)
+    wl = synthetic.WORKLOADS[config]
+    pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(config), synthetic.make_id_weights(seed=99), dev)
     B, P = wl["queries"], wl["gen_points"]
     tokens = torch.stack([synthetic.make_tokens(256, 384, seed=7 + q) for q in range(B)]).to(dev)
     seeds = [1000 + 7919 * i for i in range(4)]
@@ -226,7 +228,7 @@ def test_concurrent_captured_steps_reproduce_the_eager_path(dev):
         g.tokens.copy_(tokens)
     streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
     torch.cuda.synchronize(dev)
-    for r in range(40):
+    for r in range(rounds):
         for _ in range(3):
             for i, g in enumerate(graphs):
                 with torch.cuda.stream(streams[i]):
