@@ -540,11 +540,11 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
             torch.cuda.synchronize(device)
             return round(n_i * IQ / (time.perf_counter() - ti), 2)
 
-        net, grid, _ = create_standin_backbone(seed=0)
-        net = net.to(device)
-        from iffnerf_amd.hip_vit import NativeViT
-        result["image_to_pose_per_s"] = image_rate(ImageFrontEnd(NativeViT(net, grid), grid), WQ)
-        result["image_to_pose_per_s_torch_fp32_backbone"] = image_rate(ImageFrontEnd(net, grid), 16)      # (MIOpen's first use of a new batch shape takes minutes)
+        net, grid, _ = create_standin_backbone(seed=0, native=True)           # what create_backbone("dino") returns by default
+        stock, _, _ = create_standin_backbone(seed=0)                          # the same weights as stock fp32 torch ops
+        net, stock = net.to(device), stock.to(device)
+        result["image_to_pose_per_s"] = image_rate(ImageFrontEnd(net, grid), WQ)
+        result["image_to_pose_per_s_torch_fp32_backbone"] = image_rate(ImageFrontEnd(stock, grid), 16)      # (MIOpen's first use of a new batch shape takes minutes)
         result["image_to_pose_note"] = ("32 (stock torch backbone: 16) synthetic 800x800 RGBA queries per captured graph: bicubic resize / crop / normalise + ViT-S/14 "
                                         "(DINOv2's architecture, seeded stand-in weights) + token assembly kernel + stage C on resident rays "
                                         "with the cached encoder; 4 graphs in flight; never part of `value`.  image_to_pose_per_s runs the "

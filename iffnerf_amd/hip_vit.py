@@ -1,9 +1,10 @@
 """The image backbone on the matrix cores: DINOv2 ViT-S/14 ``forward_features`` through ``iff_vit_forward``.
 
-``ViTHandle`` owns the bf16 / fp32 weight slab of one network; ``NativeViT`` wraps a backbone module (DINOv2's ``dinov2_vits14``
-from ``torch.hub`` -- reference pose_estimation/backbone.py:12-14 -- or the seeded stand-in of this package's backbone.py) so that
-``forward_features(x)["x_norm_patchtokens"]`` (what pose_estimation/identification_module.py:141 reads) runs in libiffnerf_hip
-under ``torch.no_grad``; with autograd enabled on a trainable backbone the wrapped module's own torch forward runs instead.
+``ViTHandle`` owns the weight slab of one network; ``serve_natively`` installs the native ``forward_features`` ON a backbone module
+(DINOv2's ``dinov2_vits14`` from ``torch.hub`` -- reference pose_estimation/backbone.py:12-14 -- or the seeded stand-in of this
+package's backbone.py) so that ``forward_features(x)["x_norm_patchtokens"]`` (what pose_estimation/identification_module.py:141
+reads) runs in libiffnerf_hip under ``torch.no_grad`` while the module -- class, parameters, ``state_dict`` keys -- stays what the
+reference's ``create_backbone`` returns; with autograd enabled on a trainable backbone the module's own torch forward runs.
 State-dict keys of both sources are understood (``blocks.i.attn.qkv.*``, ``blocks.i.ls1.gamma``, ``blocks.i.mlp.fc1.*`` for
 DINOv2; ``blocks.i.qkv.*``, ``blocks.i.ls1``, ``blocks.i.fc1.*`` for the stand-in).
 """
@@ -20,10 +21,10 @@ from . import _lib
 from ._lib import check, dptr, stream_ptr
 
 
-def interpolate_pos_embed(pos: torch.Tensor, gh: int, gw: int, patch: int = 14) -> torch.Tensor:
+def interpolate_pos_embed(pos: torch.Tensor, gh: int, gw: int, patch: int = 14, differentiable: bool = False) -> torch.Tensor:
     """DINOv2's ``interpolate_pos_encoding`` for an input of gh x gw patches: ``pos`` [1, 1 + n, D] -> [1 + gh*gw, D].  The class
     position is kept; the patch grid is resized bicubically with the +0.1 scale-factor offset of the original implementation."""
-    pos = pos.detach().float()
+    pos = pos.float() if differentiable else pos.detach().float()
     n = pos.shape[1] - 1
     if n == gh * gw:
         return pos[0].contiguous()
@@ -126,15 +127,22 @@ class ViTHandle:
         return (tok, cls) if want_cls else tok
 
 
-class NativeViT(torch.nn.Module):
-    """A backbone module (``forward_features``) served by ``iff_vit_forward``.  Keeps the wrapped module -- its parameters,
-    ``state_dict`` and training behaviour are unchanged; only no-grad inference on the GPU goes through the HIP kernels."""
+class _NativeForwardFeatures:
+    """The callable installed as a backbone module's ``forward_features`` by ``serve_natively``.  It holds the module it serves (the
+    module holds it in turn: an ordinary reference cycle) and the ``iff_vit`` handle built from the module's CURRENT parameters."""
 
-    def __init__(self, module: torch.nn.Module, grid=(16, 16), patch: int = 14):
-        super().__init__()
+    def __init__(self, module: torch.nn.Module, grid, patch: int):
         self.module, self.grid, self.patch = module, (int(grid[0]), int(grid[1])), int(patch)
         self._handle: Optional[ViTHandle] = None
         self._key = None
+
+    # a handle is a device resource of THIS process: copies and pickles of the module start without one
+    def __getstate__(self):
+        return {"module": self.module, "grid": self.grid, "patch": self.patch, "_handle": None, "_key": None}
+
+    def stock(self, x, *args, **kwargs):
+        """The module's own (class-level) ``forward_features``: stock torch ops."""
+        return type(self.module).forward_features(self.module, x, *args, **kwargs)
 
     def _vit(self, device) -> ViTHandle:
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
@@ -144,12 +152,39 @@ class NativeViT(torch.nn.Module):
             self._handle, self._key = ViTHandle(self.module.state_dict(), device, self.grid, self.patch), key
         return self._handle
 
-    def forward_features(self, x, masks=None):
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.module.parameters()))
-        if needs_grad or masks is not None:
-            return self.module.forward_features(x) if masks is None else self.module.forward_features(x, masks)
+    def __call__(self, x, masks=None, *args, **kwargs):
+        if not isinstance(x, torch.Tensor) or masks is not None or args or kwargs:
+            return self.stock(x, masks, *args, **kwargs)          # token masking / list inputs: DINOv2's training-side forms
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.module.parameters())):
+            return self.stock(x)
         tok, cls = self._vit(x.device).forward(x, want_cls=True)
         return {"x_norm_clstoken": cls, "x_norm_patchtokens": tok}
 
-    def forward(self, x):
-        return self.forward_features(x)["x_norm_clstoken"]
+
+def serve_natively(module: torch.nn.Module, grid=(16, 16), patch: int = 14) -> torch.nn.Module:
+    """Serve ``module.forward_features`` (what pose_estimation/identification_module.py:141 calls) from ``iff_vit_forward`` and
+    return THE SAME module.  Nothing is wrapped: the module keeps its class, its parameters and its ``state_dict`` keys, so an
+    ``IdentificationModule`` built on it saves and strict-loads ``image_preprocessing_net.<backbone key>`` exactly as the reference
+    does (train_eval_pose_est.py:59-66, pose_estimation/train.py:226).  Only the instance attribute ``forward_features`` is
+    installed: no-grad inference on a GPU tensor goes through the HIP kernels (the handle is rebuilt when a parameter moves or
+    changes in place); with autograd enabled on a trainable backbone, with token masks or list inputs the module's own torch
+    forward runs.  ``restore_stock(module)`` removes it."""
+    if not hasattr(type(module), "forward_features"):
+        raise RuntimeError(f"{type(module).__name__} has no forward_features: not a DINOv2-style backbone")
+    restore_stock(module)
+    object.__setattr__(module, "forward_features", _NativeForwardFeatures(module, grid, patch))
+    return module
+
+
+def restore_stock(module: torch.nn.Module) -> torch.nn.Module:
+    """Undo ``serve_natively``: ``forward_features`` is the class's method again."""
+    cur = module.__dict__.get("forward_features")
+    if isinstance(cur, _NativeForwardFeatures):
+        if cur._handle is not None:
+            cur._handle.close()
+        object.__delattr__(module, "forward_features")
+    return module
+
+
+def is_served_natively(module: torch.nn.Module) -> bool:
+    return isinstance(module.__dict__.get("forward_features"), _NativeForwardFeatures)

@@ -29,10 +29,10 @@ if WHAT == "warm":
         graphs.append((g, out, lambda i=i: pipe.identify_resident(toks[i], resident, 100)))
 else:
     from iffnerf_amd.image_frontend import ImageFrontEnd
-    from iffnerf_amd.hip_vit import NativeViT
+    from iffnerf_amd.hip_vit import serve_natively
     from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
     net, grid, _ = create_standin_backbone(seed=0)
-    fe = ImageFrontEnd(NativeViT(net.to(dev), grid), grid)
+    fe = ImageFrontEnd(serve_natively(net.to(dev), grid), grid)
     for i in range(NF):
         imgs = torch.rand(Q, 800, 800, 3, generator=gen).to(dev)
         masks = (torch.rand(Q, 800, 800, generator=gen) > 0.2).float().to(dev)

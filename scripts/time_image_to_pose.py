@@ -5,7 +5,7 @@ import torch
 from iffnerf_amd import synthetic
 from iffnerf_amd.pipeline import PosePipeline, CapturedImageQuery
 from iffnerf_amd.image_frontend import ImageFrontEnd
-from iffnerf_amd.hip_vit import NativeViT
+from iffnerf_amd.hip_vit import serve_natively
 from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
 dev = torch.device("cuda:0")
 wl = synthetic.WORKLOADS["lego16k"]
@@ -13,7 +13,7 @@ pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt("lego16k"), sy
 ori, dirs, rgb = pipe.emit(wl["gen_points"], seed=42)
 resident = pipe.make_resident(ori, dirs, rgb)
 net, grid, _ = create_standin_backbone(seed=0)
-fe = ImageFrontEnd(NativeViT(net.to(dev), grid), grid)
+fe = ImageFrontEnd(serve_natively(net.to(dev), grid), grid)
 gen = torch.Generator().manual_seed(11)
 NF = int(os.environ.get("INFLIGHT", "4"))
 for Q in [int(x) for x in os.environ.get("QS", "16,32").split(",")]:

@@ -21,6 +21,9 @@ Vectors (names follow SURVEY.md section 8c):
   g12_march_grad    d loss / d rays through forward(rays) (slab sampler) and through the point-centred sampler, the
                     autograd path of inerf/estimate_pose_inerf.py:164-176 (`python make_golden.py g12` writes only this one)
   g13_inerf_host    CameraTransfer, get_ray_directions_Ks / get_rays, SoftDiceLossV2 of the iNeRF loop (`... g13`)
+  g14_api_surface   (JSON) the boundary itself as the imported reference presents it: inspect.signature of every callable the
+                    mirror keeps, state_dict keys + shapes of IdentificationModule("dino") over a DINOv2-keyed backbone and of
+                    TensorVMSplit, the checkpoint's kwargs keys (`... g14`)
 """
 import hashlib
 import io
@@ -180,7 +183,114 @@ def g13():
          dice_logits=logits.detach(), dice_labels=labels, dice_loss=dl.detach(), dice_grad=gl)
 
 
+API_SURFACE = {
+    "pose_estimation.model_utils": ["load_model", "explore_model"],
+    "pose_estimation.sampling": ["iterative_surface_sampling_process", "samples_points_normals", "generate_all_possible_rays",
+                                 "evaluate_viewdirs_color", "sampling_isocell", "has_valid_occupancy_grid"],
+    "pose_estimation.isocell": ["isocell_distribution", "rotate_isocell"],
+    "pose_estimation.backbone": ["create_backbone"],
+    "pose_estimation.ray_preprocessor": ["RayPreprocessor.__init__", "RayPreprocessor.forward"],
+    "pose_estimation.multihead_attention": ["scaled_attention_product", "MultiHeadAttention.__init__", "MultiHeadAttention.forward"],
+    "pose_estimation.identification_module": ["IdentificationModule.__init__", "IdentificationModule.get_img_position_encoding",
+                                              "IdentificationModule.image_processing", "IdentificationModule.run_attention",
+                                              "IdentificationModule.forward", "IdentificationModule.test_image"],
+    "pose_estimation.pose_geometry": ["compute_line_intersection_impl2", "exclude_negatives", "make_rotation_mat"],
+    "pose_estimation.errors": ["compute_translation_error", "compute_angular_error"],
+    "pose_estimation.test": ["test_pose_estimation"],
+    "models.tensorBase": ["positional_encoding", "raw2alpha", "AlphaGridMask.__init__", "AlphaGridMask.sample_alpha",
+                          "AlphaGridMask.normalize_coord", "TensorBase.__init__", "TensorBase.forward", "TensorBase.compute_alpha",
+                          "TensorBase.normalize_coord", "TensorBase.feature2density", "TensorBase.sample_point_color",
+                          "TensorBase.sample_ray", "TensorBase.update_stepSize", "TensorBase.get_kwargs", "TensorBase.save",
+                          "TensorBase.load"],
+    "models.tensoRF": ["TensorVMSplit.__init__", "TensorVMSplit.compute_densityfeature", "TensorVMSplit.compute_appfeature",
+                       "TensorVMSplit.init_svd_volume"],
+    "models.ref": ["Ref.__init__", "Ref.forward", "Ref.compute_normals"],
+    "renderer": ["OctreeRender_trilinear_fast", "evaluation"],
+    "ray_utils": ["get_ray_directions_Ks", "get_rays"],
+    "inerf.inerf": ["vec2ss_matrix", "CameraTransfer.__init__", "CameraTransfer.forward", "img2mse"],
+    "inerf.dice_loss": ["SoftDiceLossV2.__init__", "SoftDiceLossV2.forward"],
+    "inerf.estimate_pose_inerf": ["pose_estimation"],
+}
+
+
+def signature_record(fn):
+    """[[name, kind, default-as-repr or None]] of a callable, without self."""
+    import inspect
+    out = []
+    for p_ in inspect.signature(fn).parameters.values():
+        if p_.name == "self":
+            continue
+        out.append([p_.name, p_.kind.name, None if p_.default is inspect.Parameter.empty else repr(p_.default)])
+    return out
+
+
+def g14(ref):
+    """The boundary as data: signatures, state_dict keys and shapes, checkpoint kwargs -- read off the imported reference."""
+    import importlib
+    import json
+    import types
+    sigs, missing = {}, []
+    # modules _reference_import leaves as placeholders (their imports drag in OpenCV / kornia / lietorch): real import, inert names
+    for name in ("inerf", "inerf.estimate_pose_inerf"):
+        sys.modules.pop(name, None)
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
+    for attr in ("cvtColor", "COLOR_RGB2GRAY", "SIFT_create", "dilate", "INTER_LANCZOS4", "INTER_LINEAR"):
+        if not hasattr(cv2, attr):
+            setattr(cv2, attr, None)
+    sys.modules["cv2"] = cv2
+    for name in ("kornia", "kornia.geometry", "kornia.geometry.liegroup", "imageio", "imageio.v2", "dataLoader", "dataLoader.ray_utils",
+                 "dataLoader.utils"):
+        if name not in sys.modules or not hasattr(sys.modules[name], "__path__"):
+            m_ = types.ModuleType(name); m_.__path__ = []; sys.modules[name] = m_
+    sys.modules["kornia.geometry.liegroup"].Se3 = object
+    sys.modules["imageio.v2"].imread = None
+    sys.modules["dataLoader.ray_utils"].get_rays = sys.modules["dataLoader.ray_utils"].ndc_rays_blender = None     # names only
+    sys.modules["dataLoader.utils"].downsample = None
+    for modname, names in API_SURFACE.items():
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                mod = importlib.import_module(modname)
+        except Exception as e:                                          # an import this container cannot satisfy: recorded, not hidden
+            missing.append([modname, f"{type(e).__name__}: {e}"])
+            continue
+        if not (getattr(mod, "__file__", "") or "").startswith(ri.REFERENCE_ROOT):
+            raise RuntimeError(f"{modname} did not resolve to the reference checkout: {getattr(mod, '__file__', None)}")
+        for dotted in names:
+            obj = mod
+            for part in dotted.split("."):
+                obj = getattr(obj, part)
+            sigs[f"{modname}:{dotted}"] = signature_record(obj)
+    # state_dict of IdentificationModule("dino") over a backbone with DINOv2's module tree (the hub model needs the network)
+    from iffnerf_amd.pose_estimation.backbone import SeededViTS14
+    IM = ref.identification_module
+    keep = IM.create_backbone
+    IM.create_backbone = lambda type="dino", pretrained=False, **k: (SeededViTS14(seed=0), (16, 16), 384)
+    try:
+        idm = IM.IdentificationModule("dino")
+    finally:
+        IM.create_backbone = keep
+    id_sd = {k: list(v.shape) for k, v in idm.state_dict().items()}
+    m, ck = build_ref_model(ref, TINY)
+    out = {
+        "signatures": sigs,
+        "modules_not_importable_here": missing,
+        "id_module_state_dict": id_sd,
+        "id_module_children": [n for n, _ in idm.named_children()],
+        "id_module_attrs": {"backbone_wh": list(idm.backbone_wh), "img_num_features": int(idm.img_num_features)},
+        "tensorf_state_dict": {k: list(v.shape) for k, v in m.state_dict().items()},
+        "tensorf_kwargs_keys": sorted(m.get_kwargs().keys()),
+        "tensorf_grid": list(TINY["grid"]),
+    }
+    path = os.path.join(HERE, "g14_api_surface.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"g14_api_surface: {len(sigs)} signatures, {len(id_sd)} id-module keys, {len(missing)} modules not importable")
+
+
 def main():
+    if sys.argv[1:] == ["g14"]:
+        g14(ri.install())
+        return
     if sys.argv[1:] == ["g13"]:
         ri.install()
         g13()
@@ -380,6 +490,7 @@ def main():
          n_samples=np.int64(mu.nSamples), mask_value=mu.alphaMask.sample_alpha(xu))
     g12(ref)
     g13()
+    g14(ref)
     print("done")
 
 

@@ -243,7 +243,7 @@ def test_concurrent_captured_steps_reproduce_the_eager_path(dev, config, rounds)
 def test_concurrent_warm_and_image_graphs_reproduce_the_eager_path(dev):
     """The other two graph forms of the bench -- a batch of query images against resident rays, and image in -> pose out (resize /
     crop, native ViT-S/14, token assembly, stage C) -- replayed four at a time: every replay equals the same call run eagerly."""
-    from iffnerf_amd.hip_vit import NativeViT
+    from iffnerf_amd.hip_vit import serve_natively
     from iffnerf_amd.image_frontend import ImageFrontEnd
     from iffnerf_amd.pipeline import PosePipeline, CapturedImageQuery
     from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
@@ -252,7 +252,7 @@ def test_concurrent_warm_and_image_graphs_reproduce_the_eager_path(dev):
     ori, dirs, rgb = pipe.emit(wl["gen_points"], seed=42)
     resident = pipe.make_resident(ori, dirs, rgb)
     net, grid, _ = create_standin_backbone(seed=0)
-    fe = ImageFrontEnd(NativeViT(net.to(dev), grid), grid)
+    fe = ImageFrontEnd(serve_natively(net.to(dev), grid), grid)
     gen = torch.Generator().manual_seed(3)
     Q, forms = 16, []
     for i in range(4):                                           # warm: tokens in

@@ -150,7 +150,7 @@ def test_native_vit_matches_the_fp32_torch_module(dev):
     key schemes are understood by ViTHandle).  Token features agree to bf16-operand tolerance, and stage C fed with either token
     set picks the same rays."""
     from iffnerf_amd import hip_identify as H
-    from iffnerf_amd.hip_vit import NativeViT, ViTHandle
+    from iffnerf_amd.hip_vit import ViTHandle, is_served_natively, restore_stock, serve_natively
     from iffnerf_amd.image_frontend import token_assemble
     from iffnerf_amd.pipeline import PosePipeline
     from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
@@ -170,26 +170,31 @@ def test_native_vit_matches_the_fp32_torch_module(dev):
         assert torch.isfinite(tok).all() and err <= 4e-2 * scale, (err, scale)           # bf16 operands: ~2^-8 per product, 12 blocks
         assert float(cos.min()) > 0.9995
         assert float((cls - want["x_norm_clstoken"]).abs().max()) <= 4e-2 * scale
-        # DINOv2's key names load too (attn.qkv / ls1.gamma / mlp.fc1) and give the same bits
+        # the compact key names of earlier table files load too (qkv / ls1 / fc1 without attn. / .gamma / mlp.) and give the same bits
         sd = {}
         for k, v in net.state_dict().items():
-            k2 = k
-            for a, b in ((".qkv.", ".attn.qkv."), (".proj.", ".attn.proj."), (".fc1.", ".mlp.fc1."), (".fc2.", ".mlp.fc2.")):
-                if k.startswith("blocks.") and a in k and "patch_embed" not in k:
-                    k2 = k.replace(a, b)
-            if k.startswith("blocks.") and (k.endswith(".ls1") or k.endswith(".ls2")):
-                k2 = k + ".gamma"
-            if k == "patch_embed.weight":
-                k2 = "patch_embed.proj.weight"
-            if k == "patch_embed.bias":
-                k2 = "patch_embed.proj.bias"
+            k2 = k.replace(".attn.qkv.", ".qkv.").replace(".attn.proj.", ".proj.").replace(".mlp.fc", ".fc").replace("patch_embed.proj.", "patch_embed.")
+            if k2.endswith(".gamma"):
+                k2 = k2[:-len(".gamma")]
             sd[k2] = v
+        assert "blocks.0.qkv.weight" in sd and "blocks.0.ls1" in sd and "patch_embed.weight" in sd
         assert torch.equal(ViTHandle(sd, dev).forward(x), tok)
-    # the wrapper: no-grad inference through the kernels, same dictionary as the module
-    wrapped = NativeViT(net)
+    # served in place: the SAME module, its keys untouched, no-grad inference through the kernels, same dictionary as the module
+    keys = list(net.state_dict().keys())
+    assert serve_natively(net) is net and is_served_natively(net) and list(net.state_dict().keys()) == keys
     with torch.no_grad():
-        out = wrapped.forward_features(x)
+        out = net.forward_features(x)
     assert torch.equal(out["x_norm_patchtokens"], tok) and torch.equal(out["x_norm_clstoken"], cls)
+    # under autograd on a trainable backbone the module's own torch forward runs (and back-propagates)
+    xs = x[:1].clone().requires_grad_(True)
+    assert net.forward_features(xs)["x_norm_patchtokens"].requires_grad
+    # a parameter changed in place: the handle is rebuilt from the new weights
+    with torch.no_grad():
+        net.norm.weight.mul_(2.0)
+        out2 = net.forward_features(x)
+        net.norm.weight.mul_(0.5)
+    assert not torch.equal(out2["x_norm_patchtokens"], tok)
+    assert restore_stock(net) is net and not is_served_natively(net) and "forward_features" not in net.__dict__
     # stage C on the golden-size ray set: tokens from either backbone select (nearly) the same top-100 rays
     pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
     ori, dirs, rgb = pipe.emit(300, seed=9)

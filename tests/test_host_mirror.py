@@ -74,33 +74,91 @@ def test_field_module_checkpoint_round_trip(tmp_path):
         TensorVMSplit(**dict(kw, shadingMode="MLP_Fea"))
 
 
+def _api_surface():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_api_surface.json")) as f:
+        return json.load(f)
+
+
 def test_signatures_match_the_reference_surface():
-    """Argument names and defaults of the mirrored callables."""
-    from iffnerf_amd import renderer
-    from iffnerf_amd.models.tensorBase import TensorBase
-    from iffnerf_amd.pose_estimation import identification_module, model_utils, sampling, test as pe_test
-    from iffnerf_amd.pose_estimation.multihead_attention import MultiHeadAttention
-    from iffnerf_amd.pose_estimation.ray_preprocessor import RayPreprocessor
+    """Every callable the mirror keeps has the REFERENCE's parameters -- names, kinds, order, defaults -- as
+    tests/golden/make_golden.py read them off the imported reference with inspect.signature (fixture G14).
+    A mirror callable may only ADD trailing keyword parameters that have defaults (each listed here, so a new one is a decision)."""
+    import importlib
+    from tests.golden.make_golden import signature_record
+    surface = _api_surface()
+    assert surface["modules_not_importable_here"] == [] and len(surface["signatures"]) >= 60
+    extras = {}
+    for key, want in surface["signatures"].items():
+        modname, dotted = key.split(":")
+        obj = importlib.import_module("iffnerf_amd." + modname)
+        for part in dotted.split("."):
+            obj = getattr(obj, part)
+        got = signature_record(obj)
+        assert got[:len(want)] == want, (key, got, want)
+        for name, kind, default in got[len(want):]:
+            assert default is not None or kind in ("VAR_KEYWORD", "VAR_POSITIONAL"), (key, name)
+            extras.setdefault(key, []).append(name)
+    assert extras == {
+        "pose_estimation.sampling:iterative_surface_sampling_process": ["return_stats"],      # sampler statistics for the tests
+    }, extras
 
-    def params(fn):
-        return [(p.name, p.default) for p in inspect.signature(fn).parameters.values() if p.name != "self"]
 
-    E = inspect.Parameter.empty
-    assert params(model_utils.load_model) == [("checkpoint_path", E), ("device", E)]
-    assert params(model_utils.explore_model) == [("model", E), ("gen_points", 20000)]
-    assert params(sampling.iterative_surface_sampling_process)[:4] == [
-        ("model", E), ("gen_points", 8000), ("n_iteration", 4), ("max_resampling_iterations", 200)]
-    assert params(sampling.generate_all_possible_rays) == [
-        ("point_sampling", E), ("point_normals", E), ("model", E), ("num_viewdirs_per_chunk", 10240), ("sample_isocell_targets", 27)]
-    assert params(TensorBase.forward) == [("rays_chunk", E), ("white_bg", False), ("bg_color", None), ("is_train", False),
-                                          ("ndc_ray", False), ("sample_func", None), ("N_samples", -1)]
-    assert params(TensorBase.compute_alpha) == [("xyz_locs", E), ("length", 1)]
-    assert params(renderer.OctreeRender_trilinear_fast)[:4] == [("rays", E), ("tensorf", E), ("chunk", 4096), ("N_samples", -1)]
-    assert params(RayPreprocessor.__init__) == [("viewpe", 8), ("pospe", 8), ("rgbpe", 6), ("featureC", 128), ("fea_output", 128)]
-    assert params(MultiHeadAttention.__init__) == [("ray_fea_size", E), ("img_fea_size", E), ("embed_dim", E), ("num_heads", 1)]
-    assert params(identification_module.IdentificationModule.test_image) == [
-        ("img", E), ("mask", E), ("rays_ori", E), ("rays_dir", E), ("rays_rgb", E), ("rays_to_output", 100)]
-    assert [n for n, _ in params(pe_test.test_pose_estimation)][:6] == ["dataset", "id_module", "rays_ori", "rays_dirs", "rays_rgb", "model_up"]
+def _dino_keyed_id_module(monkeypatch, native: bool):
+    """IdentificationModule("dino") through the DEFAULT create_backbone; only the network access is replaced (torch.hub.load ->
+    the seeded module with DINOv2's module tree)."""
+    from iffnerf_amd.pose_estimation import backbone as bb, identification_module as im
+    monkeypatch.setattr(bb, "_hub_load", lambda repo, name: bb.SeededViTS14(seed=0))
+    if not native:
+        keep = bb.create_backbone
+        monkeypatch.setattr(im, "create_backbone", lambda **kw: keep(native=False, **kw))
+    return im.IdentificationModule("dino")
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_id_module_checkpoint_keys_are_the_references(monkeypatch, native, tmp_path):
+    """`id_module.th` (pose_estimation/train.py:226 saves id_module.state_dict(); train_eval_pose_est.py:59-66 strict-loads it):
+    the mirror over the default backbone has exactly the reference's keys and shapes, strict-loads a reference-keyed dictionary
+    and saves one the reference would load -- with the native ViT served (the default) and with the stock module."""
+    from iffnerf_amd.hip_vit import is_served_natively
+    surface = _api_surface()
+    mod = _dino_keyed_id_module(monkeypatch, native)
+    assert is_served_natively(mod.image_preprocessing_net) == native
+    assert type(mod.image_preprocessing_net).__name__ == "SeededViTS14"            # the hub module itself, not a wrapper
+    sd = mod.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == surface["id_module_state_dict"]
+    assert [n for n, _ in mod.named_children()] == surface["id_module_children"]
+    assert list(mod.backbone_wh) == surface["id_module_attrs"]["backbone_wh"] and mod.img_num_features == surface["id_module_attrs"]["img_num_features"]
+    # a reference-keyed checkpoint: the fixture's keys and shapes, fresh values, through torch.save / torch.load
+    gen = torch.Generator().manual_seed(4)
+    ref_sd = {k: torch.randn(shape, generator=gen) for k, shape in surface["id_module_state_dict"].items()}
+    path = tmp_path / "id_module.th"
+    torch.save({"epoch": 7, "model_state_dict": ref_sd}, str(path))
+    ckpt = torch.load(str(path), map_location="cpu")
+    res = mod.load_state_dict(ckpt["model_state_dict"])                             # strict, as the reference driver does
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in mod.state_dict().items():
+        assert torch.equal(v, ref_sd[k]), k
+    # attribute reads the drivers make (train_eval_pose_est.py:55-57, pose_estimation/train.py:30-42)
+    assert sum(1 for _ in mod.image_preprocessing_net.parameters()) == 175
+    assert len(list(mod.ray_preprocessor.parameters())) == 8 and len(list(mod.attention.parameters())) == 4
+    # .to() / copies keep the contract (a copy starts without a device handle)
+    import copy
+    twin = copy.deepcopy(mod)
+    assert list(twin.state_dict().keys()) == list(sd.keys()) and is_served_natively(twin.image_preprocessing_net) == native
+    if native:
+        assert twin.image_preprocessing_net.forward_features.module is twin.image_preprocessing_net
+
+
+def test_field_state_dict_is_the_references():
+    from iffnerf_amd.models.tensoRF import TensorVMSplit
+    surface = _api_surface()
+    ck = util.ckpt("tiny")
+    assert list(ck["kwargs"]["gridSize"]) == surface["tensorf_grid"]
+    m = TensorVMSplit(**dict(ck["kwargs"], device="cpu"))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == surface["tensorf_state_dict"]
+    assert sorted(m.get_kwargs().keys()) == surface["tensorf_kwargs_keys"]
 
 
 def _fake_backbone_module(monkeypatch):
@@ -118,13 +176,9 @@ def _fake_backbone_module(monkeypatch):
     return im
 
 
-def test_identification_module_state_dict_and_preprocessing(monkeypatch):
+def test_identification_module_preprocessing(monkeypatch):
     im = _fake_backbone_module(monkeypatch)
     mod = im.IdentificationModule("dino")
-    keys = set(mod.state_dict().keys())
-    want = {"norm_mean", "norm_std", "image_preprocessing_net.w"}
-    want |= set(synthetic.make_id_weights(seed=1).keys())
-    assert keys == want
     mod.load_state_dict({**mod.state_dict(), **synthetic.make_id_weights(seed=1)})
     assert mod.backbone_wh == (16, 16) and mod.img_num_features == 384
     # the 14-channel position code equals the oracle's restatement of identification_module.py:76-99
