@@ -540,15 +540,19 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
             torch.cuda.synchronize(device)
             return round(n_i * IQ / (time.perf_counter() - ti), 2)
 
-        net, grid, _ = create_standin_backbone(seed=0, native=True)           # what create_backbone("dino") returns by default
+        net, grid, _ = create_standin_backbone(seed=0, native=True)           # what create_backbone("dino") returns by default: fp32-accurate
+        fast, _, _ = create_standin_backbone(seed=0, native=True, precision="bf16")
         stock, _, _ = create_standin_backbone(seed=0)                          # the same weights as stock fp32 torch ops
-        net, stock = net.to(device), stock.to(device)
+        net, fast, stock = net.to(device), fast.to(device), stock.to(device)
         result["image_to_pose_per_s"] = image_rate(ImageFrontEnd(net, grid), WQ)
+        result["image_to_pose_per_s_bf16_backbone"] = image_rate(ImageFrontEnd(fast, grid), WQ)
         result["image_to_pose_per_s_torch_fp32_backbone"] = image_rate(ImageFrontEnd(stock, grid), 16)      # (MIOpen's first use of a new batch shape takes minutes)
         result["image_to_pose_note"] = ("32 (stock torch backbone: 16) synthetic 800x800 RGBA queries per captured graph: bicubic resize / crop / normalise + ViT-S/14 "
                                         "(DINOv2's architecture, seeded stand-in weights) + token assembly kernel + stage C on resident rays "
                                         "with the cached encoder; 4 graphs in flight; never part of `value`.  image_to_pose_per_s runs the "
-                                        "backbone in libiffnerf_hip (iff_vit_forward: bf16 MFMA, fp32 accumulate), "
+                                        "backbone in libiffnerf_hip in the reference's fp32 accuracy class (iff_vit_forward, IFF_VIT_FP32: split fp16 "
+                                        "operands, three MFMA products per block, fp32 accumulate), image_to_pose_per_s_bf16_backbone with bf16 operands "
+                                        "(IFF_VIT_BF16: ~1e-2 relative on the tokens, a throughput option), "
                                         "image_to_pose_per_s_torch_fp32_backbone the same module as stock fp32 torch ops")
         result["warm_note"] = ("rays resident (the reference's eval semantics): 32 query images per graph against one ray set whose "
                                "encoder output is cached per model, 4 graphs in flight; never part of `value`")

@@ -14,9 +14,11 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
+# IFF_LIB_PATH: a development build (scripts/build_dev.sh -> build/lib_<tag>.so) loaded INSTEAD of the in-tree library, so A/B runs
+# never overwrite the product's .so; unset (the default, and what tests / bench / the driver use) -> the library next to this file
+LIB_PATH = os.environ.get("IFF_LIB_PATH") or os.path.join(_HERE, "libiffnerf_hip.so")
 _lib = None
-ABI_VERSION = 8          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 9          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -47,7 +49,10 @@ class IdNetDesc(C.Structure):
 class VitDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "mlp", "patch", "grid_h", "grid_w")] + [("ln_eps", C.c_float)] + [
         (n, C.c_void_p) for n in ("patch_w", "patch_b", "cls", "pos", "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
-                                  "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "norm_w", "norm_b")]
+                                  "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "norm_w", "norm_b")] + [("precision", C.c_int32)]
+
+
+VIT_FP32, VIT_BF16 = 0, 1          # include/iffnerf_hip.h IFF_VIT_FP32 / IFF_VIT_BF16
 
 
 # name -> (restype, argtypes); must list every function include/iffnerf_hip.h declares (tests/test_abi.py checks)
@@ -64,6 +69,7 @@ SIGNATURES = {
     "iff_idnet_load": (C.c_int, [C.c_char_p, _VP, C.POINTER(_VP)]),
     "iff_normalize_coord": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_mask_sample": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_mask_occupied": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_density_feature": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_app_feature": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_point_alpha": (C.c_int, [_VP, _VP, _I64, _F, _VP, _VP]),

@@ -62,7 +62,7 @@ static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 // Where every table of a field handle sits in its slab, as a function of the descriptor's dimensions alone: iff_field_create
 // lays the slab out with it and iff_field_load checks a table file against it (a file is accepted only if it is exactly what
 // iff_field_create would have produced for the dimensions it claims).
-struct FieldLayout { size_t dp[3], dl[3], ap[3], al[3], basis, basis_l, basis_l12, head, mask, n_mask, total; };
+struct FieldLayout { size_t dp[3], dl[3], ap[3], al[3], basis, basis_l, basis_l12, head, mask, n_mask, cell, n_cell, total; };
 static FieldLayout field_layout(const int G[3], int n_density, int n_app, int app_dim, int feature_c, const int mask_dims[3], bool has_mask) {
     FieldLayout L;
     size_t off = 0;
@@ -79,6 +79,8 @@ static FieldLayout field_layout(const int G[3], int n_density, int n_app, int ap
     L.head = off; off = up256(off + (size_t)head_offsets(app_dim, feature_c).total * 4);
     L.n_mask = has_mask ? (size_t)mask_dims[0] * mask_dims[1] * mask_dims[2] : 0;
     L.mask = off; off = up256(off + L.n_mask);
+    L.n_cell = has_mask ? (size_t)(mask_dims[0] + 1) * (mask_dims[1] + 1) * (mask_dims[2] + 1) : 0;
+    L.cell = off; off = up256(off + L.n_cell);
     L.total = off;
     return L;
 }
@@ -92,8 +94,12 @@ static int check_field_dims(const int G[3], int n_density, int n_app, int app_di
     IFF_REQUIRE(density_lanes == 0 || density_lanes == 4 || (density_lanes == 1 && n_density == 16),
                 "density_lanes = %d: must be 0 (auto), 4, or 1 with density_n_comp = 16", density_lanes);
     IFF_REQUIRE(feature_c >= 16 && feature_c <= 512 && feature_c % 16 == 0, "featureC = %d unsupported", feature_c);
-    if (has_mask)
+    if (has_mask) {
         for (int i = 0; i < 3; ++i) IFF_REQUIRE(mask_dims[i] >= 1 && mask_dims[i] <= 4096, "mask dim %d out of range", i);
+        // the corner-bit table is indexed with 32-bit arithmetic (iff_device.h mask_occupied_at)
+        IFF_REQUIRE((uint64_t)(mask_dims[0] + 1) * (uint64_t)(mask_dims[1] + 1) * (uint64_t)(mask_dims[2] + 1) < (1ull << 31),
+                    "occupancy mask %d x %d x %d: 2^31 cells and more are not addressable", mask_dims[0], mask_dims[1], mask_dims[2]);
+    }
     for (int i = 0; i < 3; ++i) {
         // the gathers address a table by a 32-bit byte offset from its base (iff_device.h ld4_tex)
         const uint64_t texels = (uint64_t)G[mat_a(i)] * (uint64_t)G[mat_b(i)];
@@ -168,6 +174,8 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     if (d->mask_volume) {
         IFF_CREATE_HIP(launch_k0_mask_bytes(d->mask_volume, (uint8_t*)(base + o_mask), (int64_t)n_mask, s));
         v.mask = (const uint8_t*)(base + o_mask);
+        IFF_CREATE_HIP(launch_k0_mask_cells(v.mask, (uint8_t*)(base + L.cell), d->mask_dims[0], d->mask_dims[1], d->mask_dims[2], s));
+        v.cell = (const uint8_t*)(base + L.cell);
         // occupied-voxel list for the sampler's seeds (pose_estimation/sampling.py:82-102), built once on the host
         std::vector<uint8_t> hm(n_mask);
         IFF_CREATE_HIP(hipMemcpyAsync(hm.data(), base + o_mask, n_mask, hipMemcpyDeviceToHost, s));
@@ -217,6 +225,14 @@ extern "C" int iff_mask_sample(const iff_field* f, const float* xyz, int64_t n, 
     IFF_HIP(launch_mask_sample(f->dev, xyz, n, out, (hipStream_t)stream));
     return 0;
 }
+extern "C" int iff_mask_occupied(const iff_field* f, const float* xyz, int64_t n, uint8_t* out, void* stream) {
+    IFF_FIELD_ARGS(f, xyz, n);
+    if (n == 0) return 0;
+    IFF_REQUIRE(out != nullptr, "iff_mask_occupied: null output");
+    IFF_HIP(launch_mask_occupied(f->dev, xyz, n, out, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int iff_density_feature(const iff_field* f, const float* xn, int64_t n, float* out, void* stream) {
     IFF_FIELD_ARGS(f, xn, n);
     if (n == 0) return 0;
@@ -905,7 +921,7 @@ extern "C" int iff_pose_from_topk_batched(const int64_t* idx, const float* val, 
 //   slab bytes | extra (field: the occupied-voxel list, int32 each)
 // The descriptor struct's size is stored and checked, so a file written by a build with another struct layout is refused
 // rather than misread; IFF_TABLE_FILE_VERSION changes whenever a table's layout does.
-#define IFF_TABLE_FILE_VERSION 1
+#define IFF_TABLE_FILE_VERSION 2          // 2: the field slab carries the corner-bit occupancy table (FieldDev::cell)
 struct TableFileHeader {
     char magic[8];              // "IFFTABLE"
     uint32_t version, kind;     // kind 1 = field, 2 = idnet
@@ -931,7 +947,7 @@ static std::vector<const void**> field_ptrs(FieldDev& v) {
         p.push_back((const void**)&v.aplane[i]); p.push_back((const void**)&v.aline[i]);
     }
     p.push_back((const void**)&v.basis_l); p.push_back((const void**)&v.basis_l12); p.push_back((const void**)&v.basis);
-    p.push_back((const void**)&v.mask); p.push_back((const void**)&v.head);
+    p.push_back((const void**)&v.mask); p.push_back((const void**)&v.cell); p.push_back((const void**)&v.head);
     return p;
 }
 static std::vector<const void**> idnet_ptrs(IdNetDev& v) {
@@ -1017,7 +1033,7 @@ static int validate_field_file(const char* path, const FieldDev& v, size_t slab_
         ok = ok && stored_is(v.dplane[i], true, L.dp[i]) && stored_is(v.dline[i], true, L.dl[i]) && stored_is(v.aplane[i], true, L.ap[i]) &&
              stored_is(v.aline[i], true, L.al[i]);
     ok = ok && stored_is(v.basis, true, L.basis) && stored_is(v.basis_l, true, L.basis_l) && stored_is(v.basis_l12, true, L.basis_l12) &&
-         stored_is(v.head, true, L.head) && stored_is(v.mask, has_mask, L.mask);
+         stored_is(v.head, true, L.head) && stored_is(v.mask, has_mask, L.mask) && stored_is(v.cell, has_mask, L.cell);
     if (!ok) return fail(IFF_ERR_INVALID_ARGUMENT, "%s: the table offsets / slab size do not match the dimensions the file claims", path);
     IFF_REQUIRE(v.n_samples >= 1 && (v.softplus == 0 || v.softplus == 1) && (v.unisphere == 0 || v.unisphere == 1) && v.step_size > 0.0f &&
                     v.step_size < 1e30f, "%s: implausible march parameters", path);
@@ -1142,8 +1158,12 @@ extern "C" int iff_vit_create(const iff_vit_desc* d, void* stream, iff_vit** out
     iff_vit* v = new iff_vit();
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
-    const size_t o_pw = take(D * kp * 2), o_qkv = take(L * 3 * D * D * 2), o_proj = take(L * D * D * 2), o_fc1 = take(L * F * D * 2),
-                 o_fc2 = take(L * D * F * 2);
+    IFF_REQUIRE(d->precision == IFF_VIT_FP32 || d->precision == IFF_VIT_BF16, "iff_vit_create: precision %d is neither IFF_VIT_FP32 nor IFF_VIT_BF16", d->precision);
+    IFF_REQUIRE(d->depth <= VIT_MAX_DEPTH, "iff_vit_create: depth %d exceeds %d", d->depth, VIT_MAX_DEPTH);
+    const bool split = d->precision == IFF_VIT_FP32;
+    const size_t eb = split ? 4 : 2;               // bytes per weight: bf16, or fp16 hi + lo planes
+    const size_t o_pw = take(D * kp * eb), o_qkv = take(L * 3 * D * D * eb), o_proj = take(L * D * D * eb), o_fc1 = take(L * F * D * eb),
+                 o_fc2 = take(L * D * F * eb);
     struct { const float* src; size_t n; size_t off; } vecs[] = {
         {d->patch_b, D, 0}, {d->cls, D, 0}, {d->pos, T * D, 0}, {d->ln1_w, L * D, 0}, {d->ln1_b, L * D, 0}, {d->ln2_w, L * D, 0},
         {d->ln2_b, L * D, 0}, {d->qkv_b, L * 3 * D, 0}, {d->proj_b, L * D, 0}, {d->fc1_b, L * F, 0}, {d->fc2_b, L * D, 0}, {d->ls1, L * D, 0},
@@ -1158,13 +1178,49 @@ extern "C" int iff_vit_create(const iff_vit_desc* d, void* stream, iff_vit** out
         hipError_t e__ = (call);                                       \
         if (e__ != hipSuccess) { iff_vit_destroy(v); return hip_fail(e__, #call); } \
     } while (0)
-    IFF_VIT_HIP(launch_vit_pad_rows(d->patch_w, (int)D, (int)kraw, (int)kp, b + o_pw, s));
-    IFF_VIT_HIP(launch_vit_to_bf16(d->qkv_w, (int64_t)(L * 3 * D * D), b + o_qkv, s));
-    IFF_VIT_HIP(launch_vit_to_bf16(d->proj_w, (int64_t)(L * D * D), b + o_proj, s));
-    IFF_VIT_HIP(launch_vit_to_bf16(d->fc1_w, (int64_t)(L * F * D), b + o_fc1, s));
-    IFF_VIT_HIP(launch_vit_to_bf16(d->fc2_w, (int64_t)(L * D * F), b + o_fc2, s));
-    for (auto& x : vecs) IFF_VIT_HIP(hipMemcpyAsync(b + x.off, x.src, x.n * 4, hipMemcpyDeviceToDevice, s));
     VitDev& w = v->dev;
+    memset(&w, 0, sizeof(w));
+    w.prec = split ? 1 : 0;
+    w.s_patch = 1.0f;
+    for (int l = 0; l < VIT_MAX_DEPTH; ++l) w.s_qkv[l] = w.s_proj[l] = w.s_fc1[l] = w.s_fc2[l] = 1.0f;
+    if (!split) {
+        IFF_VIT_HIP(launch_vit_pad_rows(d->patch_w, (int)D, (int)kraw, (int)kp, b + o_pw, s));
+        IFF_VIT_HIP(launch_vit_to_bf16(d->qkv_w, (int64_t)(L * 3 * D * D), b + o_qkv, s));
+        IFF_VIT_HIP(launch_vit_to_bf16(d->proj_w, (int64_t)(L * D * D), b + o_proj, s));
+        IFF_VIT_HIP(launch_vit_to_bf16(d->fc1_w, (int64_t)(L * F * D), b + o_fc1, s));
+        IFF_VIT_HIP(launch_vit_to_bf16(d->fc2_w, (int64_t)(L * D * F), b + o_fc2, s));
+    } else {
+        // fp16 hi / lo planes of every matrix times a power of two: the largest |weight| of the matrix lands in [2^13, 2^14), so
+        // the hi piece uses fp16's normal range and the lo piece (2^-11 of it) stays normal down to weights 2^-16 of the largest;
+        // the GEMM epilogue multiplies the accumulator by the exact inverse (VitDev::s_*)
+        std::vector<float> host;
+        auto convert = [&](const float* src, size_t rows, size_t cols, size_t KP, size_t layers, char* dst, float* scales) -> hipError_t {
+            try { host.resize(layers * rows * cols); } catch (const std::exception&) { return hipErrorOutOfMemory; }
+            hipError_t e2 = hipMemcpyAsync(host.data(), src, host.size() * 4, hipMemcpyDeviceToHost, s);
+            if (e2 != hipSuccess) return e2;
+            if ((e2 = hipStreamSynchronize(s)) != hipSuccess) return e2;
+            _Float16* hi = (_Float16*)dst;
+            _Float16* lo = hi + layers * rows * KP;
+            for (size_t l = 0; l < layers; ++l) {
+                float mx = 0.0f;
+                for (size_t i = 0; i < rows * cols; ++i) { const float a = fabsf(host[l * rows * cols + i]); if (a > mx) mx = a; }
+                if (!(mx < INFINITY)) return hipErrorInvalidValue;
+                int ex = 0;
+                if (mx > 0.0f) { (void)frexpf(mx, &ex); ex = 14 - ex; }              // mx * 2^ex in [2^13, 2^14)
+                ex = ex > 40 ? 40 : (ex < -40 ? -40 : ex);
+                scales[l] = ldexpf(1.0f, -ex);
+                if ((e2 = launch_vit_to_f16_planes(src + l * rows * cols, (int64_t)rows, (int)cols, (int)KP, ldexpf(1.0f, ex), hi + l * rows * KP,
+                                                   lo + l * rows * KP, s)) != hipSuccess) return e2;
+            }
+            return hipSuccess;
+        };
+        IFF_VIT_HIP(convert(d->patch_w, D, kraw, kp, 1, b + o_pw, &w.s_patch));
+        IFF_VIT_HIP(convert(d->qkv_w, 3 * D, D, D, L, b + o_qkv, w.s_qkv));
+        IFF_VIT_HIP(convert(d->proj_w, D, D, D, L, b + o_proj, w.s_proj));
+        IFF_VIT_HIP(convert(d->fc1_w, F, D, D, L, b + o_fc1, w.s_fc1));
+        IFF_VIT_HIP(convert(d->fc2_w, D, F, F, L, b + o_fc2, w.s_fc2));
+    }
+    for (auto& x : vecs) IFF_VIT_HIP(hipMemcpyAsync(b + x.off, x.src, x.n * 4, hipMemcpyDeviceToDevice, s));
     w.patch_w = b + o_pw; w.qkv_w = b + o_qkv; w.proj_w = b + o_proj; w.fc1_w = b + o_fc1; w.fc2_w = b + o_fc2;
     const float** dst[] = {&w.patch_b, &w.cls, &w.pos, &w.ln1_w, &w.ln1_b, &w.ln2_w, &w.ln2_b, &w.qkv_b, &w.proj_b, &w.fc1_b, &w.fc2_b,
                            &w.ls1, &w.ls2, &w.norm_w, &w.norm_b};

@@ -78,31 +78,84 @@ __device__ __forceinline__ float sum4_dpp(float v) {
 }
 // the value of lane (i xor 4): reverse inside the quad (quad_perm [3,2,1,0]), then mirror the 8-lane half row (row_half_mirror)
 __device__ __forceinline__ float xor4_dpp(float v) { return dpp_mov<0x141>(dpp_mov<0x1B>(v)); }
-// Bilinear / linear combination of tap quarters in the operation order of lerp_plane4 / lerp_line4 (iff_device.h).
-// NOT as packed fp32 instructions.  The natural form (v_pk_mul_f32 / v_pk_fma_f32 on register pairs, the weight broadcast by op_sel:
-// -DFAN_PACKED_LERP builds it) returned wrong sums for the LAST SIXTEEN LANES of a wave -- rays 6, 7 (+ 8 w) of a tile -- about once in
-// 30 launches of 19 000 tiles, and only while a workgroup of the encoder / logits kernel (k5_trunk_h: fp16 MFMA) shared the CU: with
-// four captured steps in flight the last tiles of a march run next to another step's trunk.  Nothing else changes the rate: extra
-// waits and barriers around every LDS and memory access of the phase (a full LDS wait and eight idle cycles before the packed
-// instructions included), the cross-lane sums as ds_bpermute instead of DPP, two waves
-// per SIMD instead of three, the matrix-core rows of phase D permuted; evaluating phase C twice in the same workgroup and
-// comparing (-DFAN_CHECK_TWICE) catches every event, so it is a transient of the execution, not stale or overwritten LDS.  With
-// one v_mul / v_fma per component: 0 events in 1 600 launches (scripts/replay_vs_eager_stages.py, ONLY=trunk) where the packed form has
-// 30-40 (the packed instructions with every weight as a REAL register pair instead of the op_sel broadcast: also 0 in 1 000, and no
-// faster); the fan kernel is 5 % slower for it, a step 2-3 %.  The empty asm keeps the vectoriser from pairing them again.
+// Bilinear / linear combination of tap quarters in the operation order of lerp_plane4 / lerp_line4 (iff_device.h): one multiply and
+// fused multiply-adds per component.  THE LIBRARY IS BUILT WITHOUT PACKED FP32 INSTRUCTIONS (iffnerf_amd/build.py: -packed-fp32-ops;
+// tests/test_isa_rules.py checks the shipped code objects), so these vector expressions compile to one v_mul / v_fma per component.
+// Why: left to itself the compiler turns this function into v_pk_mul_f32 / v_pk_fma_f32 on register pairs with the weight broadcast
+// by op_sel, and THAT code returned wrong sums for the last sixteen lanes of a wave -- rays 6, 7 (+ 8 w) of a tile, waves 0-2 --
+// in 0.7 % of the steps (14 of 2 000 checked, 4 of 480), always in the last ~300 tiles of a march and only while a workgroup of
+// the encoder / logits kernel (k5_trunk_h: fp16 MFMA) shared the CU: with four captured steps in flight the tail of a march runs
+// next to another step's trunk.  Evaluating phase C twice in the same workgroup and comparing catches every event: a transient of
+// the execution, not stale LDS.  What the investigation ("the packed-fp32 fault") excluded: missing waits (the
+// s_waitcnt sequence of the faulty loop was checked load by load), waits / barriers / idle cycles around every LDS access, DPP vs
+// ds_bpermute, occupancy, scratch (none), the matrix-core row order of phase D -- and the instruction FORM: the same products as
+// hand-placed v_pk_mul_f32 / v_pk_fma_f32 (-DFAN_LERP_ASM=1..8 below: op_sel broadcast with a small-integer, equal or 1.0f high
+// half, real (w, w) pairs, the weight as src0 or src1, every destination written over the broadcast pair, every destination
+// disjoint) show 0 events in 6 400 checked steps, next to 18 in 2 480 for the compiler's own packing in the same runs.  So the
+// trigger is the compiler's schedule of packed fp32 code next to MFMA work, not an operand form one could avoid by hand; no packed
+// fp32 instruction is the rule that holds for all ~8 000 the compiler had placed in this library, and it costs nothing measurable
+// (14 590-14 760 poses/s without, 14 590-14 810 with, same box, same run).
+#if defined(FAN_LERP_ASM)
+// Experiment builds of the packed-fp32 investigation (need +packed-fp32-ops; scripts/gpu_r4_call2.sh ran them): the tap combination
+// as hand-placed v_pk_mul_f32 / v_pk_fma_f32 with the weight operand in a chosen form.  FAN_LERP_ASM = 1: op_sel broadcast of the low half, high half = a small integer (what the
+// compiler's own packing leaves there: an LDS address); 2: broadcast, high half = the weight again; 3: broadcast, high half = 1.0f;
+// 4: no op_sel, a real (w, w) pair; 6: broadcast with the weight as src0 (the form of the compositing-weight accumulate);
+// 7: as 1 with every result written OVER the broadcast pair (the destination overlaps the op_sel source); 8: as 1 with every
+// destination disjoint from its sources.
+typedef float f32p __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float opq(float v) { asm volatile("" : "+v"(v)); return v; }
-#ifndef FAN_PACKED_LERP
-__device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
-    f32q r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = opq(fmaf(se[e], pw[3], opq(fmaf(sw[e], pw[2], opq(fmaf(ne[e], pw[1], opq(nw[e] * pw[0])))))));
+__device__ __forceinline__ f32p wpair(float w) {
+#if FAN_LERP_ASM == 1 || FAN_LERP_ASM == 6 || FAN_LERP_ASM == 7 || FAN_LERP_ASM == 8
+    return f32p{w, __uint_as_float(0x1200u + 16u * (threadIdx.x & 63u))};
+#elif FAN_LERP_ASM == 3
+    return f32p{w, opq(1.0f)};
+#else
+    return f32p{w, opq(w)};
+#endif
+}
+__device__ __forceinline__ f32p pk_mul_w(f32p x, f32p w) {
+    f32p r;
+#if FAN_LERP_ASM == 4
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(w), "v"(x));
+#elif FAN_LERP_ASM == 7          // the destination IS the broadcast source pair
+    asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[0,1]" : "+v"(w) : "v"(x));
+    r = w;
+#elif FAN_LERP_ASM == 8          // the destination never overlaps a source (early clobber)
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=&v"(r) : "v"(w), "v"(x));
+#else
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(x));
+#endif
     return r;
 }
-__device__ __forceinline__ f32q lerp_line_q(f32q lo, f32q hi, const float lw[2]) {
-    f32q r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = opq(fmaf(hi[e], lw[1], opq(lo[e] * lw[0])));
+__device__ __forceinline__ f32p pk_fma_w(f32p x, f32p w, f32p c) {
+    f32p r;
+#if FAN_LERP_ASM == 4
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(w), "v"(c));
+#elif FAN_LERP_ASM == 6
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(x), "v"(c));
+#elif FAN_LERP_ASM == 7
+    asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[1,0,1]" : "+v"(w) : "v"(x), "v"(c));
+    r = w;
+#elif FAN_LERP_ASM == 8
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=&v"(r) : "v"(x), "v"(w), "v"(c));
+#else
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(w), "v"(c));
+#endif
     return r;
+}
+__device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
+    const f32p w0 = wpair(pw[0]), w1 = wpair(pw[1]), w2 = wpair(pw[2]), w3 = wpair(pw[3]);
+    f32p lo = pk_mul_w(f32p{nw.x, nw.y}, w0), hi = pk_mul_w(f32p{nw.z, nw.w}, w0);
+    lo = pk_fma_w(f32p{ne.x, ne.y}, w1, lo); hi = pk_fma_w(f32p{ne.z, ne.w}, w1, hi);
+    lo = pk_fma_w(f32p{sw.x, sw.y}, w2, lo); hi = pk_fma_w(f32p{sw.z, sw.w}, w2, hi);
+    lo = pk_fma_w(f32p{se.x, se.y}, w3, lo); hi = pk_fma_w(f32p{se.z, se.w}, w3, hi);
+    return f32q{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32q lerp_line_q(f32q lo_, f32q hi_, const float lw[2]) {
+    const f32p w0 = wpair(lw[0]), w1 = wpair(lw[1]);
+    f32p lo = pk_mul_w(f32p{lo_.x, lo_.y}, w0), hi = pk_mul_w(f32p{lo_.z, lo_.w}, w0);
+    lo = pk_fma_w(f32p{hi_.x, hi_.y}, w1, lo); hi = pk_fma_w(f32p{hi_.z, hi_.w}, w1, hi);
+    return f32q{lo.x, lo.y, hi.x, hi.y};
 }
 #else
 __device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
@@ -139,36 +192,6 @@ __device__ __forceinline__ const f32q* line_chunk(const float* __restrict__ tab,
     const int rz = chunk / CPT, q = chunk - rz * CPT;
     const int row = fast ? lov + rz : min(lov + rz, Gv - 1);
     return reinterpret_cast<const f32q*>(tab + (size_t)row * C + 4 * q);
-}
-
-// mask_value (iff_device.h) with its eight byte loads unconditional (indices clamped into the volume, the bounds test applied to
-// the loaded value afterwards): the same products and the same summation order, but all loads of a sample -- and of the three
-// samples a lane handles -- are in flight together instead of one L2 round trip per corner behind its bounds branch.
-__device__ __forceinline__ float mask_value_flat(const FieldDev& f, const float p[3]) {
-    float g[3];
-    mask_normalize(f, p, g);
-    const int W = f.mask_dims[2], H = f.mask_dims[1], D = f.mask_dims[0];
-    const float ix = unnorm(g[0], W), iy = unnorm(g[1], H), iz = unnorm(g[2], D);
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
-    const bool ok = ix > -2.0f && ix < (float)(W + 1) && iy > -2.0f && iy < (float)(H + 1) && iz > -2.0f && iz < (float)(D + 1);
-    const int x0 = ok ? (int)fx : -2, y0 = ok ? (int)fy : -2, z0 = ok ? (int)fz : -2;
-    unsigned char v[8];
-#pragma unroll
-    for (int c8 = 0; c8 < 8; ++c8) {
-        const int x = x0 + (c8 & 1), y = y0 + ((c8 >> 1) & 1), z = z0 + (c8 >> 2);
-        const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1), zc = min(max(z, 0), D - 1);
-        v[c8] = f.mask[((size_t)zc * H + yc) * W + xc];
-    }
-    float acc = 0.0f;
-#pragma unroll
-    for (int c8 = 0; c8 < 8; ++c8) {                  // corner order of mask_value: dz outermost, dx innermost
-        const int dx = c8 & 1, dy = (c8 >> 1) & 1, dz = c8 >> 2;
-        const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
-        const bool in = (x >= 0) && (x < W) && (y >= 0) && (y < H) && (z >= 0) && (z < D);
-        acc = acc + (in ? (float)v[c8] : 0.0f) * (wx[dx] * wy[dy] * wz[dz]);
-    }
-    return ok ? acc : 0.0f;
 }
 
 struct RecView {           // one sample record, unpacked (all lanes of a sub-group read the same record)
@@ -418,15 +441,16 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
         const float* sr = s_ray + g * 8;
         const bool live = g < n_live;
         const int l8 = tid & 7;
-        // the occupancy values of the lane's (up to) three samples first: 24 independent byte loads in flight together
-        float mvs[3] = {1.0f, 1.0f, 1.0f};
+        // the occupancy bytes of the lane's (up to) three samples first (one byte each from the corner-bit table, iff_device.h
+        // mask_occupied): three independent loads in flight together
+        bool occ[3] = {true, true, true};
         if (f.mask) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int s = min(l8 + 8 * k, FS - 1);
                 const float z = z_of(f, 0, FS, 0.0f, s);
                 const float p[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
-                mvs[k] = (live && inside_aabb(f, p)) ? mask_value_flat(f, p) : 0.0f;
+                occ[k] = mask_occupied(f, p);
             }
         }
 #pragma unroll
@@ -440,7 +464,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
             if (inside) {
                 float xn[3];
                 field_normalize(f, p, xn);
-                uint32_t packed = (mvs[k] > 0.0f) ? (1u << 15) : 0u;
+                uint32_t packed = occ[k] ? (1u << 15) : 0u;
                 float wt[3][2];
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {

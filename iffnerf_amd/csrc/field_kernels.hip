@@ -22,6 +22,21 @@ __global__ void k0_mask_bytes(const float* __restrict__ src, uint8_t* __restrict
         dst[t] = (src[t] > 0.0f) ? 1 : 0;
 }
 
+// mask bytes [D][H][W] -> corner bits [D+1][H+1][W+1] (FieldDev::cell, iff_device.h mask_occupied_at): entry (zi, yi, xi) describes
+// the cell whose low corner is (xi - 1, yi - 1, zi - 1)
+__global__ void k0_mask_cells(const uint8_t* __restrict__ mask, uint8_t* __restrict__ cell, int D, int H, int W) {
+    const int64_t n = (int64_t)(D + 1) * (H + 1) * (W + 1);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int xi = (int)(t % (W + 1)), yi = (int)((t / (W + 1)) % (H + 1)), zi = (int)(t / ((int64_t)(W + 1) * (H + 1)));
+        unsigned bits = 0u;
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const int x = xi - 1 + (c8 & 1), y = yi - 1 + ((c8 >> 1) & 1), z = zi - 1 + (c8 >> 2);
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D && mask[((size_t)z * H + y) * W + x]) bits |= 1u << c8;
+        }
+        cell[t] = (uint8_t)bits;
+    }
+}
+
 // basis_mat [app_dim][3*n_app] -> [app_dim][4][3*n_app/4]: slice `sub` holds, in order (plane i, j, e), the weights of
 // channels ch = 16 j + 4 sub + e -- the order app_products_slice() produces them in.
 __global__ void k0_basis_slices(const float* __restrict__ src, float* __restrict__ dst, int app_dim, int n_app) {
@@ -65,6 +80,13 @@ __global__ void k_mask_sample(FieldDev f, const float* __restrict__ xyz, int64_t
     }
 }
 
+__global__ void k_mask_occupied(FieldDev f, const float* __restrict__ xyz, int64_t n, uint8_t* __restrict__ out) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float p[3] = {xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2]};
+        out[t] = (f.mask ? mask_occupied(f, p) : true) ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 // mode 0: compute_densityfeature(xn) -> feature ; mode 1: compute_alpha(xyz, length) -> alpha
 template <int MODE>
@@ -82,7 +104,7 @@ __global__ void __launch_bounds__(256) k1_point_density(FieldDev f, const float*
         bool valid = live;
         if (MODE == 1) {
             field_normalize(f, p, xn);
-            if (f.mask) valid = valid && (mask_value(f, p, xn) > 0.0f);
+            if (f.mask) valid = valid && mask_occupied(f, p, xn);
         } else {
             xn[0] = p[0]; xn[1] = p[1]; xn[2] = p[2];
         }
@@ -247,6 +269,10 @@ hipError_t launch_k0_mask_bytes(const float* src, uint8_t* dst, int64_t n, hipSt
     hipLaunchKernelGGL(k0_mask_bytes, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
     return hipGetLastError();
 }
+hipError_t launch_k0_mask_cells(const uint8_t* mask, uint8_t* cell, int D, int H, int W, hipStream_t s) {
+    hipLaunchKernelGGL(k0_mask_cells, dim3(grid_for((int64_t)(D + 1) * (H + 1) * (W + 1))), dim3(256), 0, s, mask, cell, D, H, W);
+    return hipGetLastError();
+}
 hipError_t launch_k0_basis_slices(const float* src, float* dst, int app_dim, int n_app, hipStream_t s) {
     hipLaunchKernelGGL(k0_basis_slices, dim3(grid_for(app_dim * 3 * n_app)), dim3(256), 0, s, src, dst, app_dim, n_app);
     return hipGetLastError();
@@ -261,6 +287,10 @@ hipError_t launch_normalize_coord(const FieldDev& f, const float* xyz, int64_t n
 }
 hipError_t launch_mask_sample(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_mask_sample, dim3(grid_for(n)), dim3(256), 0, s, f, xyz, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_mask_occupied(const FieldDev& f, const float* xyz, int64_t n, uint8_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_occupied, dim3(grid_for(n)), dim3(256), 0, s, f, xyz, n, out);
     return hipGetLastError();
 }
 hipError_t launch_density_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s) {

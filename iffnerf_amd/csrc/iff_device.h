@@ -22,6 +22,8 @@ struct FieldDev {
     const float* basis_l12;     // basis_mat re-laid [app_dim][n_app/4][12] for the 12-lanes-per-point gather (K4b)
     const float* basis;         // basis_mat as given [app_dim][3*n_app]
     const uint8_t* mask;        // [D][H][W] bytes in {0,1}, or nullptr
+    const uint8_t* cell;        // [D+1][H+1][W+1] corner bits of the mask cell (z0, y0, x0) = index - 1: bit dx + 2 dy + 4 dz is set
+                                // when corner (x0+dx, y0+dy, z0+dz) lies inside the volume and is occupied (mask_occupied below)
     const float* head;          // packed Ref head, offsets below
     int grid[3];
     int mask_dims[3];           // D,H,W
@@ -156,6 +158,47 @@ __device__ inline float mask_value(const FieldDev& f, const float p[3], const fl
         mask_normalize(f, p, g);
     }
     return mask_value_at(f, g);
+}
+
+// `mask_value(...) > 0` -- the only use the march, compute_alpha and the surface sampler make of the occupancy lookup
+// (tensorBase.py:66-72 + :764, :832: alpha_mask = sample_alpha(xyz) > 0) -- from ONE byte of the corner-bit table instead of eight
+// loads and a trilinear sum.  Exact: the mask holds {0,1} and every weight is >= 0, so the sum is positive iff some in-range
+// occupied corner has a positive weight product.  A low-corner weight (i0 + 1) - i is always positive; a high-corner weight
+// i - i0 is zero exactly when the coordinate sits on a texel.  Non-zero weights are >= 2^-25 (the coordinate (g + 1) / 2 (size - 1)
+// is a multiple of 2^-25 near 0 and has an ulp >= 2^-24 elsewhere), so a product of three never underflows to zero and
+// "product > 0" is "all three factors > 0": the corners that count are those of bit set (dx or frac_x > 0) and (dy or ...) and
+// (dz or ...).  Coordinates for which mask_value_at bails out (NaN, beyond one texel outside) index no cell: false.
+__device__ inline bool mask_occupied_at(const FieldDev& f, const float g[3]) {
+    const int W = f.mask_dims[2], H = f.mask_dims[1], D = f.mask_dims[0];
+    const float ix = unnorm(g[0], W), iy = unnorm(g[1], H), iz = unnorm(g[2], D);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    // cell index = i0 + 1 in [0, size]: i0 = -1 (low corner outside) .. size - 1 (high corner outside); NaN fails every comparison
+    const bool ok = (fx >= -1.0f) && (fx <= (float)(W - 1)) && (fy >= -1.0f) && (fy <= (float)(H - 1)) && (fz >= -1.0f) && (fz <= (float)(D - 1));
+    // the load is unconditional (cell 0 when the point indexes none): callers issue it together with their table taps
+    const int xi = ok ? (int)fx + 1 : 0, yi = ok ? (int)fy + 1 : 0, zi = ok ? (int)fz + 1 : 0;
+    const unsigned bits = f.cell[(unsigned)((zi * (H + 1) + yi) * (W + 1) + xi)];          // < 2^31 cells: checked at create
+    const unsigned allow = (ix > fx ? 0xFFu : 0x55u) & (iy > fy ? 0xFFu : 0x33u) & (iz > fz ? 0xFFu : 0x0Fu);
+    return ok && (bits & allow) != 0u;
+}
+__device__ inline bool mask_occupied(const FieldDev& f, const float p[3]) {
+    float g[3];
+    mask_normalize(f, p, g);
+    return mask_occupied_at(f, g);
+}
+// with the point's field-normalised coordinate at hand (see mask_value(f, p, xn) above)
+__device__ inline bool mask_occupied(const FieldDev& f, const float p[3], const float xn[3]) {
+    float g[3];
+    if (f.unisphere) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float cm = (f.mask_lo[a] + f.mask_hi[a]) / 2.0f, cf = (f.aabb_lo[a] + f.aabb_hi[a]) / 2.0f;
+            if (cm == cf) g[a] = xn[a];                    // wave-uniform
+            else g[a] = contract_power(p[a] - cm);
+        }
+    } else {
+        mask_normalize(f, p, g);
+    }
+    return mask_occupied_at(f, g);
 }
 
 // ---------------------------------------------------------------------------------------- VM addressing

@@ -7,10 +7,12 @@
 // field_kernels.hip
 hipError_t launch_k0_channels_last(const float* src, float* dst, int C, int64_t HW, hipStream_t s);
 hipError_t launch_k0_mask_bytes(const float* src, uint8_t* dst, int64_t n, hipStream_t s);
+hipError_t launch_k0_mask_cells(const uint8_t* mask, uint8_t* cell, int D, int H, int W, hipStream_t s);
 hipError_t launch_k0_basis_slices(const float* src, float* dst, int app_dim, int n_app, hipStream_t s);
 hipError_t launch_k0_basis_lanes(const float* src, float* dst, int app_dim, int n_app, hipStream_t s);
 hipError_t launch_normalize_coord(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
 hipError_t launch_mask_sample(const FieldDev& f, const float* xyz, int64_t n, float* out, hipStream_t s);
+hipError_t launch_mask_occupied(const FieldDev& f, const float* xyz, int64_t n, uint8_t* out, hipStream_t s);
 hipError_t launch_density_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s);
 hipError_t launch_point_alpha(const FieldDev& f, const float* xyz, int64_t n, float length, float* out, hipStream_t s);
 hipError_t launch_app_feature(const FieldDev& f, const float* xn, int64_t n, float* out, hipStream_t s);
@@ -124,8 +126,10 @@ hipError_t launch_pose(const int64_t* idx, const float* val, int Q, int k, const
                        int64_t ray_batch_stride, const float* up3, float* c2w, float* parts, hipStream_t s);
 
 // vit_kernels.hip -- the ViT-S/14 image backbone (pose_estimation/backbone.py:12-14)
+constexpr int VIT_MAX_DEPTH = 64;
 struct VitDev {
-    // bf16 GEMM weights in nn.Linear layout [out][in], stacked over the blocks
+    // GEMM weights in nn.Linear layout [out][in], stacked over the blocks: bf16 (prec 0), or fp16 hi plane followed by the lo
+    // plane of the whole stack, each layer's weights times the power of two 1 / s_*[layer] (prec 1: the fp32-accurate mode)
     const void* patch_w;                  // [dim][kp]           patch_embed.proj.weight, k = c P P + dy P + dx, zero padded to kp
     const void* qkv_w;                    // [depth][3 dim][dim]
     const void* proj_w;                   // [depth][dim][dim]
@@ -139,11 +143,14 @@ struct VitDev {
     const float* norm_w; const float* norm_b;
     int dim, depth, heads, mlp, patch, gh, gw, T, kp;
     float eps;
+    int prec;                             // 0: bf16 operands; 1: split fp16 operands (hi + lo), three products per block
+    float s_patch, s_qkv[VIT_MAX_DEPTH], s_proj[VIT_MAX_DEPTH], s_fc1[VIT_MAX_DEPTH], s_fc2[VIT_MAX_DEPTH];      // accumulator scales (prec 1)
 };
 hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int rh, int rw, int top, int left, int ch, int cw, int cubic,
                               const float* mean, const float* std, float* dst, hipStream_t s);
 size_t vit_workspace_bytes(const VitDev& v, int Q);
 hipError_t launch_vit_to_bf16(const float* src, int64_t n, void* dst, hipStream_t s);
+hipError_t launch_vit_to_f16_planes(const float* src, int64_t rows, int cols, int KP, float scale, void* hi, void* lo, hipStream_t s);
 hipError_t launch_vit_pad_rows(const float* src, int rows, int cols, int KP, void* dst, hipStream_t s);
 hipError_t launch_vit_forward(const VitDev& v, const float* images, int Q, int H, int W, float* patch_tokens, float* cls_opt, void* ws,
                               size_t ws_bytes, hipStream_t s);

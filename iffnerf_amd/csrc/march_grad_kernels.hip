@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(64 * GRAD_WAVES) k_march_grad(FieldDev f, Grad
             float feat = 0.0f;
             if (valid) {
                 field_normalize(f, p, xn);
-                if (f.mask) valid = mask_value(f, p, xn) > 0.0f;
+                if (f.mask) valid = mask_occupied(f, p, xn);
                 if (valid) feat = density_full(f, xn);
             }
             const float sigma = valid ? feature2density(f, feat) : 0.0f;

@@ -131,14 +131,15 @@ __global__ void __launch_bounds__(256) k4a_density_composite(FieldDev f, MarchAr
                 const bool inside = live && (ray0 + rl < a.R) && inside_aabb(f, p);
                 // the occupancy bytes and the density taps are requested together (both are safe for any coordinate);
                 // the mask decides afterwards which points count -- one memory round trip per pass instead of two
-                float part = 0.0f, mv = 1.0f;
+                float part = 0.0f;
+                bool occ = true;
                 if (inside) {
                     float xn[3];
                     field_normalize(f, p, xn);
-                    if (f.mask) mv = mask_value(f, p, xn);
+                    if (f.mask) occ = mask_occupied(f, p, xn);
                     part = (LPS == 4) ? density_partial(f, xn, lsub) : density_full(f, xn);
                 }
-                const bool valid = inside && (mv > 0.0f);
+                const bool valid = inside && occ;
                 float feat = (LPS == 4) ? sum4(valid ? part : 0.0f) : (valid ? part : 0.0f);
                 if (live && lsub == 0) {
                     // sigma and, already here, alpha (tensorBase.py:25,849): the sequential pass below keeps only the

@@ -103,9 +103,9 @@ __device__ inline bool grid_sync(SamplerWs* ws, unsigned& generation, unsigned n
 __device__ inline float alpha1(const FieldDev& f, const float p[3], bool live) {
     float xn[3];
     field_normalize(f, p, xn);
-    float mv = f.mask ? mask_value(f, p, xn) : 1.0f;
+    const bool occ = f.mask ? mask_occupied(f, p, xn) : true;
     float part = density_full(f, xn);
-    bool valid = live && (mv > 0.0f);
+    bool valid = live && occ;
     float sigma = valid ? feature2density(f, valid ? part : 0.0f) : 0.0f;
     return 1.0f - expf(-sigma * 1.0f);
 }
@@ -113,9 +113,9 @@ __device__ inline float alpha1(const FieldDev& f, const float p[3], bool live) {
 __device__ inline float alpha4(const FieldDev& f, const float p[3], int sub, bool live) {
     float xn[3];
     field_normalize(f, p, xn);
-    float mv = f.mask ? mask_value(f, p, xn) : 1.0f;
+    const bool occ = f.mask ? mask_occupied(f, p, xn) : true;
     float part = density_partial(f, xn, sub);
-    bool valid = live && (mv > 0.0f);
+    bool valid = live && occ;
     float feat = sum4(valid ? part : 0.0f);
     float sigma = valid ? feature2density(f, feat) : 0.0f;
     return 1.0f - expf(-sigma * 1.0f);
@@ -139,8 +139,7 @@ __device__ __forceinline__ void alpha_quad_step(const FieldDev& f, const float x
 __device__ inline float alpha_quad(const FieldDev& f, const float p[3], bool live) {
     float xn[3];
     field_normalize(f, p, xn);
-    const float mv = f.mask ? mask_value(f, p, xn) : 1.0f;
-    const bool valid = live && (mv > 0.0f);
+    const bool valid = live && (f.mask ? mask_occupied(f, p, xn) : true);
     const int sub = threadIdx.x & 3;
     float feat = 0.0f;
     alpha_quad_step<0>(f, xn, valid, sub, feat);

@@ -6,8 +6,15 @@
 //                     LayerNorm -> MLP 384 -> 1536 (exact GELU) -> 384, LayerScale, residual
 //   final LayerNorm   -> patch tokens [Q, 256, 384] fp32 (and the class token)
 //
-// Arithmetic: bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the residual stream, the LayerNorms, softmax
-// statistics and every epilogue are fp32.  One GEMM kernel (128 x 128 x 64 tiles, weights as the MFMA's A operand so that a lane
+// Arithmetic, two precisions behind one template parameter PREC:
+//   PREC 1 (the default of the Python side): fp32-accurate products on the fp16 matrix cores.  Every operand is the exact split
+//     a = hi + lo (hi = fp16(a), lo = fp16(a - hi): 22 significant bits) kept as two fp16 planes, and a product block is
+//     hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16 (the dropped lo lo term is <= 2^-22 of the product) -- the k loop simply
+//     runs three times over the planes.  Weights are stored times a power of two chosen at create so that fp16's range is used
+//     (the accumulator is multiplied back by the exact inverse).  The reference runs DINOv2 in fp32
+//     (pose_estimation/identification_module.py:137-142, backbone.py:12-14): this is that accuracy class.
+//   PREC 0: bf16 operands on v_mfma_f32_32x32x16_bf16 (one product per block: 8 significant bits) -- a throughput option.
+// fp32 accumulation, residual stream, LayerNorms, softmax statistics and epilogues in both.  One GEMM kernel (128 x 128 x 64 tiles, weights as the MFMA's A operand so that a lane
 // ends up with 4 consecutive output features of one token: 8- / 16-byte stores) with four epilogues; one attention kernel per
 // (image, head, 128-query block) that keeps K and V^T of the head in LDS, forms S^T = K Q^T so that a lane owns one query's whole
 // row of scores (row maximum and sum without cross-lane traffic) and feeds the probabilities to the P V product straight from the
@@ -21,11 +28,53 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// operand element of a precision, its 16- and 8-byte vectors, the MFMA that multiplies it, and the conversion from fp32:
+// PREC 0 rounds to bf16; PREC 1 returns the (hi, lo) pair of the exact split (the value clamped into fp16's range first)
+template <int PREC> struct VT;
+template <> struct VT<0> {
+    typedef __bf16 e; typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct VT<1> {
+    typedef _Float16 e; typedef f16x8 v8; typedef f16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+__device__ __forceinline__ void split_h(float v, _Float16& hi, _Float16& lo) {
+    v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+// element i (scalar) / elements i .. i + 3 of a row: PREC 0 one bf16 plane, PREC 1 the hi plane at `p` and the lo plane `lo_off` elements on
+template <int PREC>
+__device__ __forceinline__ void put1(void* p, int64_t i, int64_t lo_off, float v) {
+    if (PREC == 0) { reinterpret_cast<__bf16*>(p)[i] = (__bf16)v; return; }
+    _Float16 h, l;
+    split_h(v, h, l);
+    reinterpret_cast<_Float16*>(p)[i] = h;
+    reinterpret_cast<_Float16*>(p)[i + lo_off] = l;
+}
+template <int PREC>
+__device__ __forceinline__ void put4(void* p, int64_t i, int64_t lo_off, const float v[4]) {
+    if (PREC == 0) {
+        bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = o;
+        return;
+    }
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { _Float16 a, b; split_h(v[j], a, b); h[j] = a; l[j] = b; }
+    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(p) + i) = h;
+    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(p) + i + lo_off) = l;
+}
 
 // ------------------------------------------------------------------------------------------------ im2col, class token, LayerNorm
 // images [Q,3,H,W] fp32 (already resized / cropped / normalised) -> patches [Q * gh * gw][KP] bf16, k = c * P * P + dy * P + dx
 // (the flattening of patch_embed.proj.weight [D,3,P,P]); columns >= 3 P P are zero
-__global__ void k_vit_im2col(const float* __restrict__ img, int Q, int H, int W, int P, int gh, int gw, int KP, __bf16* __restrict__ out) {
+template <int PREC>
+__global__ void k_vit_im2col(const float* __restrict__ img, int Q, int H, int W, int P, int gh, int gw, int KP, void* __restrict__ out) {
     const int64_t n = (int64_t)Q * gh * gw * KP;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(t % KP);
@@ -36,7 +85,7 @@ __global__ void k_vit_im2col(const float* __restrict__ img, int Q, int H, int W,
             const int c = k / (P * P), r = k - c * P * P, dy = r / P, dx = r - dy * P;
             v = img[(((int64_t)q * 3 + c) * H + (py * P + dy)) * W + (px * P + dx)];
         }
-        out[t] = (__bf16)v;
+        put1<PREC>(out, t, n, v);
     }
 }
 
@@ -48,12 +97,12 @@ __global__ void k_vit_cls(const float* __restrict__ cls, const float* __restrict
     }
 }
 
-// LayerNorm over rows of D = 384 (eps inside the sqrt, affine), one wave per row.  OUT_BF16: bf16 rows for the next GEMM;
-// otherwise fp32 rows with the class-token row of every image dropped (the x_norm_patchtokens output) and, when cls_out is
-// given, the class-token rows there.
-template <bool OUT_BF16>
+// LayerNorm over rows of D = 384 (eps inside the sqrt, affine), one wave per row.  OUT = 1 / 2: operand rows for the next GEMM
+// (bf16 / fp16 hi + lo planes); OUT = 0: fp32 rows with the class-token row of every image dropped (the x_norm_patchtokens
+// output) and, when cls_out is given, the class-token rows there.
+template <int OUT>
 __global__ void __launch_bounds__(256) k_vit_layernorm(const float* __restrict__ x, int64_t M, int T, const float* __restrict__ g,
-                                                       const float* __restrict__ b, float eps, __bf16* __restrict__ out_bf,
+                                                       const float* __restrict__ b, float eps, void* __restrict__ out_op,
                                                        float* __restrict__ out_f, float* __restrict__ cls_out) {
     constexpr int D = 384;
     const int lane = threadIdx.x & 63;
@@ -81,10 +130,18 @@ __global__ void __launch_bounds__(256) k_vit_layernorm(const float* __restrict__
         const int c = 2 * lane + 128 * j;
         const float2 gg = *reinterpret_cast<const float2*>(g + c), bb = *reinterpret_cast<const float2*>(b + c);
         const float y0 = (v[2 * j] - mean) * rstd * gg.x + bb.x, y1 = (v[2 * j + 1] - mean) * rstd * gg.y + bb.y;
-        if (OUT_BF16) {
+        if (OUT == 1) {
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             bf16x2 o = {(__bf16)y0, (__bf16)y1};
-            *reinterpret_cast<bf16x2*>(out_bf + row * D + c) = o;
+            *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(out_op) + row * D + c) = o;
+        } else if (OUT == 2) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            _Float16 h0, l0, h1, l1;
+            split_h(y0, h0, l0); split_h(y1, h1, l1);
+            f16x2 oh = {h0, h1}, ol = {l0, l1};
+            _Float16* op = reinterpret_cast<_Float16*>(out_op) + row * D + c;
+            *reinterpret_cast<f16x2*>(op) = oh;
+            *reinterpret_cast<f16x2*>(op + M * D) = ol;
         } else {
             const int64_t q = row / T;
             const int t = (int)(row - q * T);
@@ -100,11 +157,13 @@ enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_EMBED = 3 };
 constexpr int AT_TP = 288;          // attention: keys padded to 9 blocks of 32 (T = 257 tokens); also the row length of V^T
 struct GemmEpi {
     const float* bias;        // [N]
-    // EPI_QKV: q (times `qscale`) and k as [img][head][T][64] bf16, v TRANSPOSED as [img][head][64][AT_TP] (the attention kernel's
-    // P V product needs its keys contiguous per feature; columns T .. AT_TP - 1 are never written and are masked by the reader)
-    __bf16* q; __bf16* k; __bf16* v; int T; int heads; float qscale;
-    // EPI_GELU: out [M][N] bf16
-    __bf16* out;
+    float wscale;             // PREC 1: the weights were stored times 1 / wscale (a power of two): acc * wscale is the product
+    // EPI_QKV: q (times `qscale`) and k as [img][head][T][64] operand rows, v TRANSPOSED as [img][head][64][AT_TP] (the attention
+    // kernel's P V product needs its keys contiguous per feature; columns T .. AT_TP - 1 are never written and are masked by the
+    // reader).  PREC 1: the lo plane of each sits `qk_lo` / `v_lo` elements behind its hi plane
+    void* q; void* k; void* v; int T; int heads; float qscale; int64_t qk_lo, v_lo;
+    // EPI_GELU: out [M][N] operand rows (PREC 1: lo plane M * N elements on)
+    void* out;
     // EPI_RESID: x[m][n] += ls[n] * (acc + bias[n])
     float* x; const float* ls;
     // EPI_EMBED: x[(m / G) * T + 1 + m % G][n] = acc + bias[n] + pos[1 + m % G][n]   (G patches per image)
@@ -128,12 +187,17 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(y, x);
 }
 
-template <int EPI, int GBM>
-__global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt, int64_t M, int N, int K,
+// PREC 1: X and Wt are the hi planes, the lo planes sit x_lo / w_lo elements behind them, and the k loop runs over the three
+// products hi hi, hi lo (the weight's lo plane), lo hi (the activation's lo plane) -- same tiles, same LDS, three times the steps.
+template <int EPI, int GBM, int PREC>
+__global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e* __restrict__ X, int64_t x_lo,
+                                                     const typename VT<PREC>::e* __restrict__ Wt, int64_t w_lo, int64_t M, int N, int K,
                                                      GemmEpi e) {
+    typedef typename VT<PREC>::e ET;
+    typedef typename VT<PREC>::v8 bf16x8;                      // (the 16-byte operand vector of this precision)
     constexpr int MB = GBM / 64;                                // 32-token blocks per wave
-    __shared__ __attribute__((aligned(16))) __bf16 sW[GBN][GLD];
-    __shared__ __attribute__((aligned(16))) __bf16 sX[GBM][GLD];
+    __shared__ __attribute__((aligned(16))) ET sW[GBN][GLD];
+    __shared__ __attribute__((aligned(16))) ET sX[GBM][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = (wave & 1) * 64, wm = (wave >> 1) * (32 * MB);      // the wave's corner of the tile
     const int lr = lane & 31, lh = lane >> 5;
@@ -150,17 +214,21 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
     // registers (sets A and B, the k loop unrolled by two): a k step is 8-16 MFMAs per wave, a third of the latency of the tile
     // that travels, and one tile ahead left every step waiting for it (K / GBK is even for every GEMM of the network: 6, 24, 10)
     bf16x8 gwA[4], gxA[2 * MB], gwB[4], gxB[2 * MB];
-    auto fetch = [&](bf16x8 (&gw)[4], bf16x8 (&gx)[2 * MB], int k0) {
+    const int KT = PREC ? 3 * K : K;                            // k steps over all products (a tile never straddles two: K % GBK == 0)
+    auto fetch = [&](bf16x8 (&gw)[4], bf16x8 (&gx)[2 * MB], int kv) {
+        const int seg = PREC ? kv / K : 0, k0 = kv - seg * K;    // wave-uniform
+        const ET* Wp = Wt + (seg == 1 ? w_lo : 0);
+        const ET* Xp = X + (seg == 2 ? x_lo : 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
-            gw[r] = *reinterpret_cast<const bf16x8*>(Wt + (int64_t)(n0 + row) * K + k0 + kc);
+            gw[r] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(n0 + row) * K + k0 + kc);
         }
 #pragma unroll
         for (int r = 0; r < 2 * MB; ++r) {
             const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
             const int64_t m = min(m0 + row, M - 1);
-            gx[r] = *reinterpret_cast<const bf16x8*>(X + m * K + k0 + kc);
+            gx[r] = *reinterpret_cast<const bf16x8*>(Xp + m * K + k0 + kc);
         }
     };
     auto step = [&](bf16x8 (&gw)[4], bf16x8 (&gx)[2 * MB], int k_next) {
@@ -176,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
             *reinterpret_cast<bf16x8*>(&sX[row][kc]) = gx[r];
         }
         __syncthreads();
-        if (k_next < K) fetch(gw, gx, k_next);     // this set's next tile (two steps ahead) travels while two tiles are multiplied
+        if (k_next < KT) fetch(gw, gx, k_next);    // this set's next tile (two steps ahead) travels while two tiles are multiplied
 #pragma unroll
         for (int ks = 0; ks < GBK / 16; ++ks) {
             bf16x8 fa[2], fb[MB];
@@ -187,14 +255,14 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < MB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < MB; ++b) acc[a][b] = VT<PREC>::mfma(fa[a], fb[b], acc[a][b]);
         }
     };
     fetch(gwA, gxA, 0);
-    if (GBK < K) fetch(gwB, gxB, GBK);
-    for (int k0 = 0; k0 < K; k0 += 2 * GBK) {
+    if (GBK < KT) fetch(gwB, gxB, GBK);
+    for (int k0 = 0; k0 < KT; k0 += 2 * GBK) {
         step(gwA, gxA, k0 + 2 * GBK);
-        if (k0 + GBK < K) step(gwB, gxB, k0 + 3 * GBK);
+        if (k0 + GBK < KT) step(gwB, gxB, k0 + 3 * GBK);
     }
     // D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh: four consecutive n per reg group
 #pragma unroll
@@ -207,27 +275,30 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const __bf16* __restrict__ 
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int n = n0 + wn + 32 * a + 8 * g4 + 4 * lh;
                 const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
-                float v[4] = {acc[a][b][4 * g4] + bi.x, acc[a][b][4 * g4 + 1] + bi.y, acc[a][b][4 * g4 + 2] + bi.z, acc[a][b][4 * g4 + 3] + bi.w};
+                float v[4] = {acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+                if (PREC) { v[0] *= e.wscale; v[1] *= e.wscale; v[2] *= e.wscale; v[3] *= e.wscale; }       // exact: a power of two
+                v[0] += bi.x; v[1] += bi.y; v[2] += bi.z; v[3] += bi.w;
                 if (EPI == EPI_QKV) {
                     // a 128-column tile lies inside one of q / k / v (D = 384 = 3 x 128): `which` is the workgroup's, not the element's
                     const int D = N / 3, which = n0 / D, c = n - which * D, head = c >> 6, d = c & 63;
                     const int img = (int)m / e.T;
                     const int t = (int)m - img * e.T;
                     if (which == 2) {            // V^T: the 32 lanes of a half wave write 32 consecutive tokens of one feature row
-                        __bf16* dst = e.v + ((int64_t)(img * e.heads + head) * 64 + d) * AT_TP + t;
+                        const int64_t at = ((int64_t)(img * e.heads + head) * 64 + d) * AT_TP + t;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) dst[i * AT_TP] = (__bf16)v[i];
+                        for (int i = 0; i < 4; ++i) put1<PREC>(e.v, at + (int64_t)i * AT_TP, e.v_lo, v[i]);
                     } else {
-                        __bf16* dst = (which == 0 ? e.q : e.k) + (((int64_t)(img * e.heads + head) * e.T + t) << 6) + d;
+                        const int64_t at = (((int64_t)(img * e.heads + head) * e.T + t) << 6) + d;
                         const float sc = which == 0 ? e.qscale : 1.0f;
-                        bf16x4 o = {(__bf16)(v[0] * sc), (__bf16)(v[1] * sc), (__bf16)(v[2] * sc), (__bf16)(v[3] * sc)};
-                        *reinterpret_cast<bf16x4*>(dst) = o;
+                        const float o[4] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+                        put4<PREC>(which == 0 ? e.q : e.k, at, e.qk_lo, o);
                     }
                 } else if (EPI == EPI_GELU) {
-                    bf16x4 o;
+                    float o[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752440f)));
-                    *reinterpret_cast<bf16x4*>(e.out + m * N + n) = o;
+                    for (int i = 0; i < 4; ++i)      // PREC 1: erff (the approximation below is good to 1.5e-7 absolute: bf16-class only)
+                        o[i] = 0.5f * v[i] * (1.0f + (PREC ? erff(v[i] * 0.70710678118654752440f) : erf_as(v[i] * 0.70710678118654752440f)));
+                    put4<PREC>(e.out, m * N + n, M * (int64_t)N, o);
                 } else if (EPI == EPI_RESID) {
                     const float4 ls = *reinterpret_cast<const float4*>(e.ls + n);
                     float4* xp = reinterpret_cast<float4*>(e.x + m * N + n);
@@ -365,6 +436,138 @@ __global__ void __launch_bounds__(256, 2) k_vit_attention(const __bf16* __restri
     }
 }
 
+// The same attention with fp32-accurate products (PREC 1): Q, K, V^T arrive as fp16 hi / lo planes (the lo plane qk_lo / v_lo
+// elements behind the hi plane), S^T = Kh Qh + Kl Qh + Kh Ql and O^T = Vh Ph + Vl Ph + Vh Pl with P split in registers.  K's two
+// planes and then V^T's two planes pass through ONE LDS buffer (83 KB: one workgroup per CU), one after the other.
+__global__ void __launch_bounds__(256, 1) k_vit_attention_x2(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Kh, int64_t qk_lo,
+                                                             const _Float16* __restrict__ Vh, int64_t v_lo, int T, int heads,
+                                                             _Float16* __restrict__ out, int64_t out_lo) {
+    constexpr int K_PLANE = AT_TP * AT_KLD, V_PLANE = 64 * AT_VLD;
+    __shared__ __attribute__((aligned(16))) _Float16 s_buf[2 * (K_PLANE > V_PLANE ? K_PLANE : V_PLANE)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int ih = blockIdx.y;
+    const int64_t base = (int64_t)ih * T * 64;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {                          // K planes: rows beyond T zero
+        f16x8 kv[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int chunk = tid + 256 * r, t = chunk >> 3, dc = (chunk & 7) * 8;
+            kv[r] = *reinterpret_cast<const f16x8*>(Kh + pl * qk_lo + base + min(t, T - 1) * 64 + dc);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int chunk = tid + 256 * r, t = chunk >> 3, dc = (chunk & 7) * 8;
+            if (t >= T) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kv[r][i] = (_Float16)0.0f;
+            }
+            *reinterpret_cast<f16x8*>(&s_buf[pl * K_PLANE + t * AT_KLD + dc]) = kv[r];
+        }
+    }
+    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    const int qc = min(q, T - 1);
+    f16x8 fq[2][4];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fq[pl][ks] = *reinterpret_cast<const f16x8*>(Qh + pl * qk_lo + base + qc * 64 + 16 * ks + 8 * lh);
+    __syncthreads();
+    f32x16 S[AT_TP / 32];
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[b][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(&s_buf[(32 * b + lr) * AT_KLD + 16 * ks + 8 * lh]);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(&s_buf[K_PLANE + (32 * b + lr) * AT_KLD + 16 * ks + 8 * lh]);
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, fq[0][ks], S[b], 0, 0, 0);      // the small terms first
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, fq[1][ks], S[b], 0, 0, 0);
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, fq[0][ks], S[b], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                         // every wave has read K: V^T's planes go over it
+    {
+        const _Float16* Vt = Vh + (int64_t)ih * 64 * AT_TP;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            f16x8 vv[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) vv[r] = *reinterpret_cast<const f16x8*>(Vt + pl * v_lo + (tid + 256 * r) * 8);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int chunk = tid + 256 * r, d = chunk / 36, t8 = (chunk - d * 36) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (t8 + i >= T) vv[r][i] = (_Float16)0.0f;
+                f16x4 lo4 = {vv[r][0], vv[r][1], vv[r][2], vv[r][3]}, hi4 = {vv[r][4], vv[r][5], vv[r][6], vv[r][7]};
+                *reinterpret_cast<f16x4*>(&s_buf[pl * V_PLANE + d * AT_VLD + t8]) = lo4;
+                *reinterpret_cast<f16x4*>(&s_buf[pl * V_PLANE + d * AT_VLD + t8 + 4]) = hi4;
+            }
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b) {
+        if (32 * b + 32 > T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh >= T) S[b][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, S[b][r]), S[b][r + 1]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[b][r] = expf(S[b][r] - mx); sum += S[b][r]; }
+    sum += __shfl_xor(sum, 32, 64);
+    __syncthreads();
+    f32x16 O[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[a][r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < AT_TP / 32; ++b)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { _Float16 h, l; split_h(S[b][8 * s2 + j], h, l); ph[j] = h; pl[j] = l; }
+            const int t0 = 32 * b + 16 * s2 + 4 * lh;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f16x8 fv[2];
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const f16x4 v0 = *reinterpret_cast<const f16x4*>(&s_buf[p2 * V_PLANE + (32 * a + lr) * AT_VLD + t0]);
+                    const f16x4 v1 = *reinterpret_cast<const f16x4*>(&s_buf[p2 * V_PLANE + (32 * a + lr) * AT_VLD + t0 + 8]);
+                    fv[p2] = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
+                O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[1], ph, O[a], 0, 0, 0);
+                O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[0], pl, O[a], 0, 0, 0);
+                O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[0], ph, O[a], 0, 0, 0);
+            }
+        }
+    if (q < T) {
+        const float inv = 1.0f / sum;
+        const int64_t img = ih / heads;
+        const int head = ih - (int)img * heads;
+        const int64_t at = ((img * T + q) * heads + head) * 64;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float o[4] = {O[a][4 * g4] * inv, O[a][4 * g4 + 1] * inv, O[a][4 * g4 + 2] * inv, O[a][4 * g4 + 3] * inv};
+                put4<1>(out, at + 32 * a + 8 * g4 + 4 * lh, out_lo, o);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ image preprocessing
 // Antialiased resize (the separable triangle / cubic a = -0.5 filters ATen's upsample_*2d_aa kernels use, i.e. what
 // F.interpolate(..., antialias=True, align_corners=False) computes) of channels-last images, cropped to a window of the resized
@@ -487,13 +690,29 @@ __global__ void k_vit_pad_rows(const float* __restrict__ src, int rows, int cols
     }
 }
 
+// fp32 weights times `scale` (a power of two) -> fp16 hi / lo planes; rows of `cols` floats zero-padded to `KP` (patch embedding)
+__global__ void k_vit_to_f16_planes(const float* __restrict__ src, int64_t rows, int cols, int KP, float scale, _Float16* __restrict__ hi,
+                                    _Float16* __restrict__ lo) {
+    const int64_t n = rows * KP;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / KP;
+        const int c = (int)(t - r * KP);
+        _Float16 h, l;
+        split_h(c < cols ? src[r * cols + c] * scale : 0.0f, h, l);
+        hi[t] = h; lo[t] = l;
+    }
+}
+
 inline unsigned grid1(int64_t n, int block = 256, int cap = 256 * 16) {
     int64_t g = (n + block - 1) / block;
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-template <int EPI>
-hipError_t gemm(const __bf16* X, const __bf16* W, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
+template <int EPI, int PREC>
+hipError_t gemm(const void* Xv, int64_t x_lo, const void* Wv, int64_t w_lo, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
+    typedef typename VT<PREC>::e ET;
+    const ET* X = (const ET*)Xv;
+    const ET* W = (const ET*)Wv;
     if (N % GBN != 0 || K % GBK != 0 || M < 1) return hipErrorInvalidValue;
     static const int force = [] { const char* e = getenv("IFF_VIT_TILE"); return e ? atoi(e) : 0; }();      // tuning aid
     // 64-token tiles for small batches (with 128 a 4112-token batch -- 16 images -- leaves CUs idle or a single workgroup per CU);
@@ -501,9 +720,9 @@ hipError_t gemm(const __bf16* X, const __bf16* W, int64_t M, int N, int K, const
     // and with several batches in flight (the bench's four graphs) the total is 5 % faster (17 700 -> 18 700 images/s at 32 images)
     const bool wide = force ? force == 128 : M >= 6144;       // (64-token tiles for the N = 384 products only: -1.7 % images/s)
     if (!wide)
-        hipLaunchKernelGGL((k_vit_gemm<EPI, 64>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, W, M, N, K, e);
+        hipLaunchKernelGGL((k_vit_gemm<EPI, 64, PREC>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, x_lo, W, w_lo, M, N, K, e);
     else
-        hipLaunchKernelGGL((k_vit_gemm<EPI, 128>), dim3((unsigned)(N / GBN), (unsigned)((M + 127) / 128)), dim3(256), 0, s, X, W, M, N, K, e);
+        hipLaunchKernelGGL((k_vit_gemm<EPI, 128, PREC>), dim3((unsigned)(N / GBN), (unsigned)((M + 127) / 128)), dim3(256), 0, s, X, x_lo, W, w_lo, M, N, K, e);
     return hipGetLastError();
 }
 
@@ -542,64 +761,86 @@ hipError_t launch_vit_pad_rows(const float* src, int rows, int cols, int KP, voi
     return hipGetLastError();
 }
 
+hipError_t launch_vit_to_f16_planes(const float* src, int64_t rows, int cols, int KP, float scale, void* hi, void* lo, hipStream_t s) {
+    hipLaunchKernelGGL(k_vit_to_f16_planes, dim3(grid1(rows * KP)), dim3(256), 0, s, src, rows, cols, KP, scale, (_Float16*)hi, (_Float16*)lo);
+    return hipGetLastError();
+}
+
 size_t vit_workspace_bytes(const VitDev& v, int Q) {
     const size_t M = (size_t)Q * v.T, G = (size_t)Q * (v.T - 1);
+    const size_t eb = v.prec ? 4 : 2;           // bytes per operand element: bf16, or fp16 hi + lo planes
     size_t b = 0;
     auto take = [&](size_t bytes) { b += (bytes + 255) / 256 * 256; };
     take(M * v.dim * 4);            // x      residual stream, fp32
-    take(M * v.dim * 2);            // xn     LayerNorm output / attention output, bf16
-    take(M * v.dim * 2 * 2);        // q, k per head
-    take((size_t)Q * v.heads * 64 * AT_TP * 2);      // v per head, transposed, rows of AT_TP keys
-    take(M * v.mlp * 2);            // MLP hidden
-    take(G * v.kp * 2);             // im2col
+    take(M * v.dim * eb);           // xn     LayerNorm output / attention output
+    take(M * v.dim * 2 * eb);       // q, k per head
+    take((size_t)Q * v.heads * 64 * AT_TP * eb);     // v per head, transposed, rows of AT_TP keys
+    take(M * v.mlp * eb);           // MLP hidden
+    take(G * v.kp * eb);            // im2col
     return b;
+}
+
+template <int PREC>
+static hipError_t vit_forward(const VitDev& v, const float* images, int Q, int H, int W, float* patch_tokens, float* cls_opt, void* ws,
+                              hipStream_t s) {
+    typedef typename VT<PREC>::e ET;
+    const int64_t M = (int64_t)Q * v.T, G = (int64_t)Q * (v.T - 1);
+    const int D = v.dim, L = v.depth;
+    const size_t eb = PREC ? 4 : 2;
+    char* p = (char*)ws;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    float* x = (float*)take((size_t)M * D * 4);
+    ET* xn = (ET*)take((size_t)M * D * eb);                    // PREC 1: [2][M][D], the lo plane behind the hi plane (likewise below)
+    ET* q = (ET*)take((size_t)M * D * 2 * eb);                 // q | k (| q lo | k lo)
+    ET* k = q + M * D;
+    ET* vv = (ET*)take((size_t)Q * v.heads * 64 * AT_TP * eb);
+    ET* hid = (ET*)take((size_t)M * v.mlp * eb);
+    ET* col = (ET*)take((size_t)G * v.kp * eb);
+    const int64_t xn_lo = M * D, qk_lo = 2 * M * D, v_lo = (int64_t)Q * v.heads * 64 * AT_TP, hid_lo = M * v.mlp, col_lo = G * v.kp;
+    // weight planes: the lo plane of a stacked weight sits the whole stack behind its hi plane
+    const int64_t w_patch_lo = (int64_t)D * v.kp, w_qkv_lo = (int64_t)L * 3 * D * D, w_proj_lo = (int64_t)L * D * D, w_fc_lo = (int64_t)L * v.mlp * D;
+    hipError_t e;
+    hipLaunchKernelGGL((k_vit_im2col<PREC>), dim3(grid1(G * v.kp)), dim3(256), 0, s, images, Q, H, W, v.patch, v.gh, v.gw, v.kp, (void*)col);
+    hipLaunchKernelGGL(k_vit_cls, dim3(grid1((int64_t)Q * D)), dim3(256), 0, s, v.cls, v.pos, Q, v.T, D, x);
+    GemmEpi ep = {};
+    ep.bias = v.patch_b; ep.x = x; ep.pos = v.pos; ep.G = v.T - 1; ep.T = v.T; ep.wscale = v.s_patch;
+    if ((e = gemm<EPI_EMBED, PREC>(col, col_lo, v.patch_w, w_patch_lo, G, D, v.kp, ep, s)) != hipSuccess) return e;
+    const unsigned ln_grid = (unsigned)((M + 3) / 4);
+    constexpr int LN_OUT = PREC ? 2 : 1;
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL((k_vit_layernorm<LN_OUT>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.ln1_w + (size_t)l * D, v.ln1_b + (size_t)l * D,
+                           v.eps, (void*)xn, nullptr, nullptr);
+        GemmEpi e0 = {};
+        e0.bias = v.qkv_b + (size_t)l * 3 * D; e0.q = q; e0.k = k; e0.v = vv; e0.T = v.T; e0.heads = v.heads; e0.qscale = 0.125f;
+        e0.qk_lo = qk_lo; e0.v_lo = v_lo; e0.wscale = v.s_qkv[l];
+        if ((e = gemm<EPI_QKV, PREC>(xn, xn_lo, (const ET*)v.qkv_w + (size_t)l * 3 * D * D, w_qkv_lo, M, 3 * D, D, e0, s)) != hipSuccess) return e;
+        if (PREC)
+            hipLaunchKernelGGL(k_vit_attention_x2, dim3((unsigned)((v.T + 127) / 128), (unsigned)(Q * v.heads)), dim3(256), 0, s, (const _Float16*)q,
+                               (const _Float16*)k, qk_lo, (const _Float16*)vv, v_lo, v.T, v.heads, (_Float16*)xn, xn_lo);
+        else
+            hipLaunchKernelGGL(k_vit_attention, dim3((unsigned)((v.T + 127) / 128), (unsigned)(Q * v.heads)), dim3(256), 0, s, (const __bf16*)q,
+                               (const __bf16*)k, (const __bf16*)vv, v.T, v.heads, (__bf16*)xn);
+        GemmEpi e1 = {};
+        e1.bias = v.proj_b + (size_t)l * D; e1.x = x; e1.ls = v.ls1 + (size_t)l * D; e1.wscale = v.s_proj[l];
+        if ((e = gemm<EPI_RESID, PREC>(xn, xn_lo, (const ET*)v.proj_w + (size_t)l * D * D, w_proj_lo, M, D, D, e1, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_vit_layernorm<LN_OUT>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.ln2_w + (size_t)l * D, v.ln2_b + (size_t)l * D,
+                           v.eps, (void*)xn, nullptr, nullptr);
+        GemmEpi e2 = {};
+        e2.bias = v.fc1_b + (size_t)l * v.mlp; e2.out = hid; e2.wscale = v.s_fc1[l];
+        if ((e = gemm<EPI_GELU, PREC>(xn, xn_lo, (const ET*)v.fc1_w + (size_t)l * v.mlp * D, w_fc_lo, M, v.mlp, D, e2, s)) != hipSuccess) return e;
+        GemmEpi e3 = {};
+        e3.bias = v.fc2_b + (size_t)l * D; e3.x = x; e3.ls = v.ls2 + (size_t)l * D; e3.wscale = v.s_fc2[l];
+        if ((e = gemm<EPI_RESID, PREC>(hid, hid_lo, (const ET*)v.fc2_w + (size_t)l * D * v.mlp, w_fc_lo, M, D, v.mlp, e3, s)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_vit_layernorm<0>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.norm_w, v.norm_b, v.eps, nullptr, patch_tokens, cls_opt);
+    return hipGetLastError();
 }
 
 hipError_t launch_vit_forward(const VitDev& v, const float* images, int Q, int H, int W, float* patch_tokens, float* cls_opt, void* ws,
                               size_t ws_bytes, hipStream_t s) {
     if (Q < 1) return hipSuccess;
     if (ws_bytes < vit_workspace_bytes(v, Q) || v.dim != 384 || v.heads * 64 != v.dim || v.T > AT_TP || H != v.gh * v.patch ||
-        W != v.gw * v.patch)
+        W != v.gw * v.patch || v.depth > VIT_MAX_DEPTH)
         return hipErrorInvalidValue;
-    const int64_t M = (int64_t)Q * v.T, G = (int64_t)Q * (v.T - 1);
-    const int D = v.dim;
-    char* p = (char*)ws;
-    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
-    float* x = (float*)take((size_t)M * D * 4);
-    __bf16* xn = (__bf16*)take((size_t)M * D * 2);
-    __bf16* q = (__bf16*)take((size_t)M * D * 2 * 2);
-    __bf16* k = q + M * D;
-    __bf16* vv = (__bf16*)take((size_t)Q * v.heads * 64 * AT_TP * 2);
-    __bf16* hid = (__bf16*)take((size_t)M * v.mlp * 2);
-    __bf16* col = (__bf16*)take((size_t)G * v.kp * 2);
-    hipError_t e;
-    hipLaunchKernelGGL(k_vit_im2col, dim3(grid1(G * v.kp)), dim3(256), 0, s, images, Q, H, W, v.patch, v.gh, v.gw, v.kp, col);
-    hipLaunchKernelGGL(k_vit_cls, dim3(grid1((int64_t)Q * D)), dim3(256), 0, s, v.cls, v.pos, Q, v.T, D, x);
-    GemmEpi ep = {};
-    ep.bias = v.patch_b; ep.x = x; ep.pos = v.pos; ep.G = v.T - 1; ep.T = v.T;
-    if ((e = gemm<EPI_EMBED>(col, (const __bf16*)v.patch_w, G, D, v.kp, ep, s)) != hipSuccess) return e;
-    const unsigned ln_grid = (unsigned)((M + 3) / 4);
-    for (int l = 0; l < v.depth; ++l) {
-        hipLaunchKernelGGL((k_vit_layernorm<true>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.ln1_w + (size_t)l * D, v.ln1_b + (size_t)l * D,
-                           v.eps, xn, nullptr, nullptr);
-        GemmEpi e0 = {};
-        e0.bias = v.qkv_b + (size_t)l * 3 * D; e0.q = q; e0.k = k; e0.v = vv; e0.T = v.T; e0.heads = v.heads; e0.qscale = 0.125f;
-        if ((e = gemm<EPI_QKV>(xn, (const __bf16*)v.qkv_w + (size_t)l * 3 * D * D, M, 3 * D, D, e0, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_vit_attention, dim3((unsigned)((v.T + 127) / 128), (unsigned)(Q * v.heads)), dim3(256), 0, s, q, k, vv, v.T,
-                           v.heads, xn);
-        GemmEpi e1 = {};
-        e1.bias = v.proj_b + (size_t)l * D; e1.x = x; e1.ls = v.ls1 + (size_t)l * D;
-        if ((e = gemm<EPI_RESID>(xn, (const __bf16*)v.proj_w + (size_t)l * D * D, M, D, D, e1, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_vit_layernorm<true>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.ln2_w + (size_t)l * D, v.ln2_b + (size_t)l * D,
-                           v.eps, xn, nullptr, nullptr);
-        GemmEpi e2 = {};
-        e2.bias = v.fc1_b + (size_t)l * v.mlp; e2.out = hid;
-        if ((e = gemm<EPI_GELU>(xn, (const __bf16*)v.fc1_w + (size_t)l * v.mlp * D, M, v.mlp, D, e2, s)) != hipSuccess) return e;
-        GemmEpi e3 = {};
-        e3.bias = v.fc2_b + (size_t)l * D; e3.x = x; e3.ls = v.ls2 + (size_t)l * D;
-        if ((e = gemm<EPI_RESID>(hid, (const __bf16*)v.fc2_w + (size_t)l * D * v.mlp, M, D, v.mlp, e3, s)) != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((k_vit_layernorm<false>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.norm_w, v.norm_b, v.eps, nullptr, patch_tokens,
-                       cls_opt);
-    return hipGetLastError();
+    return v.prec ? vit_forward<1>(v, images, Q, H, W, patch_tokens, cls_opt, ws, s) : vit_forward<0>(v, images, Q, H, W, patch_tokens, cls_opt, ws, s);
 }

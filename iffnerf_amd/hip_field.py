@@ -143,6 +143,14 @@ class FieldHandle:
         x = self._pts(xyz, "xyz")
         return self._call(_lib.lib().iff_mask_sample, x, x.new_empty(x.shape[0]))
 
+    def mask_occupied(self, xyz):
+        """``sample_alpha(xyz) > 0`` (tensorBase.py:762-764) from the corner-bit table: bool [n]."""
+        x = self._pts(xyz, "xyz")
+        out = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().iff_mask_occupied(self._h, dptr(x), x.shape[0], out.data_ptr(), stream_ptr(self.device)), "iff_mask_occupied")
+        return out.bool()
+
     def density_feature(self, xn):
         x = self._pts(xn, "xyz_sampled")
         return self._call(_lib.lib().iff_density_feature, x, x.new_empty(x.shape[0]))

@@ -38,6 +38,9 @@ def interpolate_pos_embed(pos: torch.Tensor, gh: int, gw: int, patch: int = 14, 
     return torch.cat((pos[0, :1], grid.permute(0, 2, 3, 1).reshape(gh * gw, -1)), dim=0).contiguous()
 
 
+PRECISIONS = {"fp32": _lib.VIT_FP32, "bf16": _lib.VIT_BF16}
+
+
 def _pick(sd: Dict[str, torch.Tensor], *names):
     for n in names:
         if n in sd:
@@ -48,8 +51,14 @@ def _pick(sd: Dict[str, torch.Tensor], *names):
 class ViTHandle:
     """One ViT-S/14's weights on one GPU (``iff_vit``)."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device, grid=(16, 16), patch: int = 14, heads: int = 6, ln_eps: float = 1e-6):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device, grid=(16, 16), patch: int = 14, heads: int = 6, ln_eps: float = 1e-6,
+                 precision: str = "fp32"):
+        """``precision``: "fp32" (the default) -- the accuracy class of the reference's fp32 DINOv2: every matrix operand split exactly
+        into two fp16 pieces, three MFMA products per block, fp32 accumulation (include/iffnerf_hip.h IFF_VIT_FP32); "bf16" -- bf16
+        operands, ~2x faster, token features move by ~1e-2 relative (a throughput option)."""
         self._h = None
+        if precision not in PRECISIONS:
+            raise RuntimeError(f"precision must be one of {sorted(PRECISIONS)} (got {precision!r})")
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(f"ViTHandle needs a GPU device (got {device}); libiffnerf_hip has no CPU path")
@@ -85,6 +94,8 @@ class ViTHandle:
         d = _lib.VitDesc()
         d.dim, d.depth, d.heads, d.mlp, d.patch, d.grid_h, d.grid_w = dim, depth, int(heads), int(t["fc1_w"].shape[1]), int(patch), gh, gw
         d.ln_eps = float(ln_eps)
+        d.precision = PRECISIONS[precision]
+        self.precision = precision
         keep = []
         for name, v in t.items():
             v = v.to(device=device, dtype=torch.float32).contiguous()
@@ -131,14 +142,14 @@ class _NativeForwardFeatures:
     """The callable installed as a backbone module's ``forward_features`` by ``serve_natively``.  It holds the module it serves (the
     module holds it in turn: an ordinary reference cycle) and the ``iff_vit`` handle built from the module's CURRENT parameters."""
 
-    def __init__(self, module: torch.nn.Module, grid, patch: int):
-        self.module, self.grid, self.patch = module, (int(grid[0]), int(grid[1])), int(patch)
+    def __init__(self, module: torch.nn.Module, grid, patch: int, precision: str = "fp32"):
+        self.module, self.grid, self.patch, self.precision = module, (int(grid[0]), int(grid[1])), int(patch), precision
         self._handle: Optional[ViTHandle] = None
         self._key = None
 
     # a handle is a device resource of THIS process: copies and pickles of the module start without one
     def __getstate__(self):
-        return {"module": self.module, "grid": self.grid, "patch": self.patch, "_handle": None, "_key": None}
+        return {"module": self.module, "grid": self.grid, "patch": self.patch, "precision": self.precision, "_handle": None, "_key": None}
 
     def stock(self, x, *args, **kwargs):
         """The module's own (class-level) ``forward_features``: stock torch ops."""
@@ -149,7 +160,7 @@ class _NativeForwardFeatures:
         if self._handle is None or self._key != key:
             if self._handle is not None:
                 self._handle.close()
-            self._handle, self._key = ViTHandle(self.module.state_dict(), device, self.grid, self.patch), key
+            self._handle, self._key = ViTHandle(self.module.state_dict(), device, self.grid, self.patch, precision=self.precision), key
         return self._handle
 
     def __call__(self, x, masks=None, *args, **kwargs):
@@ -161,18 +172,21 @@ class _NativeForwardFeatures:
         return {"x_norm_clstoken": cls, "x_norm_patchtokens": tok}
 
 
-def serve_natively(module: torch.nn.Module, grid=(16, 16), patch: int = 14) -> torch.nn.Module:
+def serve_natively(module: torch.nn.Module, grid=(16, 16), patch: int = 14, precision: str = "fp32") -> torch.nn.Module:
     """Serve ``module.forward_features`` (what pose_estimation/identification_module.py:141 calls) from ``iff_vit_forward`` and
     return THE SAME module.  Nothing is wrapped: the module keeps its class, its parameters and its ``state_dict`` keys, so an
     ``IdentificationModule`` built on it saves and strict-loads ``image_preprocessing_net.<backbone key>`` exactly as the reference
     does (train_eval_pose_est.py:59-66, pose_estimation/train.py:226).  Only the instance attribute ``forward_features`` is
     installed: no-grad inference on a GPU tensor goes through the HIP kernels (the handle is rebuilt when a parameter moves or
     changes in place); with autograd enabled on a trainable backbone, with token masks or list inputs the module's own torch
-    forward runs.  ``restore_stock(module)`` removes it."""
+    forward runs.  ``precision``: see ``ViTHandle`` ("fp32": the reference's accuracy class, the default; "bf16": throughput).
+    ``restore_stock(module)`` removes it."""
+    if precision not in PRECISIONS:
+        raise RuntimeError(f"precision must be one of {sorted(PRECISIONS)} (got {precision!r})")
     if not hasattr(type(module), "forward_features"):
         raise RuntimeError(f"{type(module).__name__} has no forward_features: not a DINOv2-style backbone")
     restore_stock(module)
-    object.__setattr__(module, "forward_features", _NativeForwardFeatures(module, grid, patch))
+    object.__setattr__(module, "forward_features", _NativeForwardFeatures(module, grid, patch, precision))
     return module
 
 

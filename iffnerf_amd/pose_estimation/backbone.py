@@ -14,13 +14,14 @@ def create_backbone(type="dino", pretrained=False, filter_size=4, pool_only=True
     ``state_dict`` keys, so ``IdentificationModule.state_dict()`` carries ``image_preprocessing_net.<dinov2 key>`` and a
     reference-trained ``id_module.th`` strict-loads (train_eval_pose_est.py:59-66).  ``hip_vit.serve_natively`` installs the
     native ``forward_features`` on that module (no-grad inference through ``iff_vit_forward``; everything else is the module's
-    own torch code); ``native=False`` in ``kwargs`` leaves the module untouched, exactly as the reference returns it."""
+    own torch code) in the reference's fp32 accuracy class (``precision="bf16"`` in ``kwargs``: bf16 operands, a throughput
+    option); ``native=False`` in ``kwargs`` leaves the module untouched, exactly as the reference returns it."""
     if type != "dino":
         raise RuntimeError("only the 'dino' backbone exists in the reference (backbone.py:11-14)")
     model = _hub_load("facebookresearch/dinov2", "dinov2_vits14")
     if kwargs.get("native", True):
         from ..hip_vit import serve_natively
-        model = serve_natively(model, (16, 16), 14)
+        model = serve_natively(model, (16, 16), 14, precision=kwargs.get("precision", "fp32"))
     return model, (16, 16), 384
 
 
@@ -121,10 +122,10 @@ class SeededViTS14(torch.nn.Module):
         return self.head(self.forward_features(x)["x_norm_clstoken"])
 
 
-def create_standin_backbone(seed: int = 0, native: bool = False):
+def create_standin_backbone(seed: int = 0, native: bool = False, precision: str = "fp32"):
     """(module, (16, 16), 384) like ``create_backbone("dino")``, without the network.  ``native``: ``hip_vit.serve_natively`` applied."""
     m = SeededViTS14(seed).eval()
     if native:
         from ..hip_vit import serve_natively
-        m = serve_natively(m, (16, 16), 14)
+        m = serve_natively(m, (16, 16), 14, precision=precision)
     return m, (16, 16), 384

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 8
+#define IFF_ABI_VERSION 9
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -122,6 +122,10 @@ int iff_field_load(const char* path, void* stream, iff_field** out);
 int iff_normalize_coord(const iff_field* f, const float* xyz, int64_t n, float* out, void* stream);
 /* AlphaGridMask.sample_alpha, models/tensorBase.py:66-72.  xyz [n,3] world -> value [n] */
 int iff_mask_sample(const iff_field* f, const float* xyz, int64_t n, float* out, void* stream);
+/* `AlphaGridMask.sample_alpha(xyz) > 0` -- the only use the path makes of the occupancy lookup (compute_alpha
+ * models/tensorBase.py:762-764, forward :830-833; the surface sampler reaches it through compute_alpha) -- from the corner-bit
+ * table of the handle: one byte per point, exactly the truth value of the trilinear sum.  xyz [n,3] world -> flag [n] uint8 */
+int iff_mask_occupied(const iff_field* f, const float* xyz, int64_t n, uint8_t* out, void* stream);
 /* TensorVMSplit.compute_densityfeature, models/tensoRF.py:216-235.  xn [n,3] normalised -> [n] */
 int iff_density_feature(const iff_field* f, const float* xn, int64_t n, float* out, void* stream);
 /* TensorVMSplit.compute_appfeature, models/tensoRF.py:237-256.  xn [n,3] normalised -> [n,app_dim] */
@@ -348,7 +352,15 @@ typedef struct iff_vit_desc {
     const float* fc2_w;    const float* fc2_b;        /* blocks.*.mlp.fc2                [depth, dim, mlp], [depth, dim] */
     const float* ls2;                                 /* blocks.*.ls2.gamma */
     const float* norm_w;   const float* norm_b;       /* norm.{weight,bias} [dim] */
+    int32_t precision;                                /* IFF_VIT_FP32 / IFF_VIT_BF16 below */
 } iff_vit_desc;
+/* Arithmetic of the backbone's matrix products.  The reference runs DINOv2 in fp32 (pose_estimation/identification_module.py:137-142,
+ * backbone.py:12-14); IFF_VIT_FP32 is that accuracy class on the fp16 matrix cores: every operand split exactly into two fp16
+ * pieces (22 significant bits), three MFMA products per block, fp32 accumulation -- tokens agree with the fp32 torch module to
+ * ~1e-5 relative.  IFF_VIT_BF16 rounds the operands to bf16 (8 significant bits: ~1e-2 relative on the tokens) and is ~2x
+ * faster: a throughput option, never the default of the drop-in. */
+#define IFF_VIT_FP32 0
+#define IFF_VIT_BF16 1
 /* builds the handle from the parameters of torch.hub's dinov2_vits14 (pose_estimation/backbone.py:12-14) */
 int  iff_vit_create(const iff_vit_desc* desc, void* stream, iff_vit** out);
 void iff_vit_destroy(iff_vit* vit);

@@ -2,12 +2,10 @@
 # A/B of pre-built libraries on one box: bash scripts/gpu_ab.sh build/lib_x.so [build/lib_y.so ...]; each is timed with scripts/time_march.py
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-cp iffnerf_amd/libiffnerf_hip.so /tmp/lib_keep.so
 for rep in 1 2; do
 for lib in base "$@"; do
-  if [ "$lib" = base ]; then cp /tmp/lib_keep.so iffnerf_amd/libiffnerf_hip.so; else cp "$lib" iffnerf_amd/libiffnerf_hip.so; fi
+  if [ "$lib" = base ]; then unset IFF_LIB_PATH; else export IFF_LIB_PATH="$PWD/$lib"; fi      # never copied over the product library
   echo "== $lib"
   IFF_MARCH_FAN=${FAN:-2} timeout -k 10 300 python scripts/time_march.py ${CFG:-lego16k} 2>/dev/null
 done
 done
-cp /tmp/lib_keep.so iffnerf_amd/libiffnerf_hip.so

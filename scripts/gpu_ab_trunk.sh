@@ -1,9 +1,7 @@
 #!/bin/bash
 set -u
 cd "$GRAFT_REPO_ROOT"
-cp iffnerf_amd/libiffnerf_hip.so /tmp/lib_keep.so
 for lib in base "$@"; do
-  if [ "$lib" = base ]; then cp /tmp/lib_keep.so iffnerf_amd/libiffnerf_hip.so; else cp "$lib" iffnerf_amd/libiffnerf_hip.so; fi
+  if [ "$lib" = base ]; then unset IFF_LIB_PATH; else export IFF_LIB_PATH="$PWD/$lib"; fi      # never copied over the product library
   echo "== $lib"; timeout -k 10 300 python scripts/ab_trunk.py 2>/dev/null | tail -2
 done
-cp /tmp/lib_keep.so iffnerf_amd/libiffnerf_hip.so

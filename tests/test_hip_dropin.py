@@ -240,6 +240,69 @@ def test_concurrent_captured_steps_reproduce_the_eager_path(dev, config, rounds)
             assert torch.equal(idx, g.idx) and torch.equal(val, g.val) and torch.equal(c2w, g.c2w), (r, i, float((val - g.val).abs().max()))
 
 
+@pytest.mark.parametrize("config,rounds", [("truck32k", 150), ("lego16k", 100)])
+def test_concurrent_stage_outputs_reproduce_the_eager_kernels(dev, config, rounds):
+    """The stage-level form of the check above (what found the packed-fp32 fault: scripts/replay_vs_eager_stages.py ONLY=trunk): four
+    captured graphs in flight, each the cold emission of a batch (sampler, normals, emit, the fan march) FOLLOWED BY the trunk launch
+    on static rays, so that the tail of every march runs next to another graph's fp16-MFMA workgroups; after every round each graph's
+    ray colours, depth, opacity and its logits are recomputed eagerly from the graph's OWN surface samples and compared bit for bit.
+    A final pose or a top-100 list can hide a colour that is off by 1e-3 -- this cannot.  600 / 400 steps: the compiler's packed
+    fp32 build showed 14 events per 2 000."""
+    from iffnerf_amd.hip_field import isocell_emit
+    from iffnerf_amd.pipeline import PosePipeline
+    wl = synthetic.WORKLOADS[config]
+    pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(config), synthetic.make_id_weights(seed=99), dev)
+    B, P = wl["queries"], wl["gen_points"]
+    tokens = torch.stack([synthetic.make_tokens(256, 384, seed=7 + q) for q in range(B)]).to(dev)
+    M, C = tokens.shape[1:]
+    o0, d0, c0 = pipe.emit(P, seed=5)
+    static = [x.repeat(B, 1).contiguous() for x in (o0, d0, c0)]
+    qf = pipe.idnet.q_fold(tokens.reshape(B * M, C))
+
+    def emit(samples):
+        normals = pipe.field.point_normals(samples)
+        ori, dirs, rays = isocell_emit(pipe.cells, samples, normals, want_rays6=True)
+        rgb, depth, acc = pipe.field.march(rays, 0, 20, want_alpha=False)[:3]
+        return {"ori": ori, "dirs": dirs, "rgb": rgb, "depth": depth, "acc": acc}
+
+    def step(seed, counter):
+        samples, _, _ = pipe.field.surface_sample_batched(B, P, pipe.rho, n_epochs=4, max_iterations=200, seed=seed, seed_offset=counter)
+        out = emit(samples.reshape(B * P, 3))
+        out["samples"] = samples
+        out["logits"] = pipe.idnet.ray_logits_folded_batched(qf, static[0], static[1], static[2], B)[0]
+        return out
+
+    logits_ref = pipe.idnet.ray_logits_folded_batched(qf, static[0], static[1], static[2], B)[0].clone()
+    graphs = []
+    for i in range(4):
+        counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step(1000 + 7919 * i, counter)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            counter += 1
+            out = step(1000 + 7919 * i, counter)
+        graphs.append((g, out))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    torch.cuda.synchronize(dev)
+    for r in range(rounds):
+        for _ in range(3):
+            for i, (g, _) in enumerate(graphs):
+                with torch.cuda.stream(streams[i]):
+                    g.replay()
+        torch.cuda.synchronize(dev)
+        for i, (_, out) in enumerate(graphs):
+            eager = emit(out["samples"].reshape(B * P, 3))
+            for k, v in eager.items():
+                assert torch.equal(v.nan_to_num(7.0), out[k].nan_to_num(7.0)), (r, i, k, int((v != out[k]).sum()), float((v - out[k]).abs().nan_to_num(0.0).max()))
+            assert torch.equal(out["logits"], logits_ref), (r, i, "logits")
+
+
 def test_concurrent_warm_and_image_graphs_reproduce_the_eager_path(dev):
     """The other two graph forms of the bench -- a batch of query images against resident rays, and image in -> pose out (resize /
     crop, native ViT-S/14, token assembly, stage C) -- replayed four at a time: every replay equals the same call run eagerly."""

@@ -57,6 +57,40 @@ def test_g1_point_lookups(golden, tiny, dev):
     close(tiny.point_alpha(x, float(g["step_size"])), g["alpha_len_step"], TOL_ALPHA, 2e-6, "alpha(length=step)")
 
 
+def test_corner_bit_occupancy_is_the_sign_of_the_trilinear_value(golden, tiny, small, dev):
+    """iff_mask_occupied (one byte of the corner-bit table: what the march, compute_alpha and the sampler branch on) against
+    `sample_alpha(xyz) > 0` -- the reference's own values (G1) and iff_mask_sample's trilinear sum -- on the points where the two
+    formulations could part: coordinates exactly ON mask texels (a zero high-corner weight), on faces / edges / corners of the
+    volume, up to two texels outside it, NaN and infinities; and on random points around an occupancy boundary."""
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    x = golden.t("g1_field_points", "xyz").to(dev)
+    assert np.array_equal(tiny.mask_occupied(x).cpu().numpy(), golden["g1_field_points"]["mask_value"] > 0)
+    for h, ck in ((tiny, util.ckpt("tiny")), (small, util.ckpt("small")),
+                  (field_handle_from_ckpt(util.ckpt("tiny", contraction_type="unisphere", density_shift=0.0, peak=6.0), dev), None)):
+        ck = ck or util.ckpt("tiny", contraction_type="unisphere", density_shift=0.0, peak=6.0)
+        lo, hi = ck["alphaMask.aabb"][0].double(), ck["alphaMask.aabb"][1].double()
+        D, H, W = [int(v) for v in tuple(ck["alphaMask.shape"])[-3:]]
+        gen = torch.Generator().manual_seed(77)
+        pts = []
+        # lattice: every texel coordinate of the mask (and half-way points, and one / two texels outside) on every axis
+        ax = [torch.cat((torch.arange(-2, n + 2).double(), torch.arange(-1, n).double() + 0.5)) / max(n - 1, 1) for n in (W, H, D)]
+        gx, gy, gz = torch.meshgrid(ax[0][::2], ax[1][::3], ax[2][::2], indexing="ij")
+        pts.append(torch.stack((gx, gy, gz), -1).reshape(-1, 3) * (hi - lo) + lo)
+        gx, gy, gz = torch.meshgrid(ax[0][1::3], ax[1][::2], ax[2][1::2], indexing="ij")
+        pts.append(torch.stack((gx, gy, gz), -1).reshape(-1, 3) * (hi - lo) + lo)
+        pts.append(lo + (hi - lo) * (torch.rand(20000, 3, generator=gen).double() * 1.3 - 0.15))
+        p = torch.cat(pts).float()
+        p[:6] = torch.tensor([[float("nan"), 0, 0], [0, float("inf"), 0], [0, 0, -float("inf")], [1e30, 0, 0], [0, -1e30, 0],
+                              [float("nan")] * 3])
+        p = p.to(dev)
+        val = h.mask_sample(p)
+        occ = h.mask_occupied(p)
+        assert torch.equal(occ, val > 0), int((occ != (val > 0)).sum())
+        assert 0.05 < float(occ.float().mean()) < 0.95           # both outcomes are exercised
+        on_texel = int(((val > 0) & (val < 1e-6)).sum()) + int((val == 0).sum())
+        assert on_texel > 100
+
+
 def test_g11_unisphere(golden, dev):
     from iffnerf_amd.hip_field import field_handle_from_ckpt
     g = golden["g11_unisphere"]

@@ -145,11 +145,13 @@ def test_image_in_pose_out_capture(dev, monkeypatch):
 
 
 def test_native_vit_matches_the_fp32_torch_module(dev):
-    """iff_vit_forward (bf16 MFMA, fp32 accumulate / residual / LayerNorm / softmax) against the fp32 torch module of the same
-    weights: DINOv2 ViT-S/14's architecture with seeded stand-in weights (the real ones are not available offline; both state-dict
-    key schemes are understood by ViTHandle).  Token features agree to bf16-operand tolerance, and stage C fed with either token
-    set picks the same rays."""
-    from iffnerf_amd import hip_identify as H
+    """iff_vit_forward against the fp32 torch module of the same weights: DINOv2 ViT-S/14's architecture with seeded stand-in weights
+    (the published ones are not available offline; both state-dict key schemes are understood by ViTHandle).
+    Default precision (IFF_VIT_FP32: split fp16 operands, three products per block, fp32 accumulate / residual / LayerNorm / softmax):
+    the reference's accuracy class (identification_module.py:137-142 runs the backbone in fp32) -- tokens to 1e-4 of the largest
+    token value, and stage C fed with either token set returns the SAME top-100 list (tests/util.py assert_topk_matches: only
+    near-ties of the fp32 scores may swap).  precision="bf16" (the throughput option): bf16-operand tolerance."""
+    from oracle import identify as oid
     from iffnerf_amd.hip_vit import ViTHandle, is_served_natively, restore_stock, serve_natively
     from iffnerf_amd.image_frontend import token_assemble
     from iffnerf_amd.pipeline import PosePipeline
@@ -161,15 +163,27 @@ def test_native_vit_matches_the_fp32_torch_module(dev):
         x = torch.randn(Q, 3, 224, 224, generator=gen).to(dev)
         with torch.no_grad():
             want = net.forward_features(x)
+        ref, scale = want["x_norm_patchtokens"], float(want["x_norm_patchtokens"].abs().max())
+        # an fp64 evaluation of the same module says how far fp32 torch itself is from the exact tokens
+        with torch.no_grad():
+            exact = net.double().forward_features(x.double())["x_norm_patchtokens"]
+            net.float()
+        torch_err = float((ref.double() - exact).abs().max())
         vit = ViTHandle(net.state_dict(), dev)
+        assert vit.precision == "fp32"
         tok, cls = vit.forward(x, want_cls=True)
         assert tok.shape == (Q, 256, 384) and cls.shape == (Q, 384)
-        ref, scale = want["x_norm_patchtokens"], float(want["x_norm_patchtokens"].abs().max())
         err = float((tok - ref).abs().max())
-        cos = torch.nn.functional.cosine_similarity(tok.reshape(-1, 384), ref.reshape(-1, 384), dim=-1)
-        assert torch.isfinite(tok).all() and err <= 4e-2 * scale, (err, scale)           # bf16 operands: ~2^-8 per product, 12 blocks
-        assert float(cos.min()) > 0.9995
-        assert float((cls - want["x_norm_clstoken"]).abs().max()) <= 4e-2 * scale
+        err_exact = float((tok.double() - exact).abs().max())
+        assert torch.isfinite(tok).all() and err <= 1e-4 * scale, (err, scale)
+        assert err_exact <= max(4.0 * torch_err, 2e-5 * scale), (err_exact, torch_err)       # as close to the exact tokens as fp32 torch is
+        assert float((cls - want["x_norm_clstoken"]).abs().max()) <= 1e-4 * scale
+        fast = ViTHandle(net.state_dict(), dev, precision="bf16")
+        tok_b, cls_b = fast.forward(x, want_cls=True)
+        err_b = float((tok_b - ref).abs().max())
+        cos = torch.nn.functional.cosine_similarity(tok_b.reshape(-1, 384), ref.reshape(-1, 384), dim=-1)
+        assert torch.isfinite(tok_b).all() and err_b <= 4e-2 * scale and float(cos.min()) > 0.9995, (err_b, scale)     # bf16 operands: ~2^-8 per product, 12 blocks
+        assert err < 0.02 * err_b
         # the compact key names of earlier table files load too (qkv / ls1 / fc1 without attn. / .gamma / mlp.) and give the same bits
         sd = {}
         for k, v in net.state_dict().items():
@@ -195,16 +209,19 @@ def test_native_vit_matches_the_fp32_torch_module(dev):
         net.norm.weight.mul_(0.5)
     assert not torch.equal(out2["x_norm_patchtokens"], tok)
     assert restore_stock(net) is net and not is_served_natively(net) and "forward_features" not in net.__dict__
-    # stage C on the golden-size ray set: tokens from either backbone select (nearly) the same top-100 rays
+    # stage C on the golden-size ray set: the native fp32-class tokens select the top-100 LIST the fp32 torch tokens select
     pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
     ori, dirs, rgb = pipe.emit(300, seed=9)
+    w = synthetic.make_id_weights(seed=99)
     for q in range(min(Q, 3)):
         ta, _ = token_assemble(tok[q:q + 1], grid)
         tb, _ = token_assemble(ref[q:q + 1].contiguous(), grid)
+        tc, _ = token_assemble(tok_b[q:q + 1], grid)
         _, ia, _ = pipe.identify(ta[0], ori, dirs, rgb, k=100, materialize_map=False)
-        _, ib, _ = pipe.identify(tb[0], ori, dirs, rgb, k=100, materialize_map=False)
-        overlap = len(set(ia.tolist()) & set(ib.tolist()))
-        assert overlap >= 90, overlap
+        score_ref = oid.test_image(w, tb[0].cpu(), ori.cpu(), dirs.cpu(), rgb.cpu(), 100)[2]        # the oracle on the fp32 torch tokens
+        assert util.assert_topk_matches(ia.cpu(), score_ref, 100, rel_tie=1e-4) <= 4          # token differences of 1e-5 move scores by as much
+        _, ic, _ = pipe.identify(tc[0], ori, dirs, rgb, k=100, materialize_map=False)
+        assert len(set(ic.tolist()) & set(ia.tolist())) >= 90                                    # the bf16 option: most of the same rays
     with pytest.raises(RuntimeError):
         vit.forward(x.cpu())
     with pytest.raises(RuntimeError):

@@ -94,12 +94,12 @@ def test_field_from_file_is_the_same_handle(golden, tmp_path):
         FieldHandle.from_file(corrupt("tail.ifft", [], tail=b"\0" * 8), dev)
     with pytest.raises(RuntimeError):                                             # a slab size the file cannot hold
         FieldHandle.from_file(corrupt("huge.ifft", [(24, "<Q", 1 << 39)]), dev)
-    # the descriptor starts with the 12 table pointers (stored as offset + 1), then basis x 3, mask, head, then grid[3]
+    # the descriptor starts with the 12 table pointers (stored as offset + 1), then basis x 3, mask, cell, head, then grid[3]
     with pytest.raises(RuntimeError, match="do not match"):
         FieldHandle.from_file(corrupt("ptr.ifft", [(64 + 8, "<Q", slab_bytes + 4096)]), dev)
     with pytest.raises(RuntimeError, match="do not match"):
         FieldHandle.from_file(corrupt("ptr2.ifft", [(64, "<Q", 257)]), dev)     # inside the slab, but not where the table is
-    grid_off = 64 + 8 * 17
+    grid_off = 64 + 8 * 18
     assert struct.unpack_from("<3i", data, grid_off) == tuple(util.SMALL["grid"])
     with pytest.raises(RuntimeError, match="do not match|out of range"):
         FieldHandle.from_file(corrupt("grid.ifft", [(grid_off, "<i", util.SMALL["grid"][0] + 1)]), dev)
