@@ -281,6 +281,26 @@ def main():
         if not torch.equal(eager, g.c2w):
             raise SystemExit("bench: a replayed step does not reproduce the eager path on the same seed")
     queries_per_step = B if shared else B * world_size
+    # each all_gather of a step alone, on this step's own message buffers (every rank takes part; rank 0 reports): the latency a
+    # step pays per exchange when nothing overlaps it
+    collective_us = None
+    if sharded:
+        from iffnerf_amd import distributed as D
+        g0 = graphs[0]
+        pairs = [(n, getattr(g0, n + "_all"), getattr(g0, n)) for n in ("msg", "stats", "cand") if hasattr(g0, n + "_all")]
+        collective_us = {}
+        for name, dst, src in pairs:
+            for _ in range(5):
+                D.all_gather_into(dst, src, g0.group)
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                D.all_gather_into(dst, src, g0.group)
+            e1.record()
+            torch.cuda.synchronize(device)
+            label = {"msg": "points_and_folded_queries", "stats": "row_statistics", "cand": "candidates"}[name]
+            collective_us[label] = {"us": round(e0.elapsed_time(e1) * 1e3 / 20, 1), "bytes_per_rank": int(src.numel() * src.element_size())}
 
     result = None
     if rank == 0:
@@ -301,6 +321,7 @@ def main():
         if sharded:      # what the process group itself reports (the collectives really ran over this many ranks of this backend)
             result["config"]["rccl_world_size"] = dist.get_world_size()
             result["config"]["collective_backend"] = dist.get_backend()
+            result["config"]["collective_us"] = collective_us
         if not args.no_instrument:
             instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, rank, device)
         if world_size == 1 and not args.no_cpu_baseline:

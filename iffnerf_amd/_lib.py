@@ -70,6 +70,9 @@ SIGNATURES = {
     "iff_normalize_coord": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_mask_sample": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_mask_occupied": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "iff_merge_row_stats": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP]),
+    "iff_pack_candidates": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _I64, _VP, _VP]),
+    "iff_merge_candidates": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP]),
     "iff_density_feature": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_app_feature": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "iff_point_alpha": (C.c_int, [_VP, _VP, _I64, _F, _VP, _VP]),

@@ -913,6 +913,32 @@ extern "C" int iff_pose_from_topk_batched(const int64_t* idx, const float* val, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ ray-sharded merges
+extern "C" int iff_merge_row_stats(const float* stats_all, int32_t G, int64_t R, float* gmax, float* gsum, void* stream) {
+    IFF_REQUIRE(G >= 1 && R >= 0, "iff_merge_row_stats: bad argument");
+    if (R == 0) return 0;
+    IFF_REQUIRE(stats_all && gmax && gsum, "iff_merge_row_stats: null buffer");
+    IFF_HIP(launch_merge_row_stats(stats_all, G, R, gmax, gsum, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_pack_candidates(const int64_t* idx, const float* val, const float* rays_o, const float* rays_d, int64_t ray_stride, int32_t Q,
+                                   int32_t kl, int32_t k, int64_t first_ray, float* msg, void* stream) {
+    IFF_REQUIRE(Q >= 0 && kl >= 0 && k >= 1 && kl <= k && ray_stride >= 0 && first_ray >= 0, "iff_pack_candidates: bad argument");
+    if (Q == 0) return 0;
+    IFF_REQUIRE(msg && (kl == 0 || (idx && val && rays_o && rays_d)), "iff_pack_candidates: null buffer");
+    IFF_HIP(launch_pack_candidates(idx, val, rays_o, rays_d, ray_stride, Q, kl, k, first_ray, msg, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_merge_candidates(const float* cand_all, int32_t G, int32_t Qt, int32_t q0, int32_t Q, int32_t k, float* val, int64_t* idx,
+                                    float* rays_o_out, float* rays_d_out, void* stream) {
+    IFF_REQUIRE(G >= 1 && Qt >= 0 && q0 >= 0 && Q >= 0 && q0 + Q <= Qt && k >= 1, "iff_merge_candidates: bad argument");
+    IFF_REQUIRE((int64_t)G * k * 8 <= 64 * 1024, "iff_merge_candidates: %d lists of %d candidates exceed the 8192 a workgroup merges", G, k);
+    if (Q == 0) return 0;
+    IFF_REQUIRE(cand_all && val && idx && rays_o_out && rays_d_out, "iff_merge_candidates: null buffer");
+    IFF_HIP(launch_merge_candidates(cand_all, G, Qt, q0, Q, k, val, idx, rays_o_out, rays_d_out, (hipStream_t)stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ table files
 // A handle's slab (tables already in kernel layout) written to / read from one file, so that a serving process skips the
 // reference-layout checkpoint and the K0 re-layout (models/tensorBase.py:424-458 is the reference's on-disk format; this is

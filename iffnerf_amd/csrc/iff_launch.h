@@ -121,6 +121,13 @@ size_t topk_workspace_bytes(int64_t N, int k);
 hipError_t launch_topk(const float* score, int Q, int64_t N, int k, int64_t* idx, float* val, void* ws, size_t ws_bytes,
                        hipStream_t s);
 
+// shard_kernels.hip -- merges of the ray-sharded path
+hipError_t launch_merge_row_stats(const float* stats_all, int G, int64_t R, float* gmax, float* gsum, hipStream_t s);
+hipError_t launch_pack_candidates(const int64_t* idx, const float* val, const float* ori, const float* dirs, int64_t ray_stride, int Q, int kl,
+                                  int k, int64_t first_ray, float* msg, hipStream_t s);
+hipError_t launch_merge_candidates(const float* cand_all, int G, int Qt, int q0, int Q, int k, float* val, int64_t* idx, float* ori, float* dir,
+                                   hipStream_t s);
+
 // pose_kernels.hip
 hipError_t launch_pose(const int64_t* idx, const float* val, int Q, int k, const float* rays_o, const float* rays_d, int64_t N,
                        int64_t ray_batch_stride, const float* up3, float* c2w, float* parts, hipStream_t s);

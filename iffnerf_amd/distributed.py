@@ -15,9 +15,13 @@ exchange in front: each rank draws the surface points of its own B queries (the 
 folds its own B token blocks, and one ``all_gather`` of [B*P*3 + B*M*272] floats per rank (4.5 MB at B = 16) hands every
 rank the points and folded queries of all G*B queries, of which it then emits, marches and encodes its block.
 
-The messages are a few KB to a few MB: latency-bound, no bandwidth tuning needed.  The functions below contain only the exchange
-and merge logic on small tensors and are device-agnostic, so the world_size-2 ``gloo`` tests on CPU exercise the very
-code the GPU ranks run; the heavy local work is passed in by the caller (HIP on the GPU, the oracle in those tests).
+The messages are a few KB to a few MB: latency-bound, no bandwidth tuning needed.  This module holds the exchange itself
+(``all_gather_into`` over RCCL) and, as plain torch ops on small tensors, the STATEMENT of the merge arithmetic
+(``merge_row_stats_gathered``, ``merge_topk_gathered``, ``pack_candidates``): device-agnostic, so the world_size-2 ``gloo``
+tests on CPU check the exchange logic with the oracle as the local work.  On the GPU the pipeline runs each merge as ONE HIP
+launch inside its captured segments (``iff_merge_row_stats``, ``iff_pack_candidates``, ``iff_merge_candidates``:
+csrc/shard_kernels.hip, hip_identify.merge_* -- tests/test_hip_sharded.py holds them equal to the statements below), so between
+two collectives nothing runs on the host but the collective's own issue.
 """
 from __future__ import annotations
 

@@ -386,6 +386,54 @@ def topk_batched(score: torch.Tensor, k: int):
     return idx, val
 
 
+# ---------------------------------------------------------------------------------------------- merges of the ray-sharded path
+def merge_row_stats(stats_all: torch.Tensor):
+    """stats_all [G, R, 2] (every rank's per-row (max, sum-exp), rank order; what an all_gather delivers) -> (gmax [R], gsum [R])
+    over all columns -- ``iff_merge_row_stats``, one launch (distributed.merge_row_stats_gathered states the arithmetic)."""
+    st = _gpu(stats_all, "row statistics")
+    if st.dim() != 3 or st.shape[-1] != 2:
+        raise RuntimeError("stats_all must be [G, R, 2]")
+    G, R = st.shape[:2]
+    gmax, gsum = st.new_empty(R), st.new_empty(R)
+    with torch.cuda.device(st.device):
+        check(_lib.lib().iff_merge_row_stats(dptr(st), G, R, dptr(gmax), dptr(gsum), stream_ptr(st.device)), "iff_merge_row_stats")
+    return gmax, gsum
+
+
+def pack_candidates(idx: torch.Tensor, val: torch.Tensor, rays_o: torch.Tensor, rays_d: torch.Tensor, k: int, first_ray: int):
+    """A rank's local top-kl (idx, val [Q, kl]) + its rays ([n, 3] shared or [Q, n, 3] per query) -> the message [Q, k, 8]
+    (score, global ray index bits, origin, direction; slots kl.. pad with -inf / 2^31 - 1) -- ``iff_pack_candidates``."""
+    idx = idx.detach().to(torch.int64).contiguous()
+    val = _gpu(val, "scores")
+    o, d = _gpu(rays_o, "rays"), _gpu(rays_d, "rays")
+    Q, kl = idx.shape
+    if o.shape != d.shape or o.shape[-1] != 3 or o.dim() not in (2, 3) or (o.dim() == 3 and o.shape[0] != Q) or kl > k:
+        raise RuntimeError("rays must both be [n,3] or [Q,n,3], and kl <= k")
+    stride = 0 if o.dim() == 2 else o.shape[1] * 3
+    msg = val.new_empty(Q, k, 8)
+    with torch.cuda.device(val.device):
+        check(_lib.lib().iff_pack_candidates(dptr(idx, torch.int64), dptr(val), dptr(o), dptr(d), stride, Q, kl, k, int(first_ray), dptr(msg),
+                                             stream_ptr(val.device)), "iff_pack_candidates")
+    return msg
+
+
+def merge_candidates(cand_all: torch.Tensor, k: int, q0: int = 0, n_queries=None):
+    """cand_all [G, Qt, k, 8] (every rank's message) -> the global top-k of queries q0 .. q0 + Q - 1 in torch.topk's order:
+    (val [Q, k], idx [Q, k] int64 global, origins [Q, k, 3], directions [Q, k, 3]) -- ``iff_merge_candidates``."""
+    c = _gpu(cand_all, "candidates")
+    if c.dim() != 4 or c.shape[2] != k or c.shape[3] != 8:
+        raise RuntimeError(f"cand_all must be [G, Qt, {k}, 8]")
+    G, Qt = c.shape[:2]
+    Q = Qt - q0 if n_queries is None else int(n_queries)
+    val = c.new_empty(Q, k)
+    idx = torch.empty(Q, k, dtype=torch.int64, device=c.device)
+    ori, dirs = c.new_empty(Q, k, 3), c.new_empty(Q, k, 3)
+    with torch.cuda.device(c.device):
+        check(_lib.lib().iff_merge_candidates(dptr(c), G, Qt, int(q0), Q, k, dptr(val), dptr(idx, torch.int64), dptr(ori), dptr(dirs),
+                                              stream_ptr(c.device)), "iff_merge_candidates")
+    return val, idx, ori, dirs
+
+
 def pose_from_topk_batched(idx, val, rays_o, rays_d, model_up):
     """idx, val [Q, k]; rays_o / rays_d either one shared ray set [N, 3] or per-query candidates [Q, n, 3] -> c2w [Q, 4, 4]."""
     idx = idx.detach().to(torch.int64).contiguous()

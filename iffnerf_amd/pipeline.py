@@ -206,27 +206,23 @@ class PosePipeline:
     def shard_local_candidates(self, logits, stats_all, ori, dirs, Q: int, k: int, first_ray: int, materialize_map: bool = False):
         """Segment 2: global statistics -> this rank's score columns -> its top-k candidates per query, packed as one
         message [Q, k, 8] = (score, global ray index bits, origin, direction); unfilled slots hold -inf / 2^31-1."""
-        from . import distributed as D
-        gmax, gsum = D.merge_row_stats_gathered(stats_all)
-        score = H.attn_colsum_batched(logits, gmax.contiguous(), gsum.contiguous(), Q, write_attention=materialize_map)
-        n_local = ori.shape[0]
-        kl = min(k, n_local)
-        i, v = H.topk_batched(score, kl)
-        lval = ori.new_full((Q, k), float("-inf"))
-        lidx = torch.full((Q, k), 2 ** 31 - 1, dtype=torch.int64, device=ori.device)
-        pay = ori.new_zeros(Q, k, 6)
-        lval[:, :kl], lidx[:, :kl] = v, i + first_ray
-        pay[:, :kl, :3], pay[:, :kl, 3:] = ori[i], dirs[i]
-        return D.pack_candidates(lval, lidx, pay)
+        gmax, gsum = H.merge_row_stats(stats_all)                        # one launch (iff_merge_row_stats)
+        score = H.attn_colsum_batched(logits, gmax, gsum, Q, write_attention=materialize_map)
+        i, v = H.topk_batched(score, min(k, ori.shape[0]))
+        return H.pack_candidates(i, v, ori, dirs, k, first_ray)          # one launch (iff_pack_candidates)
 
-    def shard_global_poses(self, cand_all, k: int):
-        """Segment 3: every rank's candidates [G, Q, k, 8] -> (poses [Q,4,4], val [Q,k], global ray idx [Q,k])."""
-        from . import distributed as D
-        vals, idxs, pays = D.unpack_candidates(cand_all)
-        val, idx, pay = D.merge_topk_gathered(vals, idxs, pays, k)
+    def shard_global_poses(self, cand_all, k: int, q0: int = 0, n_queries=None):
+        """Segment 3: every rank's candidates [G, Qt, k, 8] -> (poses [Q,4,4], val [Q,k], global ray idx [Q,k]) of the queries
+        q0 .. q0 + Q - 1 (default: all Qt)."""
+        val, idx, wo, wd = H.merge_candidates(cand_all, k, q0, n_queries)        # one launch (iff_merge_candidates)
         Q = val.shape[0]
-        ar = torch.arange(k, device=val.device).expand(Q, k).contiguous()
-        poses = H.pose_from_topk_batched(ar, val.contiguous(), pay[..., :3].contiguous(), pay[..., 3:].contiguous(), self.model_up)
+        # the winners arrive gathered: candidate j of a query IS row j.  One index tensor per shape, kept for the pipeline's lifetime
+        # (captured graphs hold its address)
+        cache = self.__dict__.setdefault("_arange_cache", {})
+        key = (Q, k, str(val.device))
+        if key not in cache:
+            cache[key] = torch.arange(k, device=val.device).expand(Q, k).contiguous()
+        poses = H.pose_from_topk_batched(cache[key], val, wo, wd, self.model_up)
         return poses, val, idx
 
     def query_sharded(self, tokens, gen_points: int, seed: int, k: int = 100, group=None, materialize_map: bool = False):
@@ -278,24 +274,15 @@ class PosePipeline:
     def batch_shard_local_candidates(self, logits, stats_all, ori, dirs, QT: int, k: int, first_ray: int):
         """Segment 3: global statistics -> this rank's score columns -> its top-k candidates of every query [QT, k, 8]
         (as ``shard_local_candidates``, with one ray set per query)."""
-        from . import distributed as D
-        gmax, gsum = D.merge_row_stats_gathered(stats_all)
-        score = H.attn_colsum_batched(logits, gmax.contiguous(), gsum.contiguous(), QT, write_attention=False)
+        gmax, gsum = H.merge_row_stats(stats_all)
+        score = H.attn_colsum_batched(logits, gmax, gsum, QT, write_attention=False)
         n_local = score.shape[1]
-        kl = min(k, n_local)
-        i, v = H.topk_batched(score, kl)
-        gi = i[..., None].expand(-1, -1, 3)
-        lval = ori.new_full((QT, k), float("-inf"))
-        lidx = torch.full((QT, k), 2 ** 31 - 1, dtype=torch.int64, device=ori.device)
-        pay = ori.new_zeros(QT, k, 6)
-        lval[:, :kl], lidx[:, :kl] = v, i + first_ray
-        pay[:, :kl, :3] = torch.gather(ori.view(QT, n_local, 3), 1, gi)
-        pay[:, :kl, 3:] = torch.gather(dirs.view(QT, n_local, 3), 1, gi)
-        return D.pack_candidates(lval, lidx, pay)
+        i, v = H.topk_batched(score, min(k, n_local))
+        return H.pack_candidates(i, v, ori.view(QT, n_local, 3), dirs.view(QT, n_local, 3), k, first_ray)
 
     def batch_shard_global_poses(self, cand_all, k: int, rank: int, B: int):
         """Segment 4: every rank's candidates [G, G*B, k, 8] -> the poses of THIS rank's B queries (poses [B,4,4], val, idx)."""
-        return self.shard_global_poses(cand_all[:, rank * B:(rank + 1) * B].contiguous(), k)
+        return self.shard_global_poses(cand_all, k, rank * B, B)
 
     def query_batch_sharded(self, tokens_local, gen_points: int, seed: int, k: int = 100, group=None, seed_offset=None):
         """``tokens_local`` [B,M,C]: this rank's B cold queries.  Every rank returns the poses / top-k of its own queries;

@@ -430,6 +430,23 @@ int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const float* row_
 int iff_attn_colsum_batched(float* logits_inout, int32_t Q, int32_t M, int64_t N, const float* row_max,
                             const float* row_sumexp, int32_t write_attention, float* score, void* stream);
 
+/* ---- the merge steps of the ray-sharded path (one process per GPU, rays sharded by surface point; the exchanges themselves are
+ * RCCL all_gathers issued by the caller).  The reference is single-process; over G column shards these reproduce its ONE softmax
+ * over the ray axis (pose_estimation/multihead_attention.py:11) and its ONE torch.topk (identification_module.py:207). */
+/* stats_all [G,R,2] = every rank's per-row (max, sum exp(l - max)) over its own columns, in rank order ->
+ * gmax [R], gsum [R] over all columns (ranks added in rank order: reproducible) */
+int iff_merge_row_stats(const float* stats_all, int32_t G, int64_t R, float* gmax, float* gsum, void* stream);
+/* a rank's local top-kl (idx [Q,kl] int64 into its own rays, val [Q,kl]; iff_topk_batched) -> its message msg [Q,k,8] =
+ * (score, bits of the GLOBAL ray index idx + first_ray, origin, direction); slots kl..k-1 are padding that sorts last.
+ * ray_stride = 0: all queries index one ray set rays_o / rays_d [n,3]; otherwise query q reads rays_o + q * ray_stride floats. */
+int iff_pack_candidates(const int64_t* idx, const float* val, const float* rays_o, const float* rays_d, int64_t ray_stride, int32_t Q,
+                        int32_t kl, int32_t k, int64_t first_ray, float* msg, void* stream);
+/* cand_all [G,Qt,k,8] (every rank's message, each list in torch.topk's order) -> for the queries q0 .. q0+Q-1 the global top-k
+ * of identification_module.py:207: val [Q,k] descending, lower ray index first on ties, idx [Q,k] (global), and the winners'
+ * origins / directions [Q,k,3] (what the pose solve of pose_estimation/test.py:133-174 reads) */
+int iff_merge_candidates(const float* cand_all, int32_t G, int32_t Qt, int32_t q0, int32_t Q, int32_t k, float* val, int64_t* idx,
+                         float* rays_o_out, float* rays_d_out, void* stream);
+
 /* torch.topk(scores, k) (identification_module.py:207): values descending, ties by lower index first.
  * idx [k] int64, val [k].  Workspace: iff_topk_workspace(N, k). */
 size_t iff_topk_workspace(int64_t N, int32_t k);

@@ -77,3 +77,28 @@ def near_tie_pairs(score_ref: torch.Tensor, k: int, rel_tie: float = 2e-5) -> in
     order (or, for the last pair, membership) fp32 rounding decides in ANY evaluation, the reference's own included."""
     s = torch.sort(score_ref.double(), descending=True).values[:k + 1]
     return int(((s[:-1] - s[1:]) <= rel_tie * s[:-1].abs()).sum())
+
+
+def fp64_referee(idx_got: torch.Tensor, score_ref: torch.Tensor, score_f64: torch.Tensor, k: int):
+    """For a top-k list that differs from the oracle's: which side does an fp64 evaluation of the same scores agree with?
+
+    ``score_ref`` is the oracle's fp32 score vector (the reference's arithmetic), ``score_f64`` the same op chain evaluated in
+    float64.  Every disagreement between the two lists is a statement about the order of two rays -- an adjacent pair that
+    appears swapped, or a ray that is inside one list and outside the other at the k-th place.  Returns
+    (pairs where fp64 orders them as ``idx_got`` does, pairs where fp64 orders them as the oracle does, exact fp64 ties)."""
+    want = torch.argsort(score_ref, descending=True, stable=True)[:k].tolist()
+    got = idx_got.tolist()
+    s = score_f64.double()
+    pairs = []                                   # (ray the HIP list ranks first, ray the oracle ranks first)
+    only_got, only_want = [i for i in got if i not in set(want)], [i for i in want if i not in set(got)]
+    pairs += list(zip(only_got, only_want))
+    p = 0
+    while p < k - 1:
+        if got[p] != want[p] and got[p] == want[p + 1] and got[p + 1] == want[p]:
+            pairs.append((got[p], want[p]))
+            p += 2
+        else:
+            p += 1
+    hip = sum(1 for a, b in pairs if float(s[a]) > float(s[b]))
+    orc = sum(1 for a, b in pairs if float(s[a]) < float(s[b]))
+    return hip, orc, len(pairs) - hip - orc
