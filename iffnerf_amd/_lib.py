@@ -32,7 +32,8 @@ class FieldDesc(C.Structure):
         ("basis", C.c_void_p), ("mask_volume", C.c_void_p), ("mask_dims", C.c_int32 * 3), ("mask_aabb", C.c_float * 6),
         ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
         ("step_size", C.c_float), ("n_samples", C.c_int32), ("near_far", C.c_float * 2),
-        ("softplus", C.c_int32), ("unisphere", C.c_int32), ("density_lanes", C.c_int32),
+        ("softplus", C.c_int32), ("unisphere", C.c_int32), ("density_lanes", C.c_int32), ("head_lanes", C.c_int32),
+        ("sampler_persistent", C.c_int32),
         ("normal_w", C.c_void_p), ("normal_b", C.c_void_p), ("tint_w", C.c_void_p), ("tint_b", C.c_void_p),
         ("rough_w", C.c_void_p), ("rough_b", C.c_void_p), ("diffuse_w", C.c_void_p), ("diffuse_b", C.c_void_p),
         ("bottleneck_w", C.c_void_p), ("bottleneck_b", C.c_void_p), ("specular_w", C.c_void_p), ("specular_b", C.c_void_p),

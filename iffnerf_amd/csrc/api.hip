@@ -122,6 +122,7 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     const int G[3] = {d->grid[0], d->grid[1], d->grid[2]};
     if (int rc = check_field_dims(G, d->n_density, d->n_app, d->app_dim, d->feature_c, d->density_lanes, d->mask_dims, d->mask_volume != nullptr))
         return rc;
+    IFF_REQUIRE(d->head_lanes == 0 || d->head_lanes == 16, "head_lanes = %d: must be 0 (auto) or 16", d->head_lanes);
 
     iff_field* f = new iff_field();
     FieldDev& v = f->dev;
@@ -201,7 +202,7 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     v.density_shift = d->density_shift; v.distance_scale = d->distance_scale; v.weight_thres = d->weight_thres;
     v.step_size = d->step_size; v.near = d->near_far[0]; v.far = d->near_far[1];
     v.n_samples = d->n_samples; v.softplus = d->softplus; v.unisphere = d->unisphere;
-    v.density_lanes = d->density_lanes;
+    v.density_lanes = d->density_lanes; v.head_lanes = d->head_lanes; v.sampler_persistent = d->sampler_persistent ? 1 : 0;
     v.n_density = d->n_density; v.n_app = d->n_app; v.app_dim = d->app_dim; v.feature_c = d->feature_c;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -380,7 +381,7 @@ extern "C" int iff_surface_sample_residency(const iff_field* f, int32_t B, int64
     IFF_REQUIRE(f && wgs_per_run && device_capacity && B >= 1, "iff_surface_sample_residency: bad argument");
     int w = 0, c = 0;
     IFF_HIP(sampler_residency(P, f->n_cus, sampler_lpc(f->dev, B), B, &w, &c));
-    if (sampler_stepped()) {       // no workgroup waits for another one: nothing has to be resident together
+    if (sampler_stepped(f->dev)) {       // no workgroup waits for another one: nothing has to be resident together
         const int64_t want = (5 * P * (f->dev.density_lanes == 0 ? 1 : sampler_lpc(f->dev, B)) + 255) / 256;     // quad form: one lane per candidate
         w = (int)(want > 1024 ? 1024 : want);
         c = 0x7fffffff;
@@ -1062,7 +1063,8 @@ static int validate_field_file(const char* path, const FieldDev& v, size_t slab_
          stored_is(v.head, true, L.head) && stored_is(v.mask, has_mask, L.mask) && stored_is(v.cell, has_mask, L.cell);
     if (!ok) return fail(IFF_ERR_INVALID_ARGUMENT, "%s: the table offsets / slab size do not match the dimensions the file claims", path);
     IFF_REQUIRE(v.n_samples >= 1 && (v.softplus == 0 || v.softplus == 1) && (v.unisphere == 0 || v.unisphere == 1) && v.step_size > 0.0f &&
-                    v.step_size < 1e30f, "%s: implausible march parameters", path);
+                    v.step_size < 1e30f && (v.head_lanes == 0 || v.head_lanes == 16) && (v.sampler_persistent == 0 || v.sampler_persistent == 1),
+                "%s: implausible march parameters", path);
     IFF_REQUIRE(occ.size() <= L.n_mask, "%s: %zu occupied voxels listed for a mask of %zu", path, occ.size(), L.n_mask);
     for (int i : occ) IFF_REQUIRE(i >= 0 && (size_t)i < L.n_mask, "%s: occupied-voxel index %d outside the mask", path, i);
     return 0;

@@ -332,9 +332,124 @@ __device__ __forceinline__ float ref_head_oct(const float* small, const HeadOff&
     return c * 1.002f - 0.001f;
 }
 
-// MODE 2: the whole march of a tile (density, compositing, appearance, basis_mat).  MODE 3: MODE 2 + the Ref head and the
-// background blend (phase E): the tile leaves the kernel as colours, no feature rows and no second launch.  MODE 1: appearance + basis_mat only, the
-// compositing weights come from K4a's workspace (A/B aid).
+// The same head for one ray by FOUR lanes (`sub` = the lane's index in the quad): the fused kernel's phase E runs it in TWO of the
+// tile's four waves (32 ray slots x 4 lanes) and lets the other two leave -- the per-ray part of the head is mostly arithmetic every
+// lane of a ray repeats (normalisation, reflection, the powers of r_z, the final sigmoid / sRGB), so a wave-level instruction serves
+// 16 rays instead of 8 and the tile issues ~40 % fewer vector instructions for the phase.  Bit for bit ref_head_oct /
+// ref_shade_group16: lane `sub` carries the FOUR partial sums l = sub + 4 p of the sixteen (pairs i = l, then l + 16; bottleneck
+// features l + 16 t, t ascending), the butterfly runs xor 1, 2 across the quad's lanes on each, and the xor-4 and xor-8 steps are the
+// additions (p0 + p1) + (p2 + p3); the ten small-head rows are rows sub, sub + 4, sub + 8.
+__device__ __forceinline__ float ref_head_quad(const float* small, const HeadOff& ho, int fc, float* sb, const float* F, const float* tail,
+                                              const float d[3], int sub) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int row = sub + 4 * u;
+        if (row < 10) {
+            const int blk = row / 3, o = row - 3 * blk;
+            const int w_off = blk == 0 ? ho.normal_w : (blk == 1 ? ho.tint_w : (blk == 2 ? ho.diffuse_w : ho.rough_w));
+            const int b_off = blk == 0 ? ho.normal_b : (blk == 1 ? ho.tint_b : (blk == 2 ? ho.diffuse_b : ho.rough_b));
+            const float* wr = small + w_off + o * 28;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < 28; k4 += 4) {
+                const f32q w4 = *reinterpret_cast<const f32q*>(wr + k4), f4 = *reinterpret_cast<const f32q*>(F + k4);
+                acc = fmaf(w4[0], f4[0], acc); acc = fmaf(w4[1], f4[1], acc); acc = fmaf(w4[2], f4[2], acc);
+                acc = fmaf(w4[3], k4 + 3 == 27 ? 0.0f : f4[3], acc);
+            }
+            const float raw = acc + small[b_off + o];
+            const float x = raw + (blk == 2 ? -1.0986122886681098f : -1.0f);
+            float mine = raw;
+            if (blk == 3) mine = softplusf_(x);
+            else if (blk != 0) mine = sigmoidf_(blk == 1 ? raw : x);
+            sb[fc + row] = mine;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the four lanes of a ray are lanes of one wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float nr[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) nr[o] = sb[fc + o];
+    const int ch = sub < 3 ? sub : 0;
+    const float tint_c = sb[fc + 3 + ch], diff_c = sb[fc + 6 + ch];
+    const float rough = sb[fc + 9];
+    float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
+    float n[3] = {-(nr[0] / nn), -(nr[1] / nn), -(nr[2] / nn)};
+    float v[3] = {-d[0], -d[1], -d[2]};
+    float ndv = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
+    float r[3] = {2.0f * ndv * n[0] - v[0], 2.0f * ndv * n[1] - v[1], 2.0f * ndv * n[2] - v[2]};
+    float dot = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+    const int K = fc + 39, KL = ho.spec_ld;
+    const float* spec_w = tail;
+    const float* spec_b = tail + (ho.spec_b - ho.spec_w);
+    const float* ide_mat = tail + (ho.ide_mat - ho.spec_w);
+    float part[3][4];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[o][q] = 0.0f;
+    float zp[9];
+    zp[0] = 1.0f;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) zp[k] = zp[k - 1] * r[2];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int i = sub + 4 * u;                              // pairs sub + 4 p (p = u < 4: partial p), then sub + 16 (partial 0)
+        if (i < 19) {
+            const int l = (i < 2) ? 1 : (i < 5) ? 2 : (i < 10) ? 4 : 8;
+            const int m = i - ((i < 2) ? 0 : (i < 5) ? 2 : (i < 10) ? 5 : 10);
+            float pr = 1.0f, pi = 0.0f;
+            for (int q = 0; q < m; ++q) {
+                float t = pr * r[0] - pi * r[1];
+                pi = pr * r[1] + pi * r[0];
+                pr = t;
+            }
+            float poly = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) poly = fmaf(zp[k], ide_mat[k * 19 + i], poly);
+            const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
+            const float re = pr * poly * att, im = pi * poly * att;
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+                part[o][u & 3] = fmaf(spec_w[o * KL + fc + 2 * i], re, fmaf(spec_w[o * KL + fc + 2 * i + 1], im, part[o][u & 3]));
+        }
+    }
+    // bottleneck features j = 16 t + sub + 4 p into partial sum p, t ascending; the LDS reads of a t are issued before its fmafs
+#pragma unroll 4
+    for (int j0 = 0; j0 < fc; j0 += 16) {
+        float b[4], wv[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + 4 * q + sub;
+            b[q] = sb[j];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) wv[o][q] = spec_w[o * KL + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) part[o][q] = fmaf(wv[o][q], b[q], part[o][q]);
+    }
+    float ps[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float first = fmaf(spec_w[o * KL + K - 1], dot, part[o][0]) + spec_b[o];
+        float t[4] = {sub == 0 ? first : part[o][0], part[o][1], part[o][2], part[o][3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[q] += dpp_mov<0xB1>(t[q]);                        // xor 1
+            t[q] += dpp_mov<0x4E>(t[q]);                        // xor 2
+        }
+        ps[o] = (t[0] + t[1]) + (t[2] + t[3]);                  // xor 4, xor 8
+    }
+    const float sg = sigmoidf_(ch == 0 ? ps[0] : (ch == 1 ? ps[1] : ps[2]));
+    float c = srgbf_(tint_c * sg + diff_c);
+    c = fminf(fmaxf(c, 0.0f), 1.0f);
+    return c * 1.002f - 0.001f;
+}
+
+// MODE 2: the whole march of a tile (density, compositing, appearance, basis_mat) -> feature rows.  MODE 3: MODE 2 + the Ref head and
+// the background blend (phase E): the tile leaves the kernel as colours, no feature rows and no second launch.
 template <int MODE>
 __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, MarchArgs a, int64_t n_tiles) {
     // the patch buffer and the sample records are one pool: phase D lays the two operands of its matrix product over both
@@ -418,7 +533,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     // density patches: 3 x 576 plane chunks = two full rounds per plane + one round in which wave w takes the last 64 chunks of
     // plane w; the three lines (48 chunks each) likewise by waves 0..2 in one round
     f32q pre[8];
-    if (MODE >= 2 && fits) {
+    if (fits) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pa = mat_a(i), pb = mat_b(i);
@@ -476,7 +591,6 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
                 r1.x = __float_as_uint(wt[1][0]); r1.y = __float_as_uint(wt[1][1]);
                 r1.z = __float_as_uint(wt[2][0]); r1.w = __float_as_uint(wt[2][1]);
             }
-            if (MODE == 1) r0.x = __float_as_uint(live ? a.weights[(ray0 + g) * FS + s] : 0.0f);
             uint32_t* rec = s_rec + (g * FS + s) * REC;
             *reinterpret_cast<u32q*>(rec) = r0;
             *reinterpret_cast<u32q*>(rec + 4) = r1;
@@ -484,7 +598,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     }
     STAMP(2);
     FAN_EXIT(2);
-    if (MODE >= 2 && fits) {
+    if (fits) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -518,7 +632,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     const bool live = grp_on && g < n_live;
     uint32_t* recs = s_rec + gg * FS * REC;
     unsigned shmask = 0u;
-    if (MODE >= 2) {
+    {
         // the 540 samples of the tile over the 64 four-lane sub-groups of the workgroup: sub-group q takes the samples t = q + 64 it
         // (t = 20 ray + s: the record index), its four lanes gather a sample together (one 16-B quarter of the density texel each)
         // and lane c finishes the sample of trip it = 4 k + c; the record of the next sample is read one trip ahead
@@ -623,9 +737,6 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
             a.depth[r_glob] = run_depth + (1.0f - run_acc) * sr[7];
             if (a.counts) { a.counts[r_glob * 2] = run_valid; a.counts[r_glob * 2 + 1] = run_app; }
         }
-    } else {
-#pragma unroll 1
-        for (int s = 0; s < FS; ++s) shmask |= (__uint_as_float(recs[s * REC]) > f.weight_thres ? 1u : 0u) << s;
     }
     STAMP(5);
     FAN_EXIT(5);
@@ -850,17 +961,20 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     ESTAMP(6);
     __syncthreads();
     ESTAMP(7);
-    if (grp_on) {                                      // g = ray of the tile, eight lanes each
-        const int sub = tid & 7;
-        const float* sr = s_ray + g * 8;
+    // four lanes per ray, 32 ray slots = 128 threads = two of the four waves: which two rotates with the tile (a tile's wave w always
+    // lands on the CU's w-th SIMD: the head's instructions would otherwise pile up on two SIMDs)
+    const int ew = (wave - (int)(blockIdx.x & 3u)) & 3;         // 0, 1: the two waves that run the head
+    if (ew < 2) {
+        const int eg = 16 * ew + (lane >> 2), sub = lane & 3;  // ray slot of the tile, lane of the quad
+        const float* sr = s_ray + (eg < FR ? eg : 0) * 8;
         const float d[3] = {sr[3], sr[4], sr[5]};
-        const float cch = ref_head_oct(s_small, ho, fc, s_b + g * BLD, s_feat + g * 28, s_tail, d, sub);
-        if (sub < 3 && g < n_live) {
-            const bool shaded = s_feat[g * 28 + 27] != 0.0f;
+        const float cch = ref_head_quad(s_small, ho, fc, s_b + eg * BLD, s_feat + eg * 28, s_tail, d, sub);
+        if (sub < 3 && eg < n_live) {
+            const bool shaded = s_feat[eg * 28 + 27] != 0.0f;
             const float acc = sr[6];
             float v = shaded ? cch : 0.0f;
             v = v * acc + (sub == 0 ? a.bg[0] : (sub == 1 ? a.bg[1] : a.bg[2])) * (1.0f - acc);
-            a.rgb[3 * (ray0 + g) + sub] = fminf(fmaxf(v, 0.0f), 1.0f);
+            a.rgb[3 * (ray0 + eg) + sub] = fminf(fmaxf(v, 0.0f), 1.0f);
         }
     }
     STAMP(14);
@@ -990,8 +1104,7 @@ hipError_t launch_fan_march(const FieldDev& f, const MarchArgs& a, int variant, 
     if (n_tiles == 0) return hipSuccess;
     if (n_tiles > 0x7fffffff) return hipErrorInvalidValue;
     const int64_t grid = n_tiles;
-    if (variant == 1) hipLaunchKernelGGL((k4f_fan_march<1>), dim3((unsigned)grid), dim3(NT), 0, s, f, a, n_tiles);
-    else if (variant == 3) hipLaunchKernelGGL((k4f_fan_march<3>), dim3((unsigned)grid), dim3(NT), 0, s, f, a, n_tiles);
+    if (variant == 3) hipLaunchKernelGGL((k4f_fan_march<3>), dim3((unsigned)grid), dim3(NT), 0, s, f, a, n_tiles);
     else hipLaunchKernelGGL((k4f_fan_march<2>), dim3((unsigned)grid), dim3(NT), 0, s, f, a, n_tiles);
     return hipGetLastError();
 }

@@ -312,9 +312,8 @@ hipError_t launch_point_normals(const FieldDev& f, const float* xyz, int64_t n, 
 template <bool BLEND>
 static hipError_t launch_shade_kernel(const FieldDev& f, const ShadeArgs& a, int64_t n, hipStream_t s) {
     // the reference's head shape runs in the 8-lanes-per-ray form with the bottleneck on the matrix cores (fan_march_kernels.hip:
-    // same bits); IFF_REF_SHADE_GROUP16=1 keeps this file's kernel, the form other head shapes use
-    const char* keep16 = getenv("IFF_REF_SHADE_GROUP16");          // read per call: the parity test switches forms inside one process
-    if (fan_head_fusable(f) && !(keep16 && keep16[0] == '1'))
+    // same bits); iff_field_desc.head_lanes = 16 keeps this file's kernel, the form other head shapes use
+    if (fan_head_fusable(f) && f.head_lanes != 16)
         return launch_ref_shade_oct(f, a.dirs, a.dir_stride, a.feat, a.feat_stride, BLEND ? a.acc : nullptr, a.bg, n, a.rgb, s);
     const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
     const size_t lds = (size_t)((ho.total + 3) & ~3) * sizeof(float);

@@ -32,6 +32,8 @@ struct FieldDev {
     float density_shift, distance_scale, weight_thres, step_size, near, far;
     int n_samples, softplus, unisphere;
     int density_lanes;          // 0 auto, 1 or 4 forced (iff_field_desc.density_lanes)
+    int head_lanes;             // 0 auto, 16 = the vector form of the Ref head launches (iff_field_desc.head_lanes)
+    int sampler_persistent;     // 1: the surface sampler as one persistent launch (iff_field_desc.sampler_persistent)
     int n_density, n_app, app_dim, feature_c;
 };
 

@@ -46,7 +46,7 @@ hipError_t launch_march_grad(const FieldDev& f, const float* rays, int ray_cols,
 // sampler_kernels.hip
 size_t sampler_workspace_bytes(int64_t P);
 int sampler_lpc(const FieldDev& f, int B);
-bool sampler_stepped();
+bool sampler_stepped(const FieldDev& f);
 hipError_t sampler_residency(int64_t P, int n_cus, int lpc, int B, int* wgs_per_query, int* capacity);
 hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int n_occ, int B, int64_t P, int n_epochs,
                                      int max_iterations, uint64_t seed, const uint64_t* seed_dev, float rho, float* samples,

@@ -403,19 +403,14 @@ __global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance12(FieldDev f, M
 static size_t march_feat_offset(int64_t R, int S) { return ((size_t)R * (size_t)S * sizeof(float) + 255) / 256 * 256; }
 size_t march_workspace_bytes(int64_t R, int S) { return march_feat_offset(R, S) + (size_t)R * 28 * sizeof(float); }
 
-// 0 = the general kernels, 1 = K4a + the fan kernel's appearance half (A/B aid), 2 = the fused fan kernel.
-// IFF_MARCH_FAN (environment, read once; tuning / A-B aid) caps the choice; iff_field_desc.density_lanes != 0 names one of the
-// general kernels and therefore keeps them.
+// 0 = the general kernels, 2 = the fused fan kernel (iff_field_desc.density_lanes != 0 names one of the general kernels and
+// therefore keeps them: what the parity tests compare the fan kernel with).
 int march_plan(const FieldDev& f, int mode, int S) {
-    static const int fan_knob = [] { const char* e = getenv("IFF_MARCH_FAN"); return e ? atoi(e) : 2; }();
-    return (fan_knob > 0 && f.density_lanes == 0 && fan_march_eligible(f, mode, S)) ? (fan_knob == 1 ? 1 : 2) : 0;
+    return (f.density_lanes == 0 && fan_march_eligible(f, mode, S)) ? 2 : 0;
 }
 
-// the colours call of the fused plan also runs the Ref head in the fan kernel (IFF_MARCH_FAN_HEAD=0, read once: keep the separate launch)
-bool march_head_fused(const FieldDev& f) {
-    static const bool head_env = [] { const char* v = getenv("IFF_MARCH_FAN_HEAD"); return !(v && v[0] == '0'); }();
-    return head_env && fan_head_fusable(f);
-}
+// the colours call of the fused plan also runs the Ref head in the fan kernel
+bool march_head_fused(const FieldDev& f) { return fan_head_fusable(f) && f.head_lanes != 16; }
 
 hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S, const float* bg,
                         float* rgb, float* depth, float* acc, float* alpha, int* counts, float* feat_out, void* ws,
@@ -452,7 +447,7 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
     const bool fuse_head = fan == 2 && !feat_out && march_head_fused(f);
     if (fan) {
-        e = launch_fan_march(f, a, fuse_head ? 3 : fan, s);
+        e = launch_fan_march(f, a, fuse_head ? 3 : 2, s);
         if (e != hipSuccess) return e;
     } else if (mode == 0 && S <= 32) {
         const int64_t tiles12 = (R + 19) / 20;

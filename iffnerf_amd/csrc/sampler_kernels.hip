@@ -809,7 +809,7 @@ __global__ void k_zero_u64(unsigned long long* p, int64_t n) {
 int sampler_lpc(const FieldDev& f, int B) {
     if (f.n_density != 16 || f.density_lanes == 4) return 4;
     if (f.density_lanes == 1) return 1;
-    if (sampler_stepped()) return 4;          // (the stepped form's default is the quad form: launch_surface_sample_occ; 4 = its footprint class)
+    if (sampler_stepped(f)) return 4;          // (the stepped form's default is the quad form: launch_surface_sample_occ; 4 = its footprint class)
     return B >= 8 ? 1 : 4;
 }
 
@@ -838,11 +838,8 @@ hipError_t sampler_residency(int64_t P, int n_cus, int lpc, int B, int* wgs_per_
     return hipSuccess;
 }
 
-// IFF_SAMPLER_PERSISTENT=1 (environment, read at every call: a test switches it) keeps the one-launch form
-bool sampler_stepped() {
-    const char* v = getenv("IFF_SAMPLER_PERSISTENT");
-    return !(v && v[0] == '1');
-}
+// iff_field_desc.sampler_persistent = 1 keeps the one-launch form (the parity test builds such a handle)
+bool sampler_stepped(const FieldDev& f) { return f.sampler_persistent == 0; }
 
 static hipError_t launch_surface_sample_stepped(const FieldDev& f, SamplerArgs a, int B, hipStream_t s) {
     const int64_t P = a.P;
@@ -884,7 +881,7 @@ hipError_t launch_surface_sample_occ(const FieldDev& f, const int* occ_list, int
         return hipErrorInvalidValue;
     const size_t per_query = sampler_workspace_bytes(P);
     if (ws_bytes < per_query * (size_t)B) return hipErrorInvalidValue;
-    if (sampler_stepped()) {
+    if (sampler_stepped(f)) {
         const int64_t n_words = (int64_t)(per_query * (size_t)B / 8);
         hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, (unsigned long long*)ws, n_words);
         hipError_t e0 = hipGetLastError();

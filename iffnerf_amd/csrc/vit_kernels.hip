@@ -714,11 +714,10 @@ hipError_t gemm(const void* Xv, int64_t x_lo, const void* Wv, int64_t w_lo, int6
     const ET* X = (const ET*)Xv;
     const ET* W = (const ET*)Wv;
     if (N % GBN != 0 || K % GBK != 0 || M < 1) return hipErrorInvalidValue;
-    static const int force = [] { const char* e = getenv("IFF_VIT_TILE"); return e ? atoi(e) : 0; }();      // tuning aid
     // 64-token tiles for small batches (with 128 a 4112-token batch -- 16 images -- leaves CUs idle or a single workgroup per CU);
     // from 24 images on 128-token tiles: each launch alone is 5-15 % slower, but the workgroups read 1/3 fewer operand bytes per flop
     // and with several batches in flight (the bench's four graphs) the total is 5 % faster (17 700 -> 18 700 images/s at 32 images)
-    const bool wide = force ? force == 128 : M >= 6144;       // (64-token tiles for the N = 384 products only: -1.7 % images/s)
+    const bool wide = M >= 6144;       // (64-token tiles for the N = 384 products only: -1.7 % images/s)
     if (!wide)
         hipLaunchKernelGGL((k_vit_gemm<EPI, 64, PREC>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, x_lo, W, w_lo, M, N, K, e);
     else

@@ -28,7 +28,8 @@ class FieldHandle:
                  density_plane, density_line, app_plane, app_line, basis: torch.Tensor, head: Dict[str, torch.Tensor],
                  mask_volume: Optional[torch.Tensor], mask_aabb: Optional[torch.Tensor],
                  density_shift: float, distance_scale: float, weight_thres: float, step_size: float, n_samples: int,
-                 near_far, softplus: bool = True, unisphere: bool = False, density_lanes: int = 0):
+                 near_far, softplus: bool = True, unisphere: bool = False, density_lanes: int = 0, head_lanes: int = 0,
+                 sampler_persistent: bool = False):
         self._h = None
         L = _lib.lib()
         device = torch.device(device)
@@ -71,6 +72,8 @@ class FieldHandle:
         d.near_far[:] = [float(near_far[0]), float(near_far[1])]
         d.softplus, d.unisphere = int(bool(softplus)), int(bool(unisphere))
         d.density_lanes = int(density_lanes)          # 0 = auto; 1 / 4 force a gather form (include/iffnerf_hip.h)
+        d.head_lanes = int(head_lanes)                # 0 = auto; 16 = the vector form of the Ref head launches
+        d.sampler_persistent = int(bool(sampler_persistent))      # the one-launch form of the surface sampler (parity tests)
         for field, key in (("normal", "normal_mlp.0"), ("tint", "tint_color_mlp.0"), ("rough", "roughness_mlp.0"),
                            ("diffuse", "diffuse_color_mlp.0"), ("bottleneck", "bottleneck_mlp"),
                            ("specular", "specular_mlp.0")):
@@ -354,7 +357,7 @@ def isocell_emit(cells: torch.Tensor, points: torch.Tensor, normals: torch.Tenso
     return (ori, dirs, rays6) if want_rays6 else (ori, dirs)
 
 
-def field_handle_from_ckpt(ckpt: dict, device, density_lanes: int = 0) -> FieldHandle:
+def field_handle_from_ckpt(ckpt: dict, device, density_lanes: int = 0, head_lanes: int = 0, sampler_persistent: bool = False) -> FieldHandle:
     """Build a handle straight from a checkpoint dictionary (TensorBase.save layout); used by tests and bench."""
     from .models.tensorBase import derive_step
     kw = ckpt["kwargs"]
@@ -378,4 +381,5 @@ def field_handle_from_ckpt(ckpt: dict, device, density_lanes: int = 0) -> FieldH
         density_shift=kw.get("density_shift", -10), distance_scale=kw.get("distance_scale", 25),
         weight_thres=kw.get("rayMarch_weight_thres", 1e-4), step_size=float(step), n_samples=n_samples,
         near_far=kw.get("near_far", (2.0, 6.0)), softplus=kw.get("fea2denseAct", "softplus") == "softplus",
-        unisphere=kw.get("contraction_type", "aabb") == "unisphere", density_lanes=density_lanes)
+        unisphere=kw.get("contraction_type", "aabb") == "unisphere", density_lanes=density_lanes, head_lanes=head_lanes,
+        sampler_persistent=sampler_persistent)

@@ -95,7 +95,14 @@ typedef struct iff_field_desc {
     int32_t density_lanes;           /* lanes that share one density lookup (compute_densityfeature, tensoRF.py:216-235) in the
                                         march and the surface sampler: 0 = choose (one lane per point when a density texel
                                         is one 64-B line, and for sampler batches < 8 four), 1 or 4 = force that form.  Both
-                                        forms produce the same bits; the knob exists for A/B tests and tuning. */
+                                        forms produce the same bits; the knob exists for A/B tests and tuning.  A non-zero value
+                                        also keeps the point-centred march on the general kernels (K4a / K4b / head launch). */
+    int32_t head_lanes;              /* lanes that share one ray in the Ref head launches (Ref.forward, models/ref.py:103-152):
+                                        0 = choose (8, the bottleneck on the fp32 matrix cores, for the reference's head shape),
+                                        16 = the 16-lane vector form every head shape can take.  Same bits; for parity tests. */
+    int32_t sampler_persistent;      /* 0: the surface sampler (pose_estimation/sampling.py:509-532) as a chain of short launches;
+                                        1: ONE persistent launch with in-kernel grid barriers (the same samples bit for bit; then
+                                        iff_surface_sample_residency bounds the launches that may be in flight).  For parity tests. */
     /* Ref head, models/ref.py:69-101 (nn.Linear layouts [out,in]) */
     const float* normal_w;  const float* normal_b;    /* [3,app_dim],[3] */
     const float* tint_w;    const float* tint_b;      /* [3,app_dim],[3] */

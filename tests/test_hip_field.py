@@ -210,33 +210,31 @@ def test_one_lane_density_gather_is_bit_identical_to_the_four_lane_form(dev):
                 assert torch.equal(x, y), (P, mode)
 
 
-def test_ref_head_forms_return_the_same_bits(small, dev, monkeypatch):
+def test_ref_head_forms_return_the_same_bits(small, dev):
     """Ref.forward in the 8-lanes-per-ray form (bottleneck on the fp32 matrix cores: k_ref_shade_oct, the default for the reference's
-    head shape) against the 16-lanes-per-ray vector form (k_ref_shade, IFF_REF_SHADE_GROUP16=1), plain and as the march's shade +
-    blend step: EQUAL bits, on full, ragged and looped tile counts."""
+    head shape) against the 16-lanes-per-ray vector form (k_ref_shade: a handle made with iff_field_desc.head_lanes = 16), plain and
+    as the march's shade + blend step: EQUAL bits, on full, ragged and looped tile counts."""
     from iffnerf_amd.hip_field import field_handle_from_ckpt
+    small16 = field_handle_from_ckpt(util.ckpt("small"), dev, head_lanes=16)
     g = torch.Generator().manual_seed(5)
     for n in (1, 31, 32, 33, 1000, 40007):                                  # 40007 rays = 1251 tiles > the grid's 1024 workgroups
         d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
         feat = (torch.randn(n, 27, generator=g) * 2.0).to(dev)
-        monkeypatch.setenv("IFF_REF_SHADE_GROUP16", "1")
-        want = small.ref_shade(d, feat)
-        monkeypatch.delenv("IFF_REF_SHADE_GROUP16")
+        want = small16.ref_shade(d, feat)
         got = small.ref_shade(d, feat)
         assert torch.equal(got, want), (n, float((got - want).abs().max()))
     gen = field_handle_from_ckpt(util.ckpt("small"), dev, density_lanes=1)   # the general march: K4a, K4b, shade + blend
-    assert gen.march_plan(0, 20) == 0
+    gen16 = field_handle_from_ckpt(util.ckpt("small"), dev, density_lanes=1, head_lanes=16)
+    assert gen.march_plan(0, 20) == 0 and gen16.march_plan(0, 20) == 0
     for R in (540, 37):
         o = (torch.rand(R, 3, generator=g) - 0.5) * 2.0
         rays = torch.cat((o, torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)), -1).to(dev)
         for bg in ((0.0, 0.0, 0.0), (1.0, 0.5, 0.25)):
-            monkeypatch.setenv("IFF_REF_SHADE_GROUP16", "1")
-            want = gen.march(rays, 0, 20, bg=bg)[0]
-            monkeypatch.delenv("IFF_REF_SHADE_GROUP16")
+            want = gen16.march(rays, 0, 20, bg=bg)[0]
             assert torch.equal(gen.march(rays, 0, 20, bg=bg)[0], want), (R, bg)
 
 
-def test_fan_march_equals_the_general_kernels(dev, monkeypatch):
+def test_fan_march_equals_the_general_kernels(dev):
     """The fused fan kernel (k4f_fan_march: LDS-staged table patches per 27-ray tile, or its in-kernel gather path when a tile's
     samples do not fit one patch) against the general kernels K4a / K4b (iff_field_desc.density_lanes = 1 keeps those): the
     per-sample arithmetic is shared, so alpha, acc, depth and the (valid, shaded) counters must be EQUAL; the colours differ
@@ -245,9 +243,6 @@ def test_fan_march_equals_the_general_kernels(dev, monkeypatch):
     from iffnerf_amd.hip_field import field_handle_from_ckpt
     from iffnerf_amd.pipeline import PosePipeline
     g = torch.Generator().manual_seed(31)
-    import os
-    if os.environ.get("IFF_MARCH_FAN", "2") == "0":
-        pytest.skip("the fan kernel is switched off (IFF_MARCH_FAN=0)")
     for which, over in (("small", {}), ("tiny", {}), ("small", dict(grid=(300, 280, 260), mask_res=(60, 56, 52))),
                         ("small", dict(contraction_type="unisphere", density_shift=0.0, density_offset=-10.0, peak=20.0,
                                        aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), near_far=(0.01, 1.4), blob_sigma=0.30, mask_radius=0.62,
@@ -255,6 +250,7 @@ def test_fan_march_equals_the_general_kernels(dev, monkeypatch):
         ck = util.ckpt(which, **over)
         pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev)
         fan, gen = field_handle_from_ckpt(ck, dev), field_handle_from_ckpt(ck, dev, density_lanes=1)
+        head16 = field_handle_from_ckpt(ck, dev, head_lanes=16)               # fan kernel without its head phase + the 16-lane head launch
         cases = []
         for P in (75, 9, 1):                                                   # fans: the staged path
             ori, dirs, _ = pipe.emit(P, seed=17 + P)
@@ -274,14 +270,14 @@ def test_fan_march_equals_the_general_kernels(dev, monkeypatch):
             fa, fb = fan.march_features(rays, 0, 20)[0], gen.march_features(rays, 0, 20)[0]
             close(fa, fb.cpu(), 2e-5, 2e-6, what="weighted features")
             assert torch.equal(fa[:, 27], fb[:, 27])
-            # the Ref head fused into the fan kernel (plan 3: bottleneck on the fp32 matrix cores, eight lanes per ray) against the
-            # separate head kernel (16 lanes per ray) on the fan kernel's own features, blended as k_ref_shade blends: EQUAL colours
-            assert fan.march_plan(0, 20) == (3 if os.environ.get("IFF_MARCH_FAN_HEAD", "1") != "0" else 2) and gen.march_plan(0, 20) == 0
+            # the Ref head fused into the fan kernel (plan 3: bottleneck on the fp32 matrix cores, four lanes per ray in two of the
+            # tile's waves) against the separate head kernel (16 lanes per ray) on the fan kernel's own features, blended as
+            # k_ref_shade blends: EQUAL colours
+            assert fan.march_plan(0, 20) == 3 and head16.march_plan(0, 20) == 2 and gen.march_plan(0, 20) == 0
             for bg in ((0.0, 0.0, 0.0), (1.0, 0.5, 0.25)):
                 fused = fan.march(rays, 0, 20, bg=bg)
-                monkeypatch.setenv("IFF_REF_SHADE_GROUP16", "1")
-                c = fan.ref_shade(rays[:, 3:6].contiguous(), fa[:, :27].contiguous())
-                monkeypatch.delenv("IFF_REF_SHADE_GROUP16")
+                assert torch.equal(head16.march(rays, 0, 20, bg=bg)[0], fused[0])     # the fan kernel + the separate 16-lane head launch
+                c = head16.ref_shade(rays[:, 3:6].contiguous(), fa[:, :27].contiguous())
                 c = torch.where(fa[:, 27:28] != 0, c, torch.zeros_like(c))
                 acc = fused[2].reshape(-1, 1)
                 want = (c * acc + torch.tensor(bg, device=c.device) * (1.0 - acc)).clamp(0.0, 1.0)

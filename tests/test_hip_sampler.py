@@ -201,34 +201,30 @@ def test_batched_runs_large_point_counts_and_residency(small, dev):
     w1, cap = small.sampler_residency(593, 1)
     w16, cap16 = small.sampler_residency(593, 16)
     assert cap == cap16 == 2 ** 31 - 1 and w1 == 12 and w16 == 12          # one lane per candidate at P = 593 (quad form) whatever the batch
-    os.environ["IFF_SAMPLER_PERSISTENT"] = "1"
-    try:
-        w1, cap = small.sampler_residency(593, 1)
-        w16, cap16 = small.sampler_residency(593, 16)
-        assert cap == cap16 and 256 <= cap < 2 ** 31 - 1 and w1 == 47 and w16 == 12      # batches of 8 or more: one lane per candidate
-        w_big, _ = small.sampler_residency(20000, 1)
-        assert w_big <= 256                                                 # never more than one workgroup per CU and run
-    finally:
-        del os.environ["IFF_SAMPLER_PERSISTENT"]
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    pers = field_handle_from_ckpt(util.ckpt("small"), dev, sampler_persistent=True)
+    w1, cap = pers.sampler_residency(593, 1)
+    w16, cap16 = pers.sampler_residency(593, 16)
+    assert cap == cap16 and 256 <= cap < 2 ** 31 - 1 and w1 == 47 and w16 == 12      # batches of 8 or more: one lane per candidate
+    w_big, _ = pers.sampler_residency(20000, 1)
+    assert w_big <= 256                                                 # never more than one workgroup per CU and run
 
 
 def test_stepped_launches_equal_the_persistent_launch(small, dev):
     """The sampler as a chain of short launches (the default: seeds | per epoch 8 iteration launches + finisher + apply, the kernel
     boundary as the grid barrier) draws the SAME samples, alphas and statistics as the one persistent launch with in-kernel grid
-    barriers (IFF_SAMPLER_PERSISTENT=1), bit for bit: both lane forms, point counts below and above the LDS-cache limit, an
+    barriers (a handle made with iff_field_desc.sampler_persistent = 1), bit for bit: both lane forms, point counts below and above the LDS-cache limit, an
     iteration bound below the number of static launches, and a jitter so small that an epoch needs more than the 8 static
     iteration launches (the finisher's loop)."""
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    pers = field_handle_from_ckpt(util.ckpt("small"), dev, sampler_persistent=True)
     rho = rho_of(util.ckpt("small"))
     cases = [(1, 593, rho, 4, 200), (16, 593, rho, 4, 200), (3, 5000, rho, 3, 200), (8, 300, rho, 2, 3), (2, 700, rho * 0.02, 2, 200),
              (9, 400, rho * 0.02, 2, 12), (2, 3000, rho * 0.02, 2, 200), (2, 20000, rho, 2, 200)]     # > 2560 points: list + candidate launches
     long_epochs = 0
     for B, P, r, E, mi in cases:
         got = small.surface_sample_batched(B, P, r, n_epochs=E, max_iterations=mi, seed=4321)
-        os.environ["IFF_SAMPLER_PERSISTENT"] = "1"
-        try:
-            want = small.surface_sample_batched(B, P, r, n_epochs=E, max_iterations=mi, seed=4321)
-        finally:
-            del os.environ["IFF_SAMPLER_PERSISTENT"]
+        want = pers.surface_sample_batched(B, P, r, n_epochs=E, max_iterations=mi, seed=4321)
         assert (want[2][..., 3] != -1).all(), "in-kernel barrier timed out"
         for x, y, what in zip(got, want, ("samples", "alpha", "stats")):
             assert torch.equal(x, y), (B, P, r, E, mi, what, (got[2] - want[2]).abs().max().item() if what == "stats" else None)
