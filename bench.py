@@ -400,7 +400,7 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     # `achieved` = ALGORITHMIC flops / bytes of SURVEY.md section 8(d) over the launch time; `traffic` = HBM-side bytes per launch
     # from the rocprofv3 PMC passes of profiles/ (only while they were collected on these kernel sources and this --config),
     # `hbm_frac_from_counters` = that over the launch time over the 8 TB/s HBM peak.
-    pmc, pmc_name = {}, "profiles/r03_hbm_traffic_%s.json" % args.config
+    pmc, pmc_name = {}, "profiles/r04_hbm_traffic_%s.json" % args.config
     try:
         with open(os.path.join(ROOT, pmc_name)) as fh:
             pmc = json.load(fh)

@@ -1073,6 +1073,9 @@ __global__ void __launch_bounds__(NT) k_ref_shade_oct(FieldDev f, const float* _
 // most that of the uncontracted step and the end-point argument of phase 0 holds unchanged.
 bool fan_march_eligible(const FieldDev& f, int mode, int S) {
     if (mode != 0 || S != FS || f.n_density != 16 || f.n_app != 48 || f.app_dim != 27) return false;
+#ifdef FAN_ELIGIBLE_ALWAYS          // experiment builds: every point-centred march through the fan kernel (its gather path when a box does not fit)
+    return true;
+#endif
     for (int ax = 0; ax < 3; ++ax) {
         const float scale = f.unisphere ? 1.0f : f.inv_aabb[ax];            // d(normalised coordinate) / d(world coordinate), at most
         const float texels = 10.0f * f.step_size * scale * 0.5f * (float)(f.grid[ax] - 1);

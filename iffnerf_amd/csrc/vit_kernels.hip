@@ -187,8 +187,9 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(y, x);
 }
 
-// PREC 1: X and Wt are the hi planes, the lo planes sit x_lo / w_lo elements behind them, and the k loop runs over the three
-// products hi hi, hi lo (the weight's lo plane), lo hi (the activation's lo plane) -- same tiles, same LDS, three times the steps.
+// PREC 1: X and Wt are the hi planes, the lo planes sit x_lo / w_lo elements behind them; a k tile stages BOTH planes of both
+// operands in LDS (four tiles) and every 16-deep k-step issues the three products lo hi, hi lo, hi hi (smallest first) from them --
+// the operand bytes of a tile are fetched once for its three products.
 template <int EPI, int GBM, int PREC>
 __global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e* __restrict__ X, int64_t x_lo,
                                                      const typename VT<PREC>::e* __restrict__ Wt, int64_t w_lo, int64_t M, int N, int K,
@@ -196,8 +197,9 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e*
     typedef typename VT<PREC>::e ET;
     typedef typename VT<PREC>::v8 bf16x8;                      // (the 16-byte operand vector of this precision)
     constexpr int MB = GBM / 64;                                // 32-token blocks per wave
-    __shared__ __attribute__((aligned(16))) ET sW[GBN][GLD];
-    __shared__ __attribute__((aligned(16))) ET sX[GBM][GLD];
+    constexpr int NP = PREC ? 2 : 1;                            // operand planes
+    __shared__ __attribute__((aligned(16))) ET sW[NP][GBN][GLD];
+    __shared__ __attribute__((aligned(16))) ET sX[NP][GBM][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = (wave & 1) * 64, wm = (wave >> 1) * (32 * MB);      // the wave's corner of the tile
     const int lr = lane & 31, lh = lane >> 5;
@@ -210,59 +212,80 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e*
         for (int b = 0; b < MB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    // a 128-row tile is 128 x 64 bf16 = 1024 chunks of 16 B: 4 per thread; the token tile 4 or 2.  TWO k tiles are in flight in
-    // registers (sets A and B, the k loop unrolled by two): a k step is 8-16 MFMAs per wave, a third of the latency of the tile
-    // that travels, and one tile ahead left every step waiting for it (K / GBK is even for every GEMM of the network: 6, 24, 10)
-    bf16x8 gwA[4], gxA[2 * MB], gwB[4], gxB[2 * MB];
-    const int KT = PREC ? 3 * K : K;                            // k steps over all products (a tile never straddles two: K % GBK == 0)
-    auto fetch = [&](bf16x8 (&gw)[4], bf16x8 (&gx)[2 * MB], int kv) {
-        const int seg = PREC ? kv / K : 0, k0 = kv - seg * K;    // wave-uniform
-        const ET* Wp = Wt + (seg == 1 ? w_lo : 0);
-        const ET* Xp = X + (seg == 2 ? x_lo : 0);
+    // a 128-row tile is 128 x 64 halves = 1024 chunks of 16 B: 4 per thread; the token tile 4 or 2.  PREC 0: TWO k tiles are in
+    // flight in registers (sets A and B, the k loop unrolled by two): a k step is 8-16 MFMAs per wave, a third of the latency of the
+    // tile that travels, and one tile ahead left every step waiting for it.  PREC 1: a k step is three times the MFMAs and the tile
+    // is two planes: one tile ahead (set A only) covers the latency and keeps the registers
+    struct Tile { bf16x8 w[NP][4], x[NP][2 * MB]; };
+    auto fetch = [&](Tile& t, int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
-            gw[r] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(n0 + row) * K + k0 + kc);
-        }
+        for (int pl = 0; pl < NP; ++pl) {
+            const ET* Wp = Wt + (pl ? w_lo : 0);
+            const ET* Xp = X + (pl ? x_lo : 0);
 #pragma unroll
-        for (int r = 0; r < 2 * MB; ++r) {
-            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
-            const int64_t m = min(m0 + row, M - 1);
-            gx[r] = *reinterpret_cast<const bf16x8*>(Xp + m * K + k0 + kc);
+            for (int r = 0; r < 4; ++r) {
+                const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
+                t.w[pl][r] = *reinterpret_cast<const bf16x8*>(Wp + (int64_t)(n0 + row) * K + k0 + kc);
+            }
+#pragma unroll
+            for (int r = 0; r < 2 * MB; ++r) {
+                const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
+                const int64_t m = min(m0 + row, M - 1);
+                t.x[pl][r] = *reinterpret_cast<const bf16x8*>(Xp + m * K + k0 + kc);
+            }
         }
     };
-    auto step = [&](bf16x8 (&gw)[4], bf16x8 (&gx)[2 * MB], int k_next) {
+    auto step = [&](Tile& t, int k_next) {
         __syncthreads();                       // the previous step's fragments have been read
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
-            *reinterpret_cast<bf16x8*>(&sW[row][kc]) = gw[r];
-        }
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-        for (int r = 0; r < 2 * MB; ++r) {
-            const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
-            *reinterpret_cast<bf16x8*>(&sX[row][kc]) = gx[r];
+            for (int r = 0; r < 4; ++r) {
+                const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
+                *reinterpret_cast<bf16x8*>(&sW[pl][row][kc]) = t.w[pl][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 2 * MB; ++r) {
+                const int chunk = tid + 256 * r, row = chunk >> 3, kc = (chunk & 7) * 8;
+                *reinterpret_cast<bf16x8*>(&sX[pl][row][kc]) = t.x[pl][r];
+            }
         }
         __syncthreads();
-        if (k_next < KT) fetch(gw, gx, k_next);    // this set's next tile (two steps ahead) travels while two tiles are multiplied
+        if (k_next < K) fetch(t, k_next);       // this set's next tile travels while the staged one is multiplied
 #pragma unroll
         for (int ks = 0; ks < GBK / 16; ++ks) {
-            bf16x8 fa[2], fb[MB];
+            bf16x8 fa[NP][2], fb[NP][MB];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(&sW[wn + 32 * a + lr][16 * ks + 8 * lh]);
+            for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int b = 0; b < MB; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(&sX[wm + 32 * b + lr][16 * ks + 8 * lh]);
+                for (int a = 0; a < 2; ++a) fa[pl][a] = *reinterpret_cast<const bf16x8*>(&sW[pl][wn + 32 * a + lr][16 * ks + 8 * lh]);
+#pragma unroll
+                for (int b = 0; b < MB; ++b) fb[pl][b] = *reinterpret_cast<const bf16x8*>(&sX[pl][wm + 32 * b + lr][16 * ks + 8 * lh]);
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < MB; ++b) acc[a][b] = VT<PREC>::mfma(fa[a], fb[b], acc[a][b]);
+                for (int b = 0; b < MB; ++b) {
+                    if (PREC) {
+                        acc[a][b] = VT<PREC>::mfma(fa[NP - 1][a], fb[0][b], acc[a][b]);      // W lo x X hi
+                        acc[a][b] = VT<PREC>::mfma(fa[0][a], fb[NP - 1][b], acc[a][b]);      // W hi x X lo
+                    }
+                    acc[a][b] = VT<PREC>::mfma(fa[0][a], fb[0][b], acc[a][b]);
+                }
         }
     };
-    fetch(gwA, gxA, 0);
-    if (GBK < KT) fetch(gwB, gxB, GBK);
-    for (int k0 = 0; k0 < KT; k0 += 2 * GBK) {
-        step(gwA, gxA, k0 + 2 * GBK);
-        if (k0 + GBK < KT) step(gwB, gxB, k0 + 3 * GBK);
+    if (PREC) {
+        Tile tA;
+        fetch(tA, 0);
+        for (int k0 = 0; k0 < K; k0 += GBK) step(tA, k0 + GBK);
+    } else {
+        Tile tA, tB;
+        fetch(tA, 0);
+        if (GBK < K) fetch(tB, GBK);
+        for (int k0 = 0; k0 < K; k0 += 2 * GBK) {
+            step(tA, k0 + 2 * GBK);
+            if (k0 + GBK < K) step(tB, k0 + 3 * GBK);
+        }
     }
     // D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh: four consecutive n per reg group
 #pragma unroll

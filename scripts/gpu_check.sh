@@ -9,10 +9,10 @@ step() {   # name, timeout, command...
     echo "== $name $(date +%T)"
     timeout -k 10 "$t" "$@" > "gpurun_out/$name.log" 2> "gpurun_out/$name.err"
     local rc=$?
-    echo "   rc=$rc"; tail -n 15 "gpurun_out/$name.log"
+    echo "   rc=$rc"; tail -n 12 "gpurun_out/$name.log" | cut -c1-1500
     if [ $rc -ne 0 ]; then tail -n 30 "gpurun_out/$name.err"; fi
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$name timed out: stopping"; exit $rc; fi
     return 0
 }
-step pytest 1000 python -m pytest tests -m gpu -q --durations=15 "$@"
-step bench 300 python bench.py --steps 100 --warmup 10
+step pytest 1000 python -m pytest tests -m gpu -q --durations=8 "$@"
+step bench 400 python bench.py --steps 150 --warmup 15

@@ -56,7 +56,7 @@ def test_defaults_and_workloads():
 
 
 def test_traffic_figure_is_keyed_on_the_kernel_sources():
-    """profiles/r03_hbm_traffic_<config>.json carries the fingerprint of the sources it was measured on and the workload; bench.py
+    """profiles/r04_hbm_traffic_<config>.json carries the fingerprint of the sources it was measured on and the workload; bench.py
     and the summariser compute the fingerprint the same way (bench.py reports `roofline.traffic` only while both agree)."""
     import bench
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -65,7 +65,7 @@ def test_traffic_figure_is_keyed_on_the_kernel_sources():
     assert fp == summarize_pmc.source_fingerprint() and len(fp) == 16
     for cfg, march in (("lego16k", "k4f_fan_march<3>"), ("truck32k", "k4f_fan_march<3>"), ("bicycle64k", "k4b_appearance12<27>"),
                        ("lego_b64", "k4f_fan_march<3>"), ("lego540k", "k4f_fan_march<3>")):
-        j = json.load(open(os.path.join(ROOT, "profiles", f"r03_hbm_traffic_{cfg}.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", f"r04_hbm_traffic_{cfg}.json")))
         assert j["config"] == cfg and len(j["source_sha16"]) == 16
         for k in ("k5_trunk_h<1, 1, 2>", march):
             assert j["kernels"][k]["hbm_bytes_per_launch"] > 0 and j["kernels"][k]["valu_wave_insts"] > 0, (cfg, k)

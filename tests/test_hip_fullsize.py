@@ -325,7 +325,7 @@ def test_top100_exactness_per_arithmetic(dev, idw):
     images against one full-size ray set (lego16k), the same rays for every mode: IFF_GEMM_F32 (v_mfma_f32_32x32x2_f32, a
     k-ordered fmaf chain, unfolded heads), IFF_GEMM_BF16X3 (six bf16 products per product block) and IFF_GEMM_F16X2 (three fp16
     products; the default).  Every list must be the oracle's up to near-tie pairs (assert_topk_matches); the count of identical
-    lists per mode goes to gpurun_out/fullsize_parity.json -> profiles/r03_fullsize_parity.json (identification_module.py:207)."""
+    lists per mode goes to gpurun_out/fullsize_parity.json -> profiles/r04_fullsize_parity.json (identification_module.py:207)."""
     from iffnerf_amd import hip_identify as H
     from iffnerf_amd.pipeline import PosePipeline
     from oracle import identify as oid
