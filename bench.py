@@ -214,7 +214,7 @@ def main():
     # issued eagerly between them (N > 1), replayed round-robin on their own streams, so the latency-bound surface sampler
     # of one step overlaps the throughput-bound stages of another.  Every replay bumps a device-side counter that is added
     # to the sampler seeds: no two steps draw the same rays.  At N > 1 all steps use the one default process group, so
-    # every rank issues the collectives in the same order.  With the persistent form of the sampler (IFF_SAMPLER_PERSISTENT=1) the
+    # every rank issues the collectives in the same order.  With the persistent form of the sampler (a field handle made with sampler_persistent=True) the
     # samplers of all in-flight steps must be co-resident (their workgroups meet at in-kernel barriers): the count is clamped to
     # what the device holds; the default chain of short launches has no such limit.
     n_sampler_runs = 1 if shared else B
@@ -498,7 +498,7 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     if plan != 3:
         # the reference's head shape runs in the 8-lanes-per-ray form (k_ref_shade_oct); other shapes in the 16-lane vector form
         shade_tr = traffic("k_ref_shade_oct<true>")
-        shade_name = "k_ref_shade_oct<true>" if shade_tr is not None or os.environ.get("IFF_REF_SHADE_GROUP16", "0") != "1" else "k_ref_shade<27, true>"
+        shade_name = "k_ref_shade_oct<true>"
         others[shade_name] = {"avg_launch_ms": round(march_launch_ms[2], 4),
                               "traffic": shade_tr if shade_name.startswith("k_ref_shade_oct") else traffic("k_ref_shade<27, true>"),
                               "note": "Ref head per ray (ref.py:103-152): bottleneck on the fp32 matrix cores, the rest vector ALU from LDS-staged weights, no roofline"}
@@ -534,7 +534,7 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
         result["warm_poses_per_s"] = round(n_w * WQ / (time.perf_counter() - tw), 2)
         # image in -> pose out: 800 x 800 query images + alpha masks through resize / crop / normalise, the ViT-S/14
         # backbone (DINOv2's architecture; seeded stand-in weights -- the real ones are not available offline), token assembly and
-        # stage C against the resident rays -- ONE captured graph per batch of 16 images, 4 in flight.  Headline figure: the backbone
+        # stage C against the resident rays -- ONE captured graph per batch of 32 images, 4 in flight.  Headline figure: the backbone
         # on the matrix cores (iff_vit_forward, bf16 operands, fp32 accumulate); beside it the same module as stock fp32 torch ops.
         from iffnerf_amd.image_frontend import ImageFrontEnd
         from iffnerf_amd.pipeline import CapturedImageQuery

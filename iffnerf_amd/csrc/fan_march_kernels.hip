@@ -920,14 +920,14 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     // ---------------------------------------------------------------------------------------------------- phase E: the Ref head
     // (models/ref.py:103-152; the separate launch k_ref_shade spends 16 lanes per ray on it.)  The bottleneck (feature_c rows over
     // the ray's 27 features) runs as W[32 rows][28] x F^T[28][32 rays] tiles on the fp32 matrix cores (the same k-ordered fmaf
-    // chain as the vector code: identical bits), one 32-row block per wave; eight lanes per ray then finish it (ref_head_oct).
+    // chain as the vector code: identical bits), one 32-row block per wave; four lanes per ray then finish it (ref_head_quad).
     constexpr int BLD = 164;                           // floats per ray in s_b: 160 rows + 4 (16-B aligned rows, spread over the banks)
     float* const s_b = s_pool + 5120;                  // behind the output rows
     static_assert(4 * 32 * 32 + 32 * 28 <= 5120 && 5120 + 32 * BLD + 680 + 296 <= PATCH_FLOATS + FR * FS * REC, "phase E operands fit the pool");
     const HeadOff ho = head_offsets(f.app_dim, f.feature_c);
     const int fc = f.feature_c;
     float* const s_tail = s_b + 32 * BLD;              // the head from spec_w on (spec_w, spec_b, ide_mat) ...
-    float* const s_small = s_tail + 680;               // ... and up to bott_w (the small heads): what ref_head_oct reads per lane
+    float* const s_small = s_tail + 680;               // ... and up to bott_w (the small heads): what ref_head_quad reads per lane
     {
         const int n_tail4 = (ho.total - ho.spec_w) / 4, n_small4 = ho.bott_w / 4;         // <= 170 + 74 <= NT (fan_head_fusable)
         if (tid < n_tail4) *reinterpret_cast<f32q*>(s_tail + 4 * tid) = stage_pre;

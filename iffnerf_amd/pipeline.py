@@ -179,7 +179,7 @@ class PosePipeline:
 
     def max_steps_in_flight(self, gen_points: int, batch: int = 1) -> int:
         """How many query graphs (each running ``batch`` samplers) may be in flight at once.  The default sampler (a chain of short
-        launches) sets no limit; the persistent form's workgroups (IFF_SAMPLER_PERSISTENT=1) meet at in-kernel barriers, so the
+        launches) sets no limit; the persistent form's workgroups (a handle made with sampler_persistent=True) meet at in-kernel barriers, so the
         samplers of ALL in-flight graphs must then fit on the device together (iff_surface_sample_residency)."""
         wgs, capacity = self.field.sampler_residency(gen_points, batch)
         return max(1, capacity // max(1, wgs * batch))

@@ -171,13 +171,15 @@ int32_t iff_march_default_samples(const iff_field* f, int32_t mode);
  *   IFF_MARCH_PLAN_FAN      two launches: the fused fan kernel + Ref head (models/ref.py:103-152).  Rays are taken 27 at a time (one iso-cell fan of
  *                           pose_estimation/sampling.py:442-488 when they come from iff_isocell_emit); the table patches the 540
  *                           samples of a tile touch are staged once in LDS and density, compositing, appearance and basis_mat run
- *                           from there.  Chosen for the point-centred 20-sample march of a field without unisphere contraction
- *                           whose ten steps span about five texels (every reference config); any rays are accepted -- a tile
+ *                           from there.  Chosen for the point-centred 20-sample march of a field whose ten steps span about five
+ *                           texels per axis (every aabb config of the reference; under unisphere contraction the reference halves
+ *                           the grid in the step, tensorBase.py:361, so its fans span ~21 texels and keep the general plan) and
+ *                           whose descriptor leaves density_lanes at 0; any rays are accepted -- a tile
  *                           whose samples do not fit one patch is gathered from global memory by the same kernel, same results.
  *   IFF_MARCH_PLAN_FAN_HEAD one launch: the fan kernel also runs the Ref head and the background blend of its 27 rays (the
  *                           bottleneck rows on the fp32 matrix cores) -- iff_march_shade under the conditions of
  *                           IFF_MARCH_PLAN_FAN when the head has the reference's shape (27 features, feature_c a multiple of 32
- *                           up to 128).  iff_march_features (no colours) runs the same kernel without that phase.
+ *                           up to 128) and the descriptor leaves head_lanes at 0.  iff_march_features (no colours) runs the same kernel without that phase.
  * All plans produce the same alpha / acc / depth / sample counters bit for bit; the fan plans' colours are bit-identical to each
  * other and agree with the general plan's to fp32 summation order. */
 #define IFF_MARCH_PLAN_GENERAL  0
@@ -236,7 +238,7 @@ int iff_surface_sample(const iff_field* f, int64_t P, int32_t n_epochs, int32_t 
 /* The sampler runs as a chain of short launches (seeds; per epoch 8 (first epoch) or 5 iteration launches, a finisher for the rare run that needs
  * more, the apply step), the kernel boundary being the grid barrier of sampling.py:143-213's loop: no workgroup waits for another
  * one and nothing has to be resident together -- device_capacity is then INT32_MAX and wgs_per_run the workgroups of one run's
- * iteration launch.  With IFF_SAMPLER_PERSISTENT=1 in the environment the sampler is ONE persistent launch whose workgroups meet
+ * iteration launch.  On a handle made with iff_field_desc.sampler_persistent = 1 the sampler is ONE persistent launch whose workgroups meet
  * at in-kernel barriers; all of them must then be resident together: device_capacity = sampler workgroups the device holds at
  * once (from the kernel's register / LDS footprint), and a caller that keeps several sampler launches in flight (streams, graphs)
  * must keep sum(B * wgs_per_run) <= device_capacity; one batched launch clamps itself.  Both forms draw the same samples bit for bit. */
