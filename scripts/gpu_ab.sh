@@ -6,6 +6,6 @@ for rep in 1 2; do
 for lib in base "$@"; do
   if [ "$lib" = base ]; then unset IFF_LIB_PATH; else export IFF_LIB_PATH="$PWD/$lib"; fi      # never copied over the product library
   echo "== $lib"
-  IFF_MARCH_FAN=${FAN:-2} timeout -k 10 300 python scripts/time_march.py ${CFG:-lego16k} 2>/dev/null
+  timeout -k 10 300 python scripts/time_march.py ${CFG:-lego16k} 2>/dev/null
 done
 done

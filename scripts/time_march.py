@@ -1,5 +1,5 @@
 """Time the point-centred march of the bench workload (16 cold queries' rays per launch) per launch stage.
-    IFF_MARCH_FAN=0|1|2 python scripts/time_march.py [config]      (dev aid; not part of the product or the tests)"""
+    [IFF_LIB_PATH=build/lib_x.so] python scripts/time_march.py [config]      (dev aid; not part of the product or the tests)"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,7 +32,7 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 c = out[4].double().sum(0)
-print(json.dumps({"config": cfg, "fan": os.environ.get("IFF_MARCH_FAN", "default"), "rays": rays.shape[0],
+print(json.dumps({"config": cfg, "plan": pipe.field.march_plan(0, 20), "lib": os.environ.get("IFF_LIB_PATH", "in-tree"), "rays": rays.shape[0],
                   "stage_ms": [round(t, 4) for t in tot], "march_ms": round(e0.elapsed_time(e1) / n, 4),
                   "valid_per_ray": round(c[0].item() / rays.shape[0], 2), "shaded_per_ray": round(c[1].item() / rays.shape[0], 2),
                   "rgb_sum": float(out[0].double().sum())}))
