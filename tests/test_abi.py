@@ -52,6 +52,16 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.iff_march_shade(None, None, 6, 4, 0, 20, None, None, None, None, None, None, None, 0, None) != 0
     with pytest.raises(RuntimeError):
         _lib.check(L.iff_attn_logits(None, None, 4, 4, 7, 1.0, None, None, None, 0, None), "iff_attn_logits")
+    # the merges of the ray-sharded path: sizes are validated before anything is launched; empty inputs are no-ops
+    assert L.iff_merge_row_stats(None, 0, 5, None, None, None) != 0 and b"bad argument" in L.iff_last_error()
+    assert L.iff_merge_row_stats(None, 2, 5, None, None, None) != 0 and b"null" in L.iff_last_error()
+    assert L.iff_merge_row_stats(None, 2, 0, None, None, None) == 0
+    assert L.iff_pack_candidates(None, None, None, None, 0, 3, 101, 100, 0, None, None) != 0          # kl > k
+    assert L.iff_pack_candidates(None, None, None, None, 0, 0, 0, 100, 0, None, None) == 0            # no queries
+    assert L.iff_merge_candidates(None, 100, 4, 0, 4, 100, None, None, None, None, None) != 0 and b"exceed" in L.iff_last_error()
+    assert L.iff_merge_candidates(None, 8, 4, 2, 3, 100, None, None, None, None, None) != 0            # window past the message
+    assert L.iff_merge_candidates(None, 8, 4, 0, 0, 100, None, None, None, None, None) == 0
+    assert L.iff_mask_occupied(None, None, 3, None, None) != 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
