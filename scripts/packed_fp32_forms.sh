@@ -5,6 +5,7 @@
 #   gpurun -- 'bash scripts/packed_fp32_forms.sh run'     on the GPU box: the stage-level replay-against-eager check under each
 # Result of the round-4 runs (2 000 checked steps each, truck32k, four graphs in flight): compiler packing 14 mismatches (rays 6, 7 /
 # 14, 15 / 22, 23 of one of the last ~300 tiles each); every hand-placed form 0; no packed fp32 at all (the product build) 0.
+# The object-file and basic-block hybrids that separated victim (march kernel) and aggressor (trunk kernel): scripts/asm_variant.py.
 set -u
 cd "$(dirname "$0")/.."
 PK="-Xclang -target-feature -Xclang +packed-fp32-ops"
