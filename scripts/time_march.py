@@ -14,6 +14,15 @@ pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(cfg), syntheti
 QB, P = wl["queries"] if not wl["shared_rays"] else 1, wl["gen_points"]
 samples, _, _ = pipe.field.surface_sample_batched(QB, P, pipe.rho, 4, 200, seed=5000)
 samples = samples.reshape(QB * P, 3)
+if os.environ.get("SORT"):          # experiment: fans in a spatially coherent order (Morton code of a 2^k grid over the samples' extent)
+    k = int(os.environ["SORT"])
+    lo_, hi_ = samples.min(0).values, samples.max(0).values
+    q = ((samples - lo_) / (hi_ - lo_ + 1e-9) * (1 << k)).long().clamp(0, (1 << k) - 1)
+    key = torch.zeros(samples.shape[0], dtype=torch.long, device=samples.device)
+    for b in range(k):
+        for ax in range(3):
+            key |= ((q[:, ax] >> b) & 1) << (3 * b + ax)
+    samples = samples[torch.argsort(key)]
 normals = pipe.field.point_normals(samples)
 ori, dirs, rays = isocell_emit(pipe.cells, samples, normals, want_rays6=True)
 tot = [0.0, 0.0, 0.0]
