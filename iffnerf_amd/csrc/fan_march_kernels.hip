@@ -461,6 +461,19 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     __shared__ float s_ray[FR * 8];
     __shared__ int s_box[8];
     const int tid = threadIdx.x;
+    // Two experiment builds behind DESIGN.md section 4 ("where it stands"); never defined in the product:
+    //   -DFAN_PAD_LDS=bytes  LDS nobody uses, so that fewer tiles fit a CU (30000: two, 50000: one): 0.98 / 1.30 / 2.35 ms per launch
+    //   -DFAN_SLEEP=n        every wave idles n x 64 clocks first (holds its slot, uses no unit): +4.1 k / 8.2 k / 16.4 k clocks on a
+    //                        tile of 89.8 k cost +3.5 / 6.6 / 12.2 % -- three quarters of what pure latency-boundness would cost
+#ifdef FAN_PAD_LDS
+    __shared__ int s_pad[FAN_PAD_LDS / 4];
+    if (a.R < 0) s_pad[threadIdx.x] = 1;
+    if (a.R < -1) a.counts[0] = s_pad[(threadIdx.x * 7) % (FAN_PAD_LDS / 4)];
+#endif
+#ifdef FAN_SLEEP
+#pragma unroll
+    for (int i = 0; i < FAN_SLEEP / 64; ++i) __builtin_amdgcn_s_sleep(64);
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int g = tid >> 3, h = (tid >> 2) & 1, c = tid & 3;     // ray of the tile, sub-group, texel quarter
     const bool grp_on = g < FR;

@@ -4,6 +4,7 @@ Rule 1 -- no packed fp32 arithmetic.  The compiler's own v_pk_mul_f32 / v_pk_add
 fan march while an MFMA kernel shared the CU (csrc/fan_march_kernels.hip, lerp_plane_q): the library is built
 with -packed-fp32-ops (iffnerf_amd/build.py) and this test holds the line for every kernel of every translation unit.
 """
+import os
 import re
 
 import pytest
@@ -43,3 +44,19 @@ def test_the_hot_kernels_are_in_the_library_and_use_the_matrix_cores(kernels):
             assert any(i.startswith(mfma) for i in kernels[n]), (n, mfma)
     for sub in ("k_ss_iter", "k6_colsum", "k7_topk", "k_pose", "k0_mask_cells", "k_mask_occupied"):
         find(sub)
+
+
+def test_experiment_patches_still_apply():
+    """scripts/experiments/*.patch are measured negatives kept reproducible: each must apply to the kernel sources
+    as committed (`git apply --check` reads the patch and the tree, it needs no repository)."""
+    import glob
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("git") is None:
+        pytest.skip("no git")
+    patches = sorted(glob.glob(os.path.join(root, "scripts", "experiments", "*.patch")))
+    assert patches
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", p], cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stderr)
