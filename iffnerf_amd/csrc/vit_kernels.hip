@@ -200,8 +200,10 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e*
     typedef typename VT<PREC>::v8 bf16x8;                      // (the 16-byte operand vector of this precision)
     constexpr int MB = GBM / 64;                                // 32-token blocks per wave
     constexpr int NP = PREC ? 2 : 1;                            // operand planes
-    __shared__ __attribute__((aligned(16))) ET sW[NP][GBN][GLD];
-    __shared__ __attribute__((aligned(16))) ET sX[NP][GBM][GLD];
+    // one pool: the operand tiles, and after the k loop the waves' output tiles (PREC 1 epilogue below)
+    __shared__ __attribute__((aligned(16))) ET s_all[NP * (GBN + GBM) * GLD];
+    ET (*sW)[GBN][GLD] = reinterpret_cast<ET (*)[GBN][GLD]>(s_all);
+    ET (*sX)[GBM][GLD] = reinterpret_cast<ET (*)[GBM][GLD]>(s_all + NP * GBN * GLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = (wave & 1) * 64, wm = (wave >> 1) * (32 * MB);      // the wave's corner of the tile
     const int lr = lane & 31, lh = lane >> 5;
@@ -289,7 +291,86 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e*
             if (k0 + GBK < K) step(tB, k0 + 3 * GBK);
         }
     }
-    // D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh: four consecutive n per reg group
+    // D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh: four consecutive n per reg group.
+    // Stored from there, an instruction touches 32 token rows with 8 or 16 bytes each.  PREC 1 (two planes to write, 4-16 us of such
+    // stores per launch): every wave turns its 64-feature x 32 MB-token tile over in LDS (the operand tiles are done) and stores whole
+    // rows -- 128 B of a plane / 256 B of the residual stream per 8 / 16 lanes.  Same values, same rounding: only the path differs.
+    // (The V third of the QKV product is written transposed -- tokens contiguous -- which the register layout already is.)
+    if constexpr (PREC == 1 && EPI != EPI_EMBED) {
+        const bool by_rows = !(EPI == EPI_QKV && n0 / (N / 3) == 2);
+        if (by_rows) {
+            constexpr int TLD = 68;                        // floats per tile row: 64 + 4 (conflict-free 16-byte writes down a column of tokens)
+            static_assert(4 * 32 * MB * TLD * 4 <= (int)sizeof(s_all), "the four output tiles fit the operand pool");
+            float* const tile = reinterpret_cast<float*>(s_all) + wave * (32 * MB) * TLD;
+            __syncthreads();                               // every wave has read its last fragments
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int nl = 32 * a + 8 * g4 + 4 * lh;
+                        const float4 bi = *reinterpret_cast<const float4*>(e.bias + n0 + wn + nl);
+                        float v[4] = {acc[a][b][4 * g4] * e.wscale + bi.x, acc[a][b][4 * g4 + 1] * e.wscale + bi.y,
+                                      acc[a][b][4 * g4 + 2] * e.wscale + bi.z, acc[a][b][4 * g4 + 3] * e.wscale + bi.w};
+                        if (EPI == EPI_QKV) {
+                            const float sc = n0 < N / 3 ? e.qscale : 1.0f;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] *= sc;
+                        } else if (EPI == EPI_GELU) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752440f));
+                        }
+                        *reinterpret_cast<float4*>(tile + (32 * b + lr) * TLD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+            __syncthreads();
+            if (EPI == EPI_RESID) {
+                const int n4 = (lane & 15) * 4;
+                const float4 ls = *reinterpret_cast<const float4*>(e.ls + n0 + wn + n4);
+#pragma unroll
+                for (int it = 0; it < 8 * MB; ++it) {
+                    const int row = 4 * it + (lane >> 4);
+                    const int64_t m = m0 + wm + row;
+                    if (m >= M) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(tile + row * TLD + n4);
+                    float4* xp = reinterpret_cast<float4*>(e.x + m * N + n0 + wn + n4);
+                    float4 xv = *xp;
+                    xv.x = fmaf(ls.x, v.x, xv.x); xv.y = fmaf(ls.y, v.y, xv.y); xv.z = fmaf(ls.z, v.z, xv.z); xv.w = fmaf(ls.w, v.w, xv.w);
+                    *xp = xv;
+                }
+            } else {
+                const int n8 = (lane & 7) * 8;
+#pragma unroll
+                for (int it = 0; it < 4 * MB; ++it) {
+                    const int row = 8 * it + (lane >> 3);
+                    const int64_t m = m0 + wm + row;
+                    if (m >= M) continue;
+                    const float4 v0 = *reinterpret_cast<const float4*>(tile + row * TLD + n8);
+                    const float4 v1 = *reinterpret_cast<const float4*>(tile + row * TLD + n8 + 4);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    f16x8 h, l;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { _Float16 hh, ll; split_h(v[j], hh, ll); h[j] = hh; l[j] = ll; }
+                    _Float16* dst;
+                    int64_t at, lo_off;
+                    if (EPI == EPI_QKV) {
+                        const int D = N / 3, which = n0 / D, head = (n0 - which * D + wn) >> 6;       // a wave's 64 features are one head
+                        const int img = (int)(m / e.T), t = (int)(m - (int64_t)img * e.T);
+                        dst = reinterpret_cast<_Float16*>(which == 0 ? e.q : e.k);
+                        at = (((int64_t)(img * e.heads + head) * e.T + t) << 6) + n8;
+                        lo_off = e.qk_lo;
+                    } else {
+                        dst = reinterpret_cast<_Float16*>(e.out);
+                        at = m * N + n0 + wn + n8;
+                        lo_off = M * (int64_t)N;
+                    }
+                    *reinterpret_cast<f16x8*>(dst + at) = h;
+                    *reinterpret_cast<f16x8*>(dst + at + lo_off) = l;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
         const int64_t m = m0 + wm + 32 * b + lr;
@@ -461,34 +542,79 @@ __global__ void __launch_bounds__(256, 2) k_vit_attention(const __bf16* __restri
 }
 
 // The same attention with fp32-accurate products (PREC 1): Q, K, V^T arrive as fp16 hi / lo planes (the lo plane qk_lo / v_lo
-// elements behind the hi plane), S^T = Kh Qh + Kl Qh + Kh Ql and O^T = Vh Ph + Vl Ph + Vh Pl with P split in registers.  K's two
-// planes and then V^T's two planes pass through ONE LDS buffer (83 KB: one workgroup per CU), one after the other.
-__global__ void __launch_bounds__(256, 1) k_vit_attention_x2(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Kh, int64_t qk_lo,
+// elements behind the hi plane), S^T = Kh Qh + Kl Qh + Kh Ql and O^T = Vh Ph + Vl Ph + Vh Pl with P split in registers.  The keys
+// pass through ONE 46-KB LDS buffer in four pieces -- K of key blocks 0..4, K of blocks 5..8, V^T of blocks 0..4, V^T of blocks 5..8,
+// both planes each -- with all nine S blocks kept in registers in between: two workgroups per CU (with K and then V^T whole the
+// buffer was 83 KB: one), the same products in the same order.  The next piece travels in registers while the current one is multiplied.
+constexpr int AX_B0 = 5, AX_T0 = 32 * AX_B0;                 // key blocks / keys of the first piece (the second: 4 / 128)
+constexpr int AX_VLD = AX_T0 + 12;                           // V^T piece rows: 344 B (as AT_VLD: conflict-free ds_read_b64 down a column of d)
+constexpr int AX_KPL = AX_T0 * AT_KLD, AX_VPL = 64 * AX_VLD; // halves per plane of a piece
+__global__ void __launch_bounds__(256, 2) k_vit_attention_x2(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Kh, int64_t qk_lo,
                                                              const _Float16* __restrict__ Vh, int64_t v_lo, int T, int heads,
                                                              _Float16* __restrict__ out, int64_t out_lo) {
-    constexpr int K_PLANE = AT_TP * AT_KLD, V_PLANE = 64 * AT_VLD;
-    __shared__ __attribute__((aligned(16))) _Float16 s_buf[2 * (K_PLANE > V_PLANE ? K_PLANE : V_PLANE)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_buf[2 * (AX_KPL > AX_VPL ? AX_KPL : AX_VPL)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int ih = blockIdx.y;
     const int64_t base = (int64_t)ih * T * 64;
+    const _Float16* Vt = Vh + (int64_t)ih * 64 * AT_TP;
+    // piece h of K: keys t0 .. t0 + 32 nb - 1, eight 16-byte chunks per key and plane; of V^T: 4 nb chunks per feature row and plane
+    f16x8 pre[2][AX_B0];                                      // [plane][round]: 256 chunks per round
+    auto fetch_k = [&](int h) {
+        const int t0 = h ? AX_T0 : 0, nb = h ? AT_TP / 32 - AX_B0 : AX_B0;
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {                          // K planes: rows beyond T zero
-        f16x8 kv[9];
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const int chunk = tid + 256 * r, t = chunk >> 3, dc = (chunk & 7) * 8;
-            kv[r] = *reinterpret_cast<const f16x8*>(Kh + pl * qk_lo + base + min(t, T - 1) * 64 + dc);
-        }
+            for (int r = 0; r < AX_B0; ++r)
+                if (r < nb) {
+                    const int chunk = tid + 256 * r, t = t0 + (chunk >> 3), dc = (chunk & 7) * 8;
+                    pre[pl][r] = *reinterpret_cast<const f16x8*>(Kh + pl * qk_lo + base + min(t, T - 1) * 64 + dc);
+                }
+    };
+    auto store_k = [&](int h) {
+        const int t0 = h ? AX_T0 : 0, nb = h ? AT_TP / 32 - AX_B0 : AX_B0;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const int chunk = tid + 256 * r, t = chunk >> 3, dc = (chunk & 7) * 8;
-            if (t >= T) {
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) kv[r][i] = (_Float16)0.0f;
-            }
-            *reinterpret_cast<f16x8*>(&s_buf[pl * K_PLANE + t * AT_KLD + dc]) = kv[r];
-        }
-    }
+            for (int r = 0; r < AX_B0; ++r)
+                if (r < nb) {
+                    const int chunk = tid + 256 * r, tl = chunk >> 3, dc = (chunk & 7) * 8;
+                    f16x8 v = pre[pl][r];
+                    if (t0 + tl >= T) {                       // rows beyond T: zero
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = (_Float16)0.0f;
+                    }
+                    *reinterpret_cast<f16x8*>(&s_buf[pl * AX_KPL + tl * AT_KLD + dc]) = v;
+                }
+    };
+    auto fetch_v = [&](int h) {
+        const int t0 = h ? AX_T0 : 0, nb = h ? AT_TP / 32 - AX_B0 : AX_B0;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int r = 0; r < AX_B0; ++r)
+                if (r < nb) {
+                    const int chunk = tid + 256 * r, d = chunk / (4 * nb), c8 = chunk - d * (4 * nb);
+                    pre[pl][r] = *reinterpret_cast<const f16x8*>(Vt + pl * v_lo + d * AT_TP + t0 + 8 * c8);
+                }
+    };
+    auto store_v = [&](int h) {
+        const int t0 = h ? AX_T0 : 0, nb = h ? AT_TP / 32 - AX_B0 : AX_B0;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int r = 0; r < AX_B0; ++r)
+                if (r < nb) {
+                    const int chunk = tid + 256 * r, d = chunk / (4 * nb), c8 = chunk - d * (4 * nb);
+                    f16x8 v = pre[pl][r];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)               // columns beyond T hold whatever the workspace held: P is 0 there, 0 x NaN is not
+                        if (t0 + 8 * c8 + i >= T) v[i] = (_Float16)0.0f;
+                    f16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f16x4*>(&s_buf[pl * AX_VPL + d * AX_VLD + 8 * c8]) = lo4;      // rows of 344 B: 8-byte aligned pieces
+                    *reinterpret_cast<f16x4*>(&s_buf[pl * AX_VPL + d * AX_VLD + 8 * c8 + 4]) = hi4;
+                }
+    };
+    fetch_k(0);
     const int q = blockIdx.x * 128 + wave * 32 + lr;
     const int qc = min(q, T - 1);
     f16x8 fq[2][4];
@@ -496,40 +622,29 @@ __global__ void __launch_bounds__(256, 1) k_vit_attention_x2(const _Float16* __r
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fq[pl][ks] = *reinterpret_cast<const f16x8*>(Qh + pl * qk_lo + base + qc * 64 + 16 * ks + 8 * lh);
-    __syncthreads();
     f32x16 S[AT_TP / 32];
 #pragma unroll
-    for (int b = 0; b < AT_TP / 32; ++b) {
+    for (int h = 0; h < 2; ++h) {
+        store_k(h);
+        __syncthreads();
+        if (h == 0) fetch_k(1); else fetch_v(0);             // the next piece, in flight under this piece's products
+        const int b0 = h ? AX_B0 : 0, nb = h ? AT_TP / 32 - AX_B0 : AX_B0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[b][r] = 0.0f;
+        for (int bl = 0; bl < AX_B0; ++bl)
+            if (bl < nb) {
+                const int b = b0 + bl;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f16x8 kh = *reinterpret_cast<const f16x8*>(&s_buf[(32 * b + lr) * AT_KLD + 16 * ks + 8 * lh]);
-            const f16x8 kl = *reinterpret_cast<const f16x8*>(&s_buf[K_PLANE + (32 * b + lr) * AT_KLD + 16 * ks + 8 * lh]);
-            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, fq[0][ks], S[b], 0, 0, 0);      // the small terms first
-            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, fq[1][ks], S[b], 0, 0, 0);
-            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, fq[0][ks], S[b], 0, 0, 0);
-        }
-    }
-    __syncthreads();                                         // every wave has read K: V^T's planes go over it
-    {
-        const _Float16* Vt = Vh + (int64_t)ih * 64 * AT_TP;
+                for (int r = 0; r < 16; ++r) S[b][r] = 0.0f;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            f16x8 vv[9];
-#pragma unroll
-            for (int r = 0; r < 9; ++r) vv[r] = *reinterpret_cast<const f16x8*>(Vt + pl * v_lo + (tid + 256 * r) * 8);
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const int chunk = tid + 256 * r, d = chunk / 36, t8 = (chunk - d * 36) * 8;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (t8 + i >= T) vv[r][i] = (_Float16)0.0f;
-                f16x4 lo4 = {vv[r][0], vv[r][1], vv[r][2], vv[r][3]}, hi4 = {vv[r][4], vv[r][5], vv[r][6], vv[r][7]};
-                *reinterpret_cast<f16x4*>(&s_buf[pl * V_PLANE + d * AT_VLD + t8]) = lo4;
-                *reinterpret_cast<f16x4*>(&s_buf[pl * V_PLANE + d * AT_VLD + t8 + 4]) = hi4;
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(&s_buf[(32 * bl + lr) * AT_KLD + 16 * ks + 8 * lh]);
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(&s_buf[AX_KPL + (32 * bl + lr) * AT_KLD + 16 * ks + 8 * lh]);
+                    S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, fq[0][ks], S[b], 0, 0, 0);      // the small terms first
+                    S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, fq[1][ks], S[b], 0, 0, 0);
+                    S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, fq[0][ks], S[b], 0, 0, 0);
+                }
             }
-        }
+        __syncthreads();                                     // every wave has read this piece: the next goes over it
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -549,34 +664,44 @@ __global__ void __launch_bounds__(256, 1) k_vit_attention_x2(const _Float16* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) { S[b][r] = expf(S[b][r] - mx); sum += S[b][r]; }
     sum += __shfl_xor(sum, 32, 64);
-    __syncthreads();
     f32x16 O[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[a][r] = 0.0f;
 #pragma unroll
-    for (int b = 0; b < AT_TP / 32; ++b)
+    for (int h = 0; h < 2; ++h) {
+        store_v(h);
+        __syncthreads();
+        if (h == 0) fetch_v(1);
+        const int b0 = h ? AX_B0 : 0, nb = h ? AT_TP / 32 - AX_B0 : AX_B0;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            f16x8 ph, pl;
+        for (int bl = 0; bl < AX_B0; ++bl)
+            if (bl < nb) {
+                const int b = b0 + bl;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { _Float16 h, l; split_h(S[b][8 * s2 + j], h, l); ph[j] = h; pl[j] = l; }
-            const int t0 = 32 * b + 16 * s2 + 4 * lh;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    f16x8 ph, pl;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                f16x8 fv[2];
+                    for (int j = 0; j < 8; ++j) { _Float16 hh, ll; split_h(S[b][8 * s2 + j], hh, ll); ph[j] = hh; pl[j] = ll; }
+                    const int t0 = 32 * bl + 16 * s2 + 4 * lh;
 #pragma unroll
-                for (int p2 = 0; p2 < 2; ++p2) {
-                    const f16x4 v0 = *reinterpret_cast<const f16x4*>(&s_buf[p2 * V_PLANE + (32 * a + lr) * AT_VLD + t0]);
-                    const f16x4 v1 = *reinterpret_cast<const f16x4*>(&s_buf[p2 * V_PLANE + (32 * a + lr) * AT_VLD + t0 + 8]);
-                    fv[p2] = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    for (int a = 0; a < 2; ++a) {
+                        f16x8 fv[2];
+#pragma unroll
+                        for (int p2 = 0; p2 < 2; ++p2) {
+                            const f16x4 v0 = *reinterpret_cast<const f16x4*>(&s_buf[p2 * AX_VPL + (32 * a + lr) * AX_VLD + t0]);
+                            const f16x4 v1 = *reinterpret_cast<const f16x4*>(&s_buf[p2 * AX_VPL + (32 * a + lr) * AX_VLD + t0 + 8]);
+                            fv[p2] = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        }
+                        O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[1], ph, O[a], 0, 0, 0);
+                        O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[0], pl, O[a], 0, 0, 0);
+                        O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[0], ph, O[a], 0, 0, 0);
+                    }
                 }
-                O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[1], ph, O[a], 0, 0, 0);
-                O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[0], pl, O[a], 0, 0, 0);
-                O[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[0], ph, O[a], 0, 0, 0);
             }
-        }
+        if (h == 0) __syncthreads();
+    }
     if (q < T) {
         const float inv = 1.0f / sum;
         const int64_t img = ih / heads;
