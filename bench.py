@@ -19,7 +19,8 @@ Step = one pass of the hot path over one batch of synthetic queries, COLD: stage
 softmax over rays, column-sum score, top-100, closed-form pose) all run inside the step; nothing is cached between steps
 but the model tables.  For the cold configs every query of the batch draws its OWN ray set (`--batch`, default 16 queries
 per step and rank); for lego_b64 the 64 queries of a step share one freshly emitted ray set (the reference's eval semantics).
-`value` counts poses: queries per step x steps / time.
+`value` counts poses: queries per step x steps / time.  Timing: SETTLE_STEPS - W untimed steps, the W warm-up steps, then EXACTLY K steps
+between two barriers (the settling is there because W = 5 steps are 10 ms of GPU time: not enough for the chip's clocks).
 
 N > 1 is the SAME workload, weak scaling: every rank owns `--batch` cold queries per step (N x batch per step in all), and
 EVERY query's ray set is sharded over all N ranks (contiguous blocks of its surface points): a rank draws the points of its
@@ -47,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 M_TOKENS = 256
 TOPK = 100
+SETTLE_STEPS = 100          # untimed steps (incl. the W warm-up steps) before the timed region: see the comment at the timed loop
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CLOCK_GHZ = 2.4                  # MI355X_MICROARCH.md: maximum clock
 L1_PEAK_GBS = 256 * 64 * CLOCK_GHZ      # 256 CUs x 64 B/clk of the vector L1 / texture path = 39.3 TB/s
@@ -260,10 +262,17 @@ def main():
                 part(i + 1, True)
             part(i, False)
 
-    run_steps(0, args.warmup)
+    # Untimed settling before the W warm-up steps: with a short warm-up (the driver's W = 5 is 10 ms of GPU time) the first timed
+    # steps still run at the clocks the chip idled at, and three of the four graphs have been replayed once: measured on one box,
+    # K = 20 after W = 5 reads 14 650-14 970 poses/s, after W = 100 15 310-15 370, K = 200 after W = 20 15 370-15 450.  The timed
+    # region is unchanged: exactly K steps between two barriers; `config.settle_steps` says how many untimed steps came before W.
+    settle = max(0, SETTLE_STEPS - args.warmup)
+    run_steps(0, settle)
+    barrier()
+    run_steps(settle, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
+    run_steps(settle + args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if sharded:
@@ -311,7 +320,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s, M=%d tokens, top-%d, cold path (A+B+C every step)" % (args.config, wl["describe"], M_TOKENS, TOPK),
                        "queries_per_step": queries_per_step, "queries_per_step_per_gpu": B if not shared else None,
-                       "rays_per_query": n_rays, "steps_in_flight": in_flight,
+                       "rays_per_query": n_rays, "steps_in_flight": in_flight, "settle_steps": settle,
                        "emissions_per_step": 1 if shared else queries_per_step,
                        "gemm": pipe.idnet.gemm_description(), "launch": launch,
                        "parallelism": "single GPU" if world_size == 1 else
