@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=SETTLE_STEPS,
+                    help="untimed steps before the timed region, the --warmup steps included (profiling passes use 0: under --pmc a step takes 10-100x longer)")
     ap.add_argument("--config", default="lego16k", choices=("lego16k", "truck32k", "bicycle64k", "lego_b64", "lego540k"),
                     help="BASELINE.json workload (default: configs[1], the one the metric is quoted on)")
     ap.add_argument("--in-flight", type=int, default=4, help="steps kept in flight on separate streams")
@@ -266,7 +268,7 @@ def main():
     # steps still run at the clocks the chip idled at, and three of the four graphs have been replayed once: measured on one box,
     # K = 20 after W = 5 reads 14 650-14 970 poses/s, after W = 100 15 310-15 370, K = 200 after W = 20 15 370-15 450.  The timed
     # region is unchanged: exactly K steps between two barriers; `config.settle_steps` says how many untimed steps came before W.
-    settle = max(0, SETTLE_STEPS - args.warmup)
+    settle = max(0, args.settle - args.warmup)
     run_steps(0, settle)
     barrier()
     run_steps(settle, args.warmup)

@@ -351,22 +351,21 @@ __global__ void __launch_bounds__(256, K4B_WAVES) k4b_appearance12(FieldDev f, M
             mask &= mask - 1ull;
             const int j = sidx >= 2 * NL ? 2 : (sidx >= NL ? 1 : 0);
             const int src = g0 + (sidx - NL * j);
-            float w = 0.0f;
+            // the ray's twelve lanes agree on (j, src): every lane picks ITS OWN slot j first and one cross-lane move per value follows
+            // (twelve moves -- LDS round trips -- and the picks after them before: 4.2e7 LDS instructions per bicycle64k launch)
+            float w = wreg[0];
 #pragma unroll
-            for (int jj = 0; jj < NW; ++jj) {
-                const float vj = __shfl(wreg[jj], src, 64);
-                w = (j == jj) ? vj : w;
-            }
+            for (int jj = 1; jj < NW; ++jj) w = (j == jj) ? wreg[jj] : w;
+            w = __shfl(w, src, 64);
             float xn[3];
             if (f.unisphere) {
-                xn[0] = xn[1] = xn[2] = 0.0f;
 #pragma unroll
-                for (int jj = 0; jj < NW; ++jj)
+                for (int ax = 0; ax < 3; ++ax) {
+                    float v = xs[0][ax];
 #pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        const float vj = __shfl(xs[jj][ax], src, 64);
-                        xn[ax] = (j == jj) ? vj : xn[ax];
-                    }
+                    for (int jj = 1; jj < NW; ++jj) v = (j == jj) ? xs[jj][ax] : v;
+                    xn[ax] = __shfl(v, src, 64);
+                }
             } else {
                 const float z = z_of(f, 0, S, 0.0f, sidx);
                 const float p[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z};

@@ -13,7 +13,7 @@ rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 run() {   # name, rocprof args...
     local name=$1; shift
     echo "== pass $name $(date +%T)"
-    timeout -k 10 400 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o b -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline ${BENCH_EXTRA:-} "${ARGS[@]}" > "$OUT/$name.log" 2>&1
+    timeout -k 10 400 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o b -- python3 bench.py --steps 6 --warmup 2 --settle 0 --no-cpu-baseline ${BENCH_EXTRA:-} "${ARGS[@]}" > "$OUT/$name.log" 2>&1
     local rc=$?
     echo "   rc=$rc"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $name timed out: stopping"; exit $rc; fi
