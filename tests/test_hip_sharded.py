@@ -139,7 +139,8 @@ def test_rccl_rehearsal_keeps_the_single_graph_rate():
     import json
     import socket
     rates = {}
-    for name, extra in (("single_graph", []), ("sharded_ws1", ["--force-sharded"]), ("single_graph_again", [])):
+    # (alternating, two runs of each form, best of two against best of two: a box drifts by a few per cent within a minute)
+    for name, extra in (("single_graph", []), ("sharded_ws1", ["--force-sharded"]), ("single_graph_again", []), ("sharded_ws1_again", ["--force-sharded"])):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "120", "--warmup", "15", "--batch", "16", "--no-cpu-baseline",
@@ -151,7 +152,7 @@ def test_rccl_rehearsal_keeps_the_single_graph_rate():
             assert line["config"]["rccl_world_size"] == 1 and line["config"]["collective_backend"] == "nccl"
             rates["collective_us"] = line["config"]["collective_us"]
     base = max(rates["single_graph"], rates["single_graph_again"])
-    rates["ratio"] = rates["sharded_ws1"] / base
+    rates["ratio"] = max(rates["sharded_ws1"], rates["sharded_ws1_again"]) / base
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "rccl_rehearsal.json"), "w") as fh:
