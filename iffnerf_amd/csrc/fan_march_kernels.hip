@@ -96,7 +96,7 @@ __device__ __forceinline__ float xor4_dpp(float v) { return dpp_mov<0x141>(dpp_m
 // fp32 instruction is the rule that holds for all ~8 000 the compiler had placed in this library, and it costs nothing measurable
 // (14 590-14 760 poses/s without, 14 590-14 810 with, same box, same run).
 #if defined(FAN_LERP_ASM)
-// Experiment builds of the packed-fp32 investigation (need +packed-fp32-ops; scripts/gpu_r4_call2.sh ran them): the tap combination
+// Experiment builds of the packed-fp32 investigation (need +packed-fp32-ops; scripts/packed_fp32_forms.sh builds and runs them): the tap combination
 // as hand-placed v_pk_mul_f32 / v_pk_fma_f32 with the weight operand in a chosen form.  FAN_LERP_ASM = 1: op_sel broadcast of the low half, high half = a small integer (what the
 // compiler's own packing leaves there: an LDS address); 2: broadcast, high half = the weight again; 3: broadcast, high half = 1.0f;
 // 4: no op_sel, a real (w, w) pair; 6: broadcast with the weight as src0 (the form of the compositing-weight accumulate);
