@@ -265,3 +265,27 @@ def test_native_resize_crop_normalize_matches_the_torch_formulation(dev):
     torch.testing.assert_close(ta, tb, atol=2e-4, rtol=0)
     with pytest.raises(RuntimeError):
         resize_crop(torch.rand(1, 4000, 4000, 3, device=dev), 256, 224, True)          # scale 15.6: beyond the kernel's 32 taps
+
+
+@pytest.mark.gpu
+def test_native_vit_other_token_counts(dev):
+    """The attention kernel of the fp32 class passes the keys through LDS in four pieces (key blocks 0-4, then 5-8, of K and of V^T)
+    and masks what lies beyond the T tokens of the grid: grids whose tokens end inside the first piece (8 x 8: T = 65), exactly at its
+    end region (12 x 13: T = 157), inside the second (14 x 14: T = 197) and near the limit of 288 (16 x 17: T = 273) against the fp32
+    torch module on the same weights, both precisions."""
+    from iffnerf_amd.hip_vit import ViTHandle
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    net, _, _ = create_standin_backbone(seed=5)
+    net = net.to(dev)
+    gen = torch.Generator().manual_seed(4)
+    for gh, gw in ((8, 8), (12, 13), (14, 14), (16, 17)):
+        x = torch.randn(3, 3, 14 * gh, 14 * gw, generator=gen).to(dev)
+        with torch.no_grad():
+            want = net.forward_features(x)
+        ref, scale = want["x_norm_patchtokens"], float(want["x_norm_patchtokens"].abs().max())
+        tok, cls = ViTHandle(net.state_dict(), dev, grid=(gh, gw)).forward(x, want_cls=True)
+        assert tok.shape == (3, gh * gw, 384) and torch.isfinite(tok).all()
+        assert float((tok - ref).abs().max()) <= 1e-4 * scale, (gh, gw, float((tok - ref).abs().max()), scale)
+        assert float((cls - want["x_norm_clstoken"]).abs().max()) <= 1e-4 * scale
+        tok_b = ViTHandle(net.state_dict(), dev, grid=(gh, gw), precision="bf16").forward(x)
+        assert torch.isfinite(tok_b).all() and float((tok_b - ref).abs().max()) <= 4e-2 * scale, (gh, gw)
