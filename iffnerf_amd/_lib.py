@@ -14,11 +14,14 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# IFF_LIB_PATH: a development build (scripts/build_dev.sh -> build/lib_<tag>.so) loaded INSTEAD of the in-tree library, so A/B runs
-# never overwrite the product's .so; unset (the default, and what tests / bench / the driver use) -> the library next to this file
-LIB_PATH = os.environ.get("IFF_LIB_PATH") or os.path.join(_HERE, "libiffnerf_hip.so")
+# IFF_LIB_PATH: a development build (`python -m iffnerf_amd.build --tag NAME -- <flags>` -> build/lib_NAME.so, or scripts/build_one_tu.sh)
+# loaded INSTEAD of the in-tree library, so A/B runs never overwrite the product's .so; unset (the default, and what tests / bench /
+# the driver use) -> the library next to this file.  An override is never silent: `lib()` warns once and bench.py prints `dev_library`.
+PRODUCT_LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
+LIB_PATH = os.environ.get("IFF_LIB_PATH") or PRODUCT_LIB_PATH
+DEV_LIBRARY = os.path.abspath(LIB_PATH) != os.path.abspath(PRODUCT_LIB_PATH)
 _lib = None
-ABI_VERSION = 9          # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 10         # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -118,6 +121,7 @@ SIGNATURES = {
     "iff_vit_workspace": (_SZ, [_VP, _I32]),
     "iff_vit_forward": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _VP, _SZ, _VP]),
     "iff_image_resize_crop": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, c_float_p, c_float_p, _VP, _VP]),
+    "iff_image_resize_crop_rgba": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, c_float_p, c_float_p, _VP, _VP]),
     "iff_token_assemble": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _F, c_float_p, c_float_p, _VP, _VP, _VP]),
     "iff_mask_token_rows": (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
     "iff_ray_cache_bytes": (_SZ, [_VP, _I64]),
@@ -131,7 +135,8 @@ SIGNATURES = {
     "iff_pose_from_topk": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _I64, c_float_p, _VP, _VP, _VP]),
     "iff_attn_colsum_batched": (C.c_int, [_VP, _I32, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
     "iff_topk_batched": (C.c_int, [_VP, _I32, _I64, _I32, _VP, _VP, _VP]),
-    "iff_pose_from_topk_batched": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _I64, _I64, c_float_p, _VP, _VP]),
+    "iff_pose_from_topk_batched": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _I64, _I64, c_float_p, _VP, _VP, _VP]),
+    "iff_pose_errors": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _VP]),
 }
 
 
@@ -144,6 +149,9 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
                 "Build it with `python -m iffnerf_amd.build` (hipcc, gfx950).")
         import torch  # noqa: F401  (loads torch's HIP runtime first so both share one libamdhip64)
+        if os.path.abspath(LIB_PATH) != os.path.abspath(PRODUCT_LIB_PATH):
+            import warnings
+            warnings.warn(f"libiffnerf_hip: IFF_LIB_PATH is set -- loading the development build {LIB_PATH} instead of the product library")
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)

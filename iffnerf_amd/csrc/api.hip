@@ -905,12 +905,20 @@ extern "C" int iff_pose_from_topk(const int64_t* idx, const float* val, int32_t 
 
 extern "C" int iff_pose_from_topk_batched(const int64_t* idx, const float* val, int32_t Q, int32_t k, const float* rays_o,
                                           const float* rays_d, int64_t N, int64_t ray_batch_stride, const float* up_host,
-                                          float* c2w, void* stream) {
+                                          float* c2w, float* parts_opt, void* stream) {
     IFF_REQUIRE(Q >= 0 && ray_batch_stride >= 0, "iff_pose_from_topk_batched: bad batch");
     if (Q == 0) return 0;
     IFF_REQUIRE(idx && val && rays_o && rays_d && up_host && c2w, "iff_pose_from_topk_batched: null buffer");
     IFF_REQUIRE(k >= 1 && k <= 1024, "iff_pose_from_topk_batched: k = %d outside [1, 1024]", k);
-    IFF_HIP(launch_pose(idx, val, Q, k, rays_o, rays_d, N, ray_batch_stride, up_host, c2w, nullptr, (hipStream_t)stream));
+    IFF_HIP(launch_pose(idx, val, Q, k, rays_o, rays_d, N, ray_batch_stride, up_host, c2w, parts_opt, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_pose_errors(const float* c2w, const float* gt_c2w, const float* parts_opt, int32_t Q, int32_t k, float* summary, void* stream) {
+    IFF_REQUIRE(Q >= 0 && k >= 0 && k <= 1024, "iff_pose_errors: bad argument");
+    if (Q == 0) return 0;
+    IFF_REQUIRE(c2w && gt_c2w && summary, "iff_pose_errors: null buffer");
+    IFF_HIP(launch_pose_errors(c2w, gt_c2w, parts_opt, Q, k, summary, (hipStream_t)stream));
     return 0;
 }
 
@@ -1183,11 +1191,11 @@ extern "C" int iff_vit_create(const iff_vit_desc* d, void* stream, iff_vit** out
                 "iff_vit_create: null weight");
     const size_t D = d->dim, L = d->depth, F = d->mlp, T = 1 + (size_t)d->grid_h * d->grid_w;
     const size_t kraw = 3 * (size_t)d->patch * d->patch, kp = (kraw + 63) / 64 * 64;
-    iff_vit* v = new iff_vit();
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
     IFF_REQUIRE(d->precision == IFF_VIT_FP32 || d->precision == IFF_VIT_BF16, "iff_vit_create: precision %d is neither IFF_VIT_FP32 nor IFF_VIT_BF16", d->precision);
     IFF_REQUIRE(d->depth <= VIT_MAX_DEPTH, "iff_vit_create: depth %d exceeds %d", d->depth, VIT_MAX_DEPTH);
+    iff_vit* v = new iff_vit();                     // every descriptor check is above this line: nothing below returns without freeing v
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
     const bool split = d->precision == IFF_VIT_FP32;
     const size_t eb = split ? 4 : 2;               // bytes per weight: bf16, or fp16 hi + lo planes
     const size_t o_pw = take(D * kp * eb), o_qkv = take(L * 3 * D * D * eb), o_proj = take(L * D * D * eb), o_fc1 = take(L * F * D * eb),
@@ -1285,6 +1293,23 @@ extern "C" int iff_image_resize_crop(const float* src, int32_t Q, int32_t H, int
     const float sy = std::max((float)H / rh, 1.0f), sx = std::max((float)W / rw, 1.0f);
     if (2.0f * sup * std::max(sx, sy) + 2.0f > 32.0f)
         return fail(IFF_ERR_UNSUPPORTED, "iff_image_resize_crop: scale factor %.2f needs more than 32 filter taps", std::max(sx, sy));
-    IFF_HIP(launch_resize_crop(src, Q, H, W, C, rh, rw, top, left, ch, cw, cubic ? 1 : 0, mean, std, dst, (hipStream_t)stream));
+    IFF_HIP(launch_resize_crop(src, Q, H, W, C, 0, rh, rw, top, left, ch, cw, cubic ? 1 : 0, mean, std, dst, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int iff_image_resize_crop_rgba(const float* src, int32_t Q, int32_t H, int32_t W, int32_t mode, int32_t rh, int32_t rw, int32_t top,
+                                          int32_t left, int32_t ch, int32_t cw, int32_t cubic, const float* mean, const float* std, float* dst,
+                                          void* stream) {
+    IFF_REQUIRE(mode == IFF_RESIZE_RGB_ON_WHITE || mode == IFF_RESIZE_ALPHA, "iff_image_resize_crop_rgba: mode %d is neither IFF_RESIZE_RGB_ON_WHITE nor IFF_RESIZE_ALPHA", mode);
+    IFF_REQUIRE(Q >= 0 && H >= 1 && W >= 1 && rh >= 1 && rw >= 1, "iff_image_resize_crop_rgba: bad shape");
+    IFF_REQUIRE(top >= 0 && left >= 0 && ch >= 1 && cw >= 1 && top + ch <= rh && left + cw <= rw, "iff_image_resize_crop_rgba: crop window outside the resized image");
+    if (Q == 0) return 0;
+    IFF_REQUIRE(src && dst, "iff_image_resize_crop_rgba: null buffer");
+    const float sup = cubic ? 2.0f : 1.0f;
+    const float sy = std::max((float)H / rh, 1.0f), sx = std::max((float)W / rw, 1.0f);
+    if (2.0f * sup * std::max(sx, sy) + 2.0f > 32.0f)
+        return fail(IFF_ERR_UNSUPPORTED, "iff_image_resize_crop_rgba: scale factor %.2f needs more than 32 filter taps", std::max(sx, sy));
+    IFF_HIP(launch_resize_crop(src, Q, H, W, mode == IFF_RESIZE_RGB_ON_WHITE ? 3 : 1, mode, rh, rw, top, left, ch, cw, cubic ? 1 : 0, mean, std, dst,
+                               (hipStream_t)stream));
     return 0;
 }

@@ -131,6 +131,7 @@ hipError_t launch_merge_candidates(const float* cand_all, int G, int Qt, int q0,
 // pose_kernels.hip
 hipError_t launch_pose(const int64_t* idx, const float* val, int Q, int k, const float* rays_o, const float* rays_d, int64_t N,
                        int64_t ray_batch_stride, const float* up3, float* c2w, float* parts, hipStream_t s);
+hipError_t launch_pose_errors(const float* c2w, const float* gt, const float* parts, int Q, int k, float* out, hipStream_t s);
 
 // vit_kernels.hip -- the ViT-S/14 image backbone (pose_estimation/backbone.py:12-14)
 constexpr int VIT_MAX_DEPTH = 64;
@@ -153,7 +154,7 @@ struct VitDev {
     int prec;                             // 0: bf16 operands; 1: split fp16 operands (hi + lo), three products per block
     float s_patch, s_qkv[VIT_MAX_DEPTH], s_proj[VIT_MAX_DEPTH], s_fc1[VIT_MAX_DEPTH], s_fc2[VIT_MAX_DEPTH];      // accumulator scales (prec 1)
 };
-hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int rh, int rw, int top, int left, int ch, int cw, int cubic,
+hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int mode, int rh, int rw, int top, int left, int ch, int cw, int cubic,
                               const float* mean, const float* std, float* dst, hipStream_t s);
 size_t vit_workspace_bytes(const VitDev& v, int Q);
 hipError_t launch_vit_to_bf16(const float* src, int64_t n, void* dst, hipStream_t s);

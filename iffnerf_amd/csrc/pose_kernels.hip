@@ -270,3 +270,45 @@ hipError_t launch_pose(const int64_t* idx, const float* val, int Q, int k, const
                        up3[2], lim, c2w, parts);
     return hipGetLastError();
 }
+
+// Error metrics of one estimated pose against the ground truth, pose_estimation/test.py:213-232 with errors.py:3-9:
+//   translation error = || gt[:3,3] - pred[:3,3] ||_2  (the camera positions [0,0,0,1] @ c2w[:3,:].T of test.py:213-225 ARE those columns)
+//   angular error     = rad2deg(acos(clamp((trace(R_gt R_pred^-1) - 1) / 2, -1, 1))), the inverse by LU with partial pivoting like torch.linalg.inv
+//   loss              = weights.mean() over the rays the origin filter kept (test.py:241), from the solver's `parts`
+// One thread per query: summary [Q,4] = (loss, translation error, angular error in degrees, rays kept).
+__global__ void k_pose_errors(const float* __restrict__ c2w, const float* __restrict__ gt, const float* __restrict__ parts, int Q, int k,
+                              float* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const float* P = c2w + 16 * (int64_t)q;
+    const float* G = gt + 16 * (int64_t)q;
+    const float dx = G[3] - P[3], dy = G[7] - P[7], dz = G[11] - P[11];
+    const float terr = sqrtf((dx * dx + dy * dy) + dz * dz);
+    Lu3 f;
+    lu3(P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10], f);
+    float i00, i01, i02, i10, i11, i12, i20, i21, i22;
+    lu3_solve(f, 1.f, 0.f, 0.f, i00, i10, i20);
+    lu3_solve(f, 0.f, 1.f, 0.f, i01, i11, i21);
+    lu3_solve(f, 0.f, 0.f, 1.f, i02, i12, i22);
+    const float t0 = (G[0] * i00 + G[1] * i10) + G[2] * i20;
+    const float t1 = (G[4] * i01 + G[5] * i11) + G[6] * i21;
+    const float t2 = (G[8] * i02 + G[9] * i12) + G[10] * i22;
+    float c = (((t0 + t1) + t2) - 1.0f) / 2.0f;
+    c = (c != c) ? c : fminf(fmaxf(c, -1.0f), 1.0f);                     // torch.clamp keeps NaN
+    const float aerr = acosf(c) * 57.29577951308232f;
+    float loss = NAN, nk = 0.0f;
+    if (parts) {
+        const float* w = parts + (int64_t)q * (8 + k) + 8;
+        float sum = 0.0f;
+        for (int i = 0; i < k; ++i)
+            if (w[i] >= 0.0f) { sum += w[i]; nk += 1.0f; }
+        loss = sum / nk;                                                  // no ray kept: 0 / 0 = NaN, as torch's mean of an empty tensor
+    }
+    out[4 * q] = loss; out[4 * q + 1] = terr; out[4 * q + 2] = aerr; out[4 * q + 3] = nk;
+}
+
+hipError_t launch_pose_errors(const float* c2w, const float* gt, const float* parts, int Q, int k, float* out, hipStream_t s) {
+    if (Q < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_pose_errors, dim3((unsigned)((Q + 63) / 64)), dim3(64), 0, s, c2w, gt, parts, Q, k, out);
+    return hipGetLastError();
+}

@@ -732,8 +732,12 @@ __device__ inline void aa_weights(int o, int in, int out, int cubic, float* w, i
     for (int j = count; j < RS_TAPS; ++j) w[j] = 0.0f;
 }
 
+// `mode` (IFF_RESIZE_*): 0 the C channels of the source as they are (Cin == C); 1 the source is RGBA (Cin = 4) and the three output
+// channels are the colour composited on white, rgb * a + (1 - a) -- pose_estimation/test.py:77-81, the three roundings of the three
+// torch ops, evaluated per input pixel inside the horizontal pass; 2 the source is RGBA and the one output channel is its alpha.
 struct ResizeArgs {
-    const float* src; int Q, H, W, C;            // [Q,H,W,C] (C <= 4)
+    const float* src; int Q, H, W, C;            // [Q,H,W,Cin]; C output channels (<= 4)
+    int Cin, mode;
     int rh, rw;                                  // size of the (virtual) resized image
     int top, left, ch, cw;                       // crop window inside it
     int cubic;
@@ -757,7 +761,7 @@ __global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows,
     else if (threadIdx.x >= 64 && threadIdx.x < 64 + tr)        // in another wave than the columns' weights: the two run side by side
         aa_weights(a.top + min(oy0 + tx, a.ch - 1), a.H, a.rh, a.cubic, s_wy[tx], s_fy[tx], s_ny[tx]);
     __syncthreads();
-    const int C = a.C;
+    const int C = a.C, Cin = a.Cin;
     float* const s_tmp = s_dyn;
     float* const s_in = s_dyn + max_rows * 16 * C;
     const int ry0 = s_fy[0], fx0 = s_fx[0];
@@ -765,8 +769,8 @@ __global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows,
     for (int i = 0; i < 16; ++i) fx1 = max(fx1, s_fx[i] + s_nx[i]);
     for (int i = 0; i < tr; ++i) ry1 = max(ry1, s_fy[i] + s_ny[i]);
     const int n_rows = min(ry1 - ry0, max_rows);
-    const int seg = min(fx1 - fx0, max_cols) * C, ld = max_cols * C;          // floats of a row this tile reads
-    const float* img = a.src + (int64_t)q * a.H * a.W * C;
+    const int seg = min(fx1 - fx0, max_cols) * Cin, ld = max_cols * Cin;      // floats of a row this tile reads
+    const float* img = a.src + (int64_t)q * a.H * a.W * Cin;
     for (int r0 = 0; r0 < n_rows; r0 += rch) {
         const int nr = min(rch, n_rows - r0);
         if (r0) __syncthreads();                // the previous chunk has been filtered
@@ -779,7 +783,7 @@ __global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows,
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int r = rb + 4 * rr;
-                    const float* src = img + ((int64_t)(ry0 + r0 + min(r, nr - 1)) * a.W + fx0) * C;
+                    const float* src = img + ((int64_t)(ry0 + r0 + min(r, nr - 1)) * a.W + fx0) * Cin;
 #pragma unroll
                     for (int kk = 0; kk < 3; ++kk) v[rr][kk] = src[min(kb + 64 * kk, seg - 1)];
                 }
@@ -792,11 +796,20 @@ __global__ void __launch_bounds__(256) k_resize_crop(ResizeArgs a, int max_rows,
         __syncthreads();
         for (int item = threadIdx.x; item < nr * 16; item += 256) {
             const int r = item >> 4, ox = item & 15;
-            const float* row = s_in + r * ld + (s_fx[ox] - fx0) * C;
+            const float* row = s_in + r * ld + (s_fx[ox] - fx0) * Cin;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int i = 0; i < s_nx[ox]; ++i) {
-                const float w = s_wx[ox][i];
-                for (int c = 0; c < C; ++c) acc[c] = fmaf(w, row[i * C + c], acc[c]);
+            if (a.mode == 0) {
+                for (int i = 0; i < s_nx[ox]; ++i) {
+                    const float w = s_wx[ox][i];
+                    for (int c = 0; c < C; ++c) acc[c] = fmaf(w, row[i * C + c], acc[c]);
+                }
+            } else if (a.mode == 1) {
+                for (int i = 0; i < s_nx[ox]; ++i) {
+                    const float w = s_wx[ox][i], al = row[i * 4 + 3], white = 1.0f - al;
+                    for (int c = 0; c < 3; ++c) acc[c] = fmaf(w, row[i * 4 + c] * al + white, acc[c]);
+                }
+            } else {
+                for (int i = 0; i < s_nx[ox]; ++i) acc[0] = fmaf(s_wx[ox][i], row[i * 4 + 3], acc[0]);
             }
             for (int c = 0; c < C; ++c) s_tmp[((r0 + r) * 16 + ox) * C + c] = acc[c];
         }
@@ -863,10 +876,12 @@ hipError_t gemm(const void* Xv, int64_t x_lo, const void* Wv, int64_t w_lo, int6
 
 }  // namespace
 
-hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int rh, int rw, int top, int left, int ch, int cw, int cubic,
+hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int mode, int rh, int rw, int top, int left, int ch, int cw, int cubic,
                               const float* mean, const float* std, float* dst, hipStream_t s) {
     if (Q < 1) return hipSuccess;
     ResizeArgs a;
+    const int Cin = mode ? 4 : C;
+    a.Cin = Cin; a.mode = mode;
     a.src = src; a.Q = Q; a.H = H; a.W = W; a.C = C; a.rh = rh; a.rw = rw; a.top = top; a.left = left; a.ch = ch; a.cw = cw; a.cubic = cubic;
     for (int c = 0; c < 4; ++c) { a.mean[c] = (mean && c < C) ? mean[c] : 0.0f; a.inv_std[c] = (std && c < C) ? 1.0f / std[c] : 1.0f; }
     a.dst = dst;
@@ -878,9 +893,9 @@ hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int 
     // ... and input columns likewise; the rows are staged `rch` at a time (about 12 KB of LDS)
     const float sx = (float)W / (float)rw, supx = (cubic ? 2.0f : 1.0f) * (sx >= 1.0f ? sx : 1.0f);
     const int max_cols = (int)(15.0f * sx + 2.0f * supx) + 4;
-    int rch = 3072 / (max_cols * C);
+    int rch = 3072 / (max_cols * Cin);
     rch = rch < 1 ? 1 : (rch > max_rows ? max_rows : rch);
-    const size_t lds = ((size_t)max_rows * 16 * C + (size_t)rch * max_cols * C) * sizeof(float);
+    const size_t lds = ((size_t)max_rows * 16 * C + (size_t)rch * max_cols * Cin) * sizeof(float);
     if (lds > 60 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_resize_crop, dim3((unsigned)((cw + 15) / 16), (unsigned)((ch + tr - 1) / tr), (unsigned)Q), dim3(256), lds, s, a, max_rows,
                        max_cols, rch, tr);

@@ -434,8 +434,9 @@ def merge_candidates(cand_all: torch.Tensor, k: int, q0: int = 0, n_queries=None
     return val, idx, ori, dirs
 
 
-def pose_from_topk_batched(idx, val, rays_o, rays_d, model_up):
-    """idx, val [Q, k]; rays_o / rays_d either one shared ray set [N, 3] or per-query candidates [Q, n, 3] -> c2w [Q, 4, 4]."""
+def pose_from_topk_batched(idx, val, rays_o, rays_d, model_up, want_parts: bool = False):
+    """idx, val [Q, k]; rays_o / rays_d either one shared ray set [N, 3] or per-query candidates [Q, n, 3] -> c2w [Q, 4, 4]
+    (+ the solver's internals [Q, 8 + k] per query as ``pose_from_topk`` when ``want_parts``)."""
     idx = idx.detach().to(torch.int64).contiguous()
     val = _gpu(val, "weights")
     if not idx.is_cuda:
@@ -450,8 +451,28 @@ def pose_from_topk_batched(idx, val, rays_o, rays_d, model_up):
     n = o.shape[-2]
     stride = n * 3 if o.dim() == 3 else 0
     c2w = o.new_empty(Q, 4, 4)
+    parts = o.new_empty(Q, 8 + k) if want_parts else None
     up = fvec(torch.as_tensor(model_up).detach().cpu().reshape(-1).tolist())
     with torch.cuda.device(o.device):
         check(_lib.lib().iff_pose_from_topk_batched(dptr(idx, torch.int64), dptr(val), Q, k, dptr(o), dptr(d), n, stride, up,
-                                                    dptr(c2w), stream_ptr(o.device)), "iff_pose_from_topk_batched")
-    return c2w
+                                                    dptr(c2w), dptr(parts), stream_ptr(o.device)), "iff_pose_from_topk_batched")
+    return (c2w, parts) if want_parts else c2w
+
+
+def pose_errors(c2w: torch.Tensor, gt_c2w: torch.Tensor, parts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The per-image error metrics of pose_estimation/test.py:213-241 for Q poses in one launch: c2w, gt_c2w [Q,4,4] (or [4,4]),
+    ``parts`` [Q, 8 + k] from the pose solve -> summary [Q,4] = (loss = mean kept weight, translation error, angular error in
+    degrees, rays kept).  Nothing is read back: the caller decides when (``iff_pose_errors``)."""
+    c = _gpu(c2w, "c2w").reshape(-1, 4, 4)
+    g = gt_c2w.detach().to(device=c.device, dtype=torch.float32).reshape(-1, 4, 4).contiguous()
+    Q = c.shape[0]
+    if g.shape[0] != Q:
+        raise RuntimeError("one ground-truth pose per estimated pose expected")
+    k = 0
+    if parts is not None:
+        parts = _gpu(parts, "parts").reshape(Q, -1)
+        k = parts.shape[1] - 8
+    out = c.new_empty(Q, 4)
+    with torch.cuda.device(c.device):
+        check(_lib.lib().iff_pose_errors(dptr(c), dptr(g), dptr(parts), Q, k, dptr(out), stream_ptr(c.device)), "iff_pose_errors")
+    return out

@@ -80,6 +80,34 @@ def resize_crop(src: torch.Tensor, resize_size: int, crop_size: int, cubic: bool
     return out
 
 
+RESIZE_RGB_ON_WHITE, RESIZE_ALPHA = 1, 2          # include/iffnerf_hip.h IFF_RESIZE_*
+
+
+def resize_crop_rgba(src: torch.Tensor, resize_size: int, crop_size, mode: int, cubic: bool, mean=None, std=None) -> torch.Tensor:
+    """``iff_image_resize_crop_rgba``: RGBA images [Q,H,W,4] -> the resized / cropped / normalised colour composited on white
+    [Q,3,crop,crop] (``RESIZE_RGB_ON_WHITE``: pose_estimation/test.py:77-81 folded into the resize) or alpha channel [Q,1,crop,crop]
+    (``RESIZE_ALPHA``) -- the images never exist as separate RGB / mask tensors."""
+    if not src.is_cuda:
+        raise RuntimeError("images must live on the GPU; libiffnerf_hip has no CPU path")
+    x = src.detach().to(torch.float32).contiguous()
+    Q, H, W, Cc = x.shape
+    if Cc != 4:
+        raise RuntimeError(f"RGBA images [Q,H,W,4] expected (got {Cc} channels)")
+    if H <= W:
+        rh, rw = resize_size, max(1, int(resize_size * W / H))
+    else:
+        rh, rw = max(1, int(resize_size * H / W)), resize_size
+    ch, cw = (rh, rw) if crop_size is None else (crop_size, crop_size)
+    top, left = int(round((rh - ch) / 2.0)), int(round((rw - cw) / 2.0))
+    out = x.new_empty(Q, 3 if mode == RESIZE_RGB_ON_WHITE else 1, ch, cw)
+    m = None if mean is None else fvec(mean)
+    s = None if std is None else fvec(std)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().iff_image_resize_crop_rgba(dptr(x), Q, H, W, int(mode), rh, rw, top, left, ch, cw, int(bool(cubic)), m, s, dptr(out),
+                                                    stream_ptr(x.device)), "iff_image_resize_crop_rgba")
+    return out
+
+
 class ImageFrontEnd:
     """Resize / crop / normalise + backbone + token assembly for a batch of query images, all on the device."""
 
@@ -124,4 +152,19 @@ class ImageFrontEnd:
             else:
                 m = _center_crop(_resize_short_edge(masks[:, None] * 1.0, self.resize_size, "bilinear"), self.crop_size)
                 mg = _resize_short_edge(m, self.grid[0], "bilinear").reshape(masks.shape[0], -1)
+        return token_assemble(feats, self.grid, mg, 0.1)
+
+    @torch.no_grad()
+    def tokens_rgba(self, rgba: torch.Tensor):
+        """RGBA query images [Q,H,W,4] as the evaluation loop holds them (pose_estimation/test.py:75-81) -> (tokens, keep): the
+        composite on white and the alpha mask are taken inside the two resize launches.  Equals ``tokens(rgb * a + (1 - a), a)``
+        bit for bit."""
+        xin = resize_crop_rgba(rgba, self.resize_size, self.crop_size, RESIZE_RGB_ON_WHITE, True, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD)
+        if self.backbone_autocast is None:
+            feats = self.backbone.forward_features(xin)["x_norm_patchtokens"]
+        else:
+            with torch.autocast(device_type="cuda", dtype=self.backbone_autocast):
+                feats = self.backbone.forward_features(xin)["x_norm_patchtokens"]
+        m = resize_crop_rgba(rgba, self.resize_size, self.crop_size, RESIZE_ALPHA, False)
+        mg = resize_crop(m.permute(0, 2, 3, 1), self.grid[0], None, False).reshape(rgba.shape[0], -1)
         return token_assemble(feats, self.grid, mg, 0.1)

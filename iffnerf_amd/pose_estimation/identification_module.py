@@ -1,8 +1,12 @@
 """Mirror of ``pose_estimation/identification_module.py``: same class, constructor, attributes and method signatures.
 
 The ray side (encoder, k_proj), q_proj, the softmax over the ray axis, the column-sum score and the top-k run in
-libiffnerf_hip (fp32 MFMA).  The image side up to the token tensor (resize / crop / normalise, DINOv2) is the stock
-PyTorch-ROCm module: it is outside the accelerated path.
+libiffnerf_hip; so does the image side of ``test_image`` (resize / crop / normalise in ``iff_image_resize_crop``, DINOv2's
+architecture in ``iff_vit_forward`` when the backbone is served natively, token assembly in ``iff_token_assemble``).
+``test_image`` (the call of pose_estimation/test.py:84-91) keeps every shape static -- the mask select of reference :157-160 is
+applied to the softmax rows instead of the token tensor --, caches the ray encoder per (weights, ray set) and
+returns the [M,N] attention map as a ``LazyAttentionMap`` that is only computed if somebody reads it; a batch of images runs
+through exactly the same launches (``static_tokens`` / ``scores_static``), which is what ``test_pose_estimation`` does.
 ``state_dict`` keys equal the reference's (``norm_mean``, ``norm_std``, ``image_preprocessing_net.*``,
 ``ray_preprocessor.mlp*.{0,2}.*``, ``attention.{q,k}_proj.*``), so ``id_module.th`` loads unchanged.
 Grad mode: under ``torch.no_grad`` / with frozen parameters (the whole north-star path) stage C
@@ -41,6 +45,79 @@ def _center_crop(x, size):
     return x[..., top:top + size, left:left + size]
 
 
+class RaySession:
+    """What stage C keeps per (module weights, ray set): the rays as the kernels read them and the ray encoder's cached output
+    (``iff_ray_cache_build``; SURVEY.md 8f-2 -- the reference re-runs the encoder per image, identification_module.py:164, on rays
+    that do not change between the images of pose_estimation/test.py:67-91).  Validity is by IDENTITY: the very tensor objects
+    ``explore_model`` returned (held weakly) at the same in-place version, and the same weight versions; anything else builds a
+    new session.  ``graphs`` holds the evaluation loop's captured batches (pose_estimation/test.py of this package)."""
+
+    def __init__(self, module: "IdentificationModule", rays_ori, rays_dir, rays_rgb):
+        from ..hip_identify import _gpu
+        self._refs = tuple(weakref.ref(t) for t in (rays_ori, rays_dir, rays_rgb))
+        self._versions = tuple(t._version for t in (rays_ori, rays_dir, rays_rgb))
+        self.weights_key = module._weights_key()
+        self.net = module._idnet()
+        self.ori, self.dirs = _gpu(rays_ori, "rays_ori", 3), _gpu(rays_dir, "rays_dir", 3)
+        self.n_rays = self.ori.shape[0]
+        self.cache = self.net.build_ray_cache(self.ori, self.dirs, rays_rgb)
+        self.graphs = {}
+
+    def serves(self, module, rays_ori, rays_dir, rays_rgb) -> bool:
+        same = all(r() is t and t._version == v for r, t, v in zip(self._refs, (rays_ori, rays_dir, rays_rgb), self._versions))
+        return same and module._net is self.net and module._weights_key() == self.weights_key
+
+
+class LazyAttentionMap:
+    """The attention map [M,N] of ``test_image`` (reference identification_module.py:165-166), computed on first use.
+    pose_estimation/test.py only reads it when a loss function is given (``attention_map.shape[-2]``, :121), and at the
+    reference's default 540 000 rays it is 553 MB per image; ``score`` / top-k never need it (the column sums come straight from
+    the logits and the row statistics).  Any tensor use -- an attribute, an index, a torch function -- materialises it through
+    ``iff_logits_from_cache`` + ``iff_attn_colsum(write_attention=1)`` and the mask select of reference :157-160."""
+
+    def __init__(self, thunk):
+        object.__setattr__(self, "_thunk", thunk)
+        object.__setattr__(self, "_tensor", None)
+
+    def materialize(self) -> torch.Tensor:
+        if self._tensor is None:
+            object.__setattr__(self, "_tensor", self._thunk())
+            object.__setattr__(self, "_thunk", None)
+        return self._tensor
+
+    @property
+    def is_materialized(self) -> bool:
+        return self._tensor is not None
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        un = lambda a: a.materialize() if isinstance(a, LazyAttentionMap) else a  # noqa: E731
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __len__(self):
+        return len(self.materialize())
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __repr__(self):
+        return repr(self._tensor) if self._tensor is not None else "LazyAttentionMap(<not computed>)"
+
+
+for _op in ("add", "sub", "mul", "truediv", "matmul", "radd", "rsub", "rmul", "rtruediv", "rmatmul", "neg", "eq", "ne", "lt", "le", "gt", "ge"):
+    def _forward(self, *a, _n="__%s__" % _op):
+        return getattr(self.materialize(), _n)(*a)
+    setattr(LazyAttentionMap, "__%s__" % _op, _forward)
+LazyAttentionMap.__hash__ = object.__hash__
+
+
 class IdentificationModule(torch.nn.Module):
     def __init__(self, backbone_type: str = "superpoint"):
         super().__init__()
@@ -57,6 +134,8 @@ class IdentificationModule(torch.nn.Module):
         self.ray_preprocessor._owner = me
         self.attention._owner = me
         self._net = None
+        self._ray_session = None
+        self._frontend = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_tables())
 
     # ------------------------------------------------------------------ preprocessing (out of the accelerated path)
@@ -96,6 +175,7 @@ class IdentificationModule(torch.nn.Module):
             self._net.close()
         self._net = None
         self._net_key = None
+        self._ray_session = None          # its encoder cache (and any captured batch) belongs to the handle just closed
 
     def _weights_key(self):
         """Identity + in-place version of every tensor the kernel handle was built from.  ``optimizer.step()`` updates the
@@ -108,6 +188,12 @@ class IdentificationModule(torch.nn.Module):
         out = super()._apply(fn, *a, **k)
         self.invalidate_tables()
         return out
+
+    def __getstate__(self):
+        """Copies and pickles start without device handles (kernel tables, encoder cache, captured batches: rebuilt on first use)."""
+        state = self.__dict__.copy()
+        state.update(_net=None, _net_key=None, _ray_session=None, _frontend=None)
+        return state
 
     def _idnet(self):
         key = self._weights_key()
@@ -161,9 +247,82 @@ class IdentificationModule(torch.nn.Module):
         scores, attention_map, tokens = self.run_attention(img, mask, rays_ori[used], rays_dir[used], rays_rgb[used])
         return scores, attention_map, tokens, used
 
+    # ------------------------------------------------------------------ the static-shape form of stage C (test_image, eval loop)
+    def custom_preprocessing(self) -> bool:
+        """``transformations`` / ``mask_transformations`` replaced on the instance (the golden harness runs the reference with
+        identity transforms on 16 x 16 inputs, tests/golden/make_golden.py): they are then called as given."""
+        return "transformations" in self.__dict__ or "mask_transformations" in self.__dict__
+
+    def serves_batches(self) -> bool:
+        """A batch of images through ``static_tokens`` returns per image exactly what the image alone returns: true for the
+        backbone served by ``iff_vit_forward`` (every row of every product is summed in one fixed order whatever the batch) with the
+        module's own preprocessing; a stock torch backbone picks its GEMM kernels by batch size, an arbitrary module may not
+        take batches at all -- those run image by image."""
+        from ..hip_vit import is_served_natively
+        return is_served_natively(self.image_preprocessing_net) and not self.custom_preprocessing()
+
+    def frontend(self):
+        if self._frontend is None or self._frontend.backbone is not self.image_preprocessing_net:
+            from ..image_frontend import ImageFrontEnd
+            self._frontend = ImageFrontEnd(self.image_preprocessing_net, self.backbone_wh, self.resize_size, self.crop_size)
+        return self._frontend
+
+    def static_tokens(self, imgs, masks):
+        """imgs [Q,H,W,3] (or RGBA [Q,H,W,4] with ``masks`` None: composited on white, alpha as the mask -- pose_estimation/test.py:75-81),
+        masks [Q,H,W] -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw] uint8): reference :130-160 without the row compaction (no
+        boolean index, no host sync; ``scores_static`` applies ``keep`` to the softmax rows)."""
+        from ..image_frontend import token_assemble
+        if imgs.shape[-1] == 4 and masks is None:
+            if not self.custom_preprocessing():
+                return self.frontend().tokens_rgba(imgs)
+            imgs, masks = imgs[..., :3] * imgs[..., -1:] + (1 - imgs[..., -1:]), imgs[..., -1]
+        if not self.custom_preprocessing():
+            return self.frontend().tokens(imgs, masks)
+        norm = self.transformations(imgs.permute(0, 3, 1, 2))
+        feats = self.image_preprocessing_net.forward_features(norm)["x_norm_patchtokens"]
+        mg = None if masks is None else self.mask_transformations(masks[:, None] * 1.0).reshape(masks.shape[0], -1)
+        return token_assemble(feats, self.backbone_wh, mg, 0.1)
+
+    def ray_session(self, rays_ori, rays_dir, rays_rgb) -> RaySession:
+        """The session of this ray set: reused while the caller passes the same (unmodified) tensors and the weights stand."""
+        s = self._ray_session
+        if s is None or not s.serves(self, rays_ori, rays_dir, rays_rgb):
+            self._idnet()                 # rebuilds the handle first if the weights moved (which also drops the old session)
+            s = self._ray_session = RaySession(self, rays_ori, rays_dir, rays_rgb)
+        return s
+
+    def scores_static(self, tokens, keep, session: RaySession, want_map: bool = True):
+        """tokens [Q,G,C+14], keep [Q,G] -> (score [Q,N], one LazyAttentionMap per image or None): identification_module.py:164-167
+        with the encoder taken from the session's cache and the mask select applied to the softmax rows."""
+        from .. import hip_identify as H
+        from ..image_frontend import mask_token_rows
+        net = session.net
+        Q, G, C = tokens.shape
+        qf = net.q_fold(tokens.reshape(Q * G, C))
+        logits, rmax, rsum = net.logits_from_cache(qf, session.cache, session.n_rays)
+        mask_token_rows(keep, rmax, rsum)
+        score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
+        if not want_map:
+            return score, None
+
+        def thunk(q):
+            def make():
+                lg, mx, sm = net.logits_from_cache(qf[q * G:(q + 1) * G], session.cache, session.n_rays)
+                mask_token_rows(keep[q], mx, sm)
+                H.attn_colsum(lg, mx, sm, write_attention=True)
+                return lg[keep[q].bool()]
+            return make
+        return score, [LazyAttentionMap(thunk(q)) for q in range(Q)]
+
     @torch.no_grad()
     def test_image(self, img, mask, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100):
         from .. import hip_identify as H
-        scores, attention_map, _ = self.run_attention(img, mask, rays_ori, rays_dir, rays_rgb)
-        indices, values = H.topk(scores, rays_to_output)
-        return indices, values, scores, attention_map
+        if not getattr(self, "fold_heads", True):
+            scores, attention_map, _ = self.run_attention(img, mask, rays_ori, rays_dir, rays_rgb)
+            indices, values = H.topk(scores, rays_to_output)
+            return indices, values, scores, attention_map
+        session = self.ray_session(rays_ori, rays_dir, rays_rgb)
+        tokens, keep = self.static_tokens(img[None], mask[None])
+        score, maps = self.scores_static(tokens, keep, session)
+        indices, values = H.topk(score[0], rays_to_output)
+        return indices, values, score[0], maps[0]

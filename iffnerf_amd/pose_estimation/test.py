@@ -1,10 +1,21 @@
 """Mirror of ``pose_estimation/test.py``: ``test_pose_estimation`` with the reference's signature and result format.
 
-Per image (reference :67-247): RGBA -> RGB on white, ``id_module.test_image`` (stage C in HIP), then the closed-form pose
-from the top-100 rays in ONE kernel (``iff_pose_from_topk``) instead of ~40 tiny host-driven tensor ops, then the
-reference's error metrics, optionally after the iNeRF refinement of reference :196-211 (``inerf_refinement=True``: 800 Adam
-steps through the HIP slab march and its HIP backward, ``iffnerf_amd/inerf``).  ``loss_fn`` / ``save`` belong to the training
-and plotting code and are out of scope for the MI355X path.
+The reference loops over the images (:66-247): RGBA -> RGB on white, ``id_module.test_image`` (which re-runs the ray encoder on
+rays that never change, writes the [M,N] attention map and boolean-indexes the tokens), ~40 host-driven tensor ops for the pose and
+three ``.item()`` reads.  Here the same call
+
+    test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, ...)
+
+serves the images in BATCHES through one set of launches per batch -- composite + resize / crop / normalise
+(``iff_image_resize_crop_rgba``), DINOv2's forward (``iff_vit_forward``), token assembly, folded query projection, logits against
+the ray encoder's cached output (``iff_ray_cache_build`` once per (weights, ray set), ``iff_logits_from_cache`` per batch), softmax
+/ column sums / top-100, the closed-form pose (``iff_pose_from_topk_batched``) and the error metrics (``iff_pose_errors``) -- with
+full batches replayed as captured hipGraphs on two alternating streams and ONE device->host read per batch.  Every number equals,
+bit for bit, what the image-by-image route below returns (tests/test_hip_eval_loop.py): both run the same kernels, whose per-row
+arithmetic does not depend on the batch.  Image by image is the route of everything a batch cannot serve: an arbitrary backbone
+module (``IdentificationModule.serves_batches``), replaced preprocessing, the iNeRF refinement of reference :196-211
+(``inerf_refinement=True``: 800 Adam steps per image through the HIP slab march and its HIP backward, ``iffnerf_amd/inerf``).
+``loss_fn`` / ``save`` belong to the training and plotting code and are out of scope for the MI355X path.
 """
 from __future__ import annotations
 
@@ -13,10 +24,16 @@ from statistics import mean
 
 import torch
 
-from .errors import compute_angular_error, compute_translation_error
+from .errors import compute_angular_error, compute_translation_error  # noqa: F401  (the reference's import line, :8)
+
+INERF_ITERS = 800      # reference test.py:204
+INERF_BATCH = 1024     # pose_estimation's default batch_size (inerf/estimate_pose_inerf.py:31), which test.py:196-209 leaves alone
+EVAL_BATCH = 32        # images per batch of the batched route (one captured hipGraph per full batch)
+LOGITS_BUDGET_BYTES = 4 << 30     # a batch's [B * 256, N] fp32 logits stay below this (540 000 rays: 7 images per batch)
+TOPK = 100             # rays_to_output of reference :90
 
 
-def estimate_pose(id_module, obs_img, mask_img, rays_ori, rays_dirs, rays_rgb, model_up, rays_to_output=100):
+def estimate_pose(id_module, obs_img, mask_img, rays_ori, rays_dirs, rays_rgb, model_up, rays_to_output=TOPK):
     """One query image -> (c2w [4,4] on the GPU, solver internals, top-k indices, top-k values, scores)."""
     from .. import hip_identify as H
     idx, weights, scores, _ = id_module.test_image(obs_img, mask_img, rays_ori, rays_dirs, rays_rgb,
@@ -25,8 +42,108 @@ def estimate_pose(id_module, obs_img, mask_img, rays_ori, rays_dirs, rays_rgb, m
     return c2w, parts, idx, weights, scores
 
 
-INERF_ITERS = 800      # reference test.py:204
-INERF_BATCH = 1024     # pose_estimation's default batch_size (inerf/estimate_pose_inerf.py:31), which test.py:196-209 leaves alone
+def _record(sequence_id, img_idx, summary_row, c2w_rows, gt_rows):
+    """One entry of the reference's result list (:234-246).  ``summary_row`` = (loss, translation error, angular error, kept)."""
+    return {"sequence_id": sequence_id, "category_name": "id_net", "frame_id": img_idx,
+            "loss": summary_row[0], "scores_loss": -1.0, "recall": -1.0, "total_optimization_time_in_ms": 0.0,
+            "pred_c2w": c2w_rows, "gt_c2w": gt_rows}
+
+
+def eval_batch(id_module, session, images, gt_poses, model_up, k=TOPK):
+    """images [B,H,W,4] (RGBA) or [B,H,W,3], gt_poses [B,4,4] -> (c2w [B,4,4], summary [B,4]) on the device, nothing read back.
+    The body of reference :71-232 for B images: the launches of ``IdentificationModule.test_image`` + pose solve + error metrics."""
+    from .. import hip_identify as H
+    tokens, keep = id_module.static_tokens(images, None)
+    score, _ = id_module.scores_static(tokens, keep, session, want_map=False)
+    idx, val = H.topk_batched(score, k)
+    c2w, parts = H.pose_from_topk_batched(idx, val, session.ori, session.dirs, model_up, want_parts=True)
+    return c2w, H.pose_errors(c2w, gt_poses, parts)
+
+
+class CapturedEvalBatch:
+    """``eval_batch`` for a fixed batch shape as one hipGraph with its own stream, static inputs (``images``, ``gt``) and pinned host
+    outputs: ``submit`` copies a batch in, replays and starts the read-back; ``collect`` waits for it."""
+
+    def __init__(self, id_module, session, shape, model_up, k=TOPK):
+        dev = session.ori.device
+        self.stream = torch.cuda.Stream(device=dev)
+        self.images = torch.zeros(shape, dtype=torch.float32, device=dev)
+        self.images[..., -1] = 1.0 if shape[-1] == 4 else 0.0
+        self.gt = torch.eye(4, device=dev).repeat(shape[0], 1, 1)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):            # warm-up outside capture (handles, workspaces, allocator)
+            for _ in range(2):
+                eval_batch(id_module, session, self.images, self.gt, model_up, k)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.c2w, self.summary = eval_batch(id_module, session, self.images, self.gt, model_up, k)
+        self.host_c2w = torch.empty(self.c2w.shape, dtype=torch.float32, pin_memory=True)
+        self.host_summary = torch.empty(self.summary.shape, dtype=torch.float32, pin_memory=True)
+        self.done = torch.cuda.Event()
+        self.pending = None
+
+    def submit(self, images, gt, tag):
+        with torch.cuda.stream(self.stream):
+            self.images.copy_(images, non_blocking=True)
+            self.gt.copy_(gt, non_blocking=True)
+            self.graph.replay()
+            self.host_c2w.copy_(self.c2w, non_blocking=True)
+            self.host_summary.copy_(self.summary, non_blocking=True)
+            self.done.record(self.stream)
+        self.pending = tag
+
+    def collect(self):
+        self.done.synchronize()
+        tag, self.pending = self.pending, None
+        return tag, self.host_c2w.clone(), self.host_summary.clone()
+
+
+def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id):
+    """Reference :66-247 over the whole dataset, a batch of images per set of launches."""
+    device = rays_ori.device
+    n, H_, W_, C_ = dataset.all_rgbs.shape
+    session = id_module.ray_session(rays_ori, rays_dirs, rays_rgb)
+    B = max(1, min(EVAL_BATCH, LOGITS_BUDGET_BYTES // (256 * 4 * max(session.n_rays, 1))))
+    up = tuple(float(v) for v in torch.as_tensor(model_up).detach().cpu().reshape(-1).tolist())
+    out = [None] * n
+
+    def harvest(first, c2w, summary):
+        c2w, summary = c2w.tolist(), summary.tolist()
+        for j in range(len(c2w)):
+            out[first + j] = (summary[j], c2w[j])
+
+    n_full = n // B
+    if n_full:
+        key = (B, H_, W_, C_, up)
+        if key not in session.graphs:
+            session.graphs[key] = [CapturedEvalBatch(id_module, session, (B, H_, W_, C_), up) for _ in range(2 if n_full > 1 else 1)]
+        slots = session.graphs[key]
+        cur = torch.cuda.current_stream(device)
+        for s in slots:
+            s.stream.wait_stream(cur)
+        for b in range(n_full):
+            slot = slots[b % len(slots)]
+            if slot.pending is not None:
+                harvest(*slot.collect())
+            slot.submit(dataset.all_rgbs[b * B:(b + 1) * B], dataset.poses[b * B:(b + 1) * B], b * B)
+        for slot in slots:
+            if slot.pending is not None:
+                harvest(*slot.collect())
+            cur.wait_stream(slot.stream)
+    if n_full * B < n:                                  # the tail batch: the same launches, eagerly
+        lo = n_full * B
+        imgs = dataset.all_rgbs[lo:].to(device=device, dtype=torch.float32, non_blocking=True)
+        gt = dataset.poses[lo:].to(device=device, dtype=torch.float32, non_blocking=True)
+        c2w, summary = eval_batch(id_module, session, imgs, gt, up)
+        harvest(lo, c2w.cpu(), summary.cpu())
+    return out
+
+
+def _batchable(dataset, id_module, rays_ori, inerf_refinement) -> bool:
+    rgbs = getattr(dataset, "all_rgbs", None)
+    return (not inerf_refinement and getattr(id_module, "fold_heads", True) and torch.is_tensor(rgbs) and rgbs.dim() == 4
+            and rgbs.shape[-1] in (3, 4) and rays_ori.is_cuda and id_module.serves_batches())
 
 
 def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id="", loss_fn=None,
@@ -36,38 +153,42 @@ def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, mode
                            "are out of scope for the MI355X hot path")
     if inerf_refinement and nerf_model is None:
         raise RuntimeError("test_pose_estimation(inerf_refinement=True) needs nerf_model (reference test.py:196-203)")
+    from .. import hip_identify as H
     id_module.eval()
     device = rays_ori.device
     n_images = dataset.all_rgbs.shape[0]
-    translation_errors, angular_errors, results = [], [], []
+    results = []
     start = time.time()
-    for img_idx in range(n_images):
-        pose = dataset.poses[img_idx].to(device, non_blocking=True)
-        obs = dataset.all_rgbs[img_idx].to(device, non_blocking=True)
-        if obs.shape[-1] == 4:
-            mask_img = obs[..., -1]
-            obs = obs[..., :3] * obs[..., -1:] + (1 - obs[..., -1:])
-        else:
-            mask_img = torch.ones_like(obs[..., -1], dtype=torch.bool)
-        c2w, parts, idx, weights, _ = estimate_pose(id_module, obs, mask_img, rays_ori, rays_dirs, rays_rgb, model_up)
-        if inerf_refinement:                                                               # reference :196-211
-            from ..inerf.estimate_pose_inerf import pose_estimation
-            rgba = torch.cat((obs, mask_img[..., None].to(obs.dtype)), dim=-1).cpu().numpy()
-            with torch.enable_grad():
-                _, c2w, _ = pose_estimation(c2w, rgba, dataset.K.to(device)[0], nerf_model, device=c2w.device, n_iters=INERF_ITERS, batch_size=INERF_BATCH,
-                                            print_progress=False, lrate=0.02, dice_loss=True, sampling_strategy="random")
-            c2w = c2w.to(device)
-        translation_errors.append(compute_translation_error(pose[:3, 3], c2w[:3, 3]).item())
-        angular_errors.append(compute_angular_error(pose[:3, :3], c2w[:3, :3]).item())
-        kept = parts[8:][parts[8:] >= 0]           # weights after exclusion of the rays that survived the origin filter
-        results.append({
-            "sequence_id": sequence_id, "category_name": "id_net", "frame_id": img_idx,
-            "loss": kept.mean().item(), "scores_loss": -1.0, "recall": -1.0, "total_optimization_time_in_ms": 0.0,
-            "pred_c2w": c2w.cpu().tolist(), "gt_c2w": pose.cpu().tolist(),
-        })
+    if _batchable(dataset, id_module, rays_ori, inerf_refinement):
+        with torch.no_grad():
+            rows = _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id)
+        for img_idx, (summary, c2w) in enumerate(rows):
+            results.append((summary, _record(sequence_id, img_idx, summary, c2w, dataset.poses[img_idx].cpu().tolist())))
+    else:
+        for img_idx in range(n_images):
+            pose = dataset.poses[img_idx].to(device, non_blocking=True)
+            obs = dataset.all_rgbs[img_idx].to(device, non_blocking=True)
+            if obs.shape[-1] == 4:
+                mask_img = obs[..., -1]
+                obs = obs[..., :3] * obs[..., -1:] + (1 - obs[..., -1:])
+            else:
+                mask_img = torch.ones_like(obs[..., -1], dtype=torch.bool)
+            c2w, parts, idx, weights, _ = estimate_pose(id_module, obs, mask_img, rays_ori, rays_dirs, rays_rgb, model_up)
+            if inerf_refinement:                                                               # reference :196-211
+                from ..inerf.estimate_pose_inerf import pose_estimation
+                rgba = torch.cat((obs, mask_img[..., None].to(obs.dtype)), dim=-1).cpu().numpy()
+                with torch.enable_grad():
+                    _, c2w, _ = pose_estimation(c2w, rgba, dataset.K.to(device)[0], nerf_model, device=c2w.device, n_iters=INERF_ITERS, batch_size=INERF_BATCH,
+                                                print_progress=False, lrate=0.02, dice_loss=True, sampling_strategy="random")
+                c2w = c2w.to(device)
+            # error metrics (:213-232) and the "loss" entry (:241) in one launch, ONE read per image
+            both = torch.cat((H.pose_errors(c2w, pose, parts).reshape(-1), c2w.detach().to(torch.float32).reshape(-1))).cpu().tolist()
+            results.append((both[:4], _record(sequence_id, img_idx, both[:4], [both[4 + 4 * r:8 + 4 * r] for r in range(4)], pose.cpu().tolist())))
     per_image = (time.time() - start) / max(n_images, 1)
     print("Time per element: ", per_image)
+    translation_errors = [s[1] for s, _ in results]
+    angular_errors = [s[2] for s, _ in results]
     avg_t, avg_a = mean(translation_errors), mean(angular_errors)
     print("Translation Error: ", avg_t)
     print("Angular Error: ", avg_a)
-    return results, avg_t, avg_a, -1.0, -1.0
+    return [r for _, r in results], avg_t, avg_a, -1.0, -1.0

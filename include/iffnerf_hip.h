@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 9
+#define IFF_ABI_VERSION 10
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -391,6 +391,19 @@ int iff_image_resize_crop(const float* src, int32_t Q, int32_t H, int32_t W, int
                           int32_t crop_top, int32_t crop_left, int32_t crop_h, int32_t crop_w, int32_t cubic, const float* mean_host_opt,
                           const float* std_host_opt, float* dst, void* stream);
 
+/* The same resize / crop / normalise straight from the RGBA query images the evaluation loop holds (dataset.all_rgbs [n,H,W,4],
+ * pose_estimation/test.py:75-81): src [Q,H,W,4];
+ *   IFF_RESIZE_RGB_ON_WHITE  dst [Q,3,crop_h,crop_w]: the colour composited on white, rgb * a + (1 - a) (test.py:78-80: the same
+ *                            three fp32 roundings as the reference's multiply / subtract / add), evaluated per input pixel, then
+ *                            filtered exactly as iff_image_resize_crop filters a [Q,H,W,3] image holding those values
+ *   IFF_RESIZE_ALPHA         dst [Q,1,crop_h,crop_w]: the alpha channel (mask_img = obs_img[..., -1], test.py:77; the mask side of
+ *                            identification_module.py:49-61, :133-136) */
+#define IFF_RESIZE_RGB_ON_WHITE 1
+#define IFF_RESIZE_ALPHA        2
+int iff_image_resize_crop_rgba(const float* src, int32_t Q, int32_t H, int32_t W, int32_t mode, int32_t resized_h, int32_t resized_w,
+                               int32_t crop_top, int32_t crop_left, int32_t crop_h, int32_t crop_w, int32_t cubic,
+                               const float* mean_host_opt, const float* std_host_opt, float* dst, void* stream);
+
 /* Image tokens for stage C: what IdentificationModule.image_processing does after the backbone
  * (pose_estimation/identification_module.py:149-160) -- append the 14-channel position code of get_img_position_encoding
  * (:76-99: grid position in [-1,1]^2, 'ij' indexing, then sin / cos of it at octaves 1, 2, 4) to every patch token, and turn
@@ -472,11 +485,19 @@ int iff_topk_batched(const float* score, int32_t Q, int64_t N, int32_t k, int64_
 int iff_pose_from_topk(const int64_t* idx, const float* val, int32_t k, const float* rays_o, const float* rays_d,
                        int64_t N, const float* up_host, float* c2w, float* parts_opt, void* stream);
 /* Q pose solves at once (the per-image loop of pose_estimation/test.py:67-91 around :133-174): idx, val [Q,k] ->
- * c2w [Q,16].  ray_batch_stride = 0: all queries index ONE ray set rays_o/rays_d [N,3]; otherwise query q reads
- * rays_o + q * ray_batch_stride (floats), e.g. k*3 for per-query gathered candidates [Q,k,3]. */
+ * c2w [Q,16], parts_opt [Q, 8 + k] (nullable; per query as iff_pose_from_topk).  ray_batch_stride = 0: all queries index ONE ray set
+ * rays_o/rays_d [N,3]; otherwise query q reads rays_o + q * ray_batch_stride (floats), e.g. k*3 for per-query gathered
+ * candidates [Q,k,3]. */
 int iff_pose_from_topk_batched(const int64_t* idx, const float* val, int32_t Q, int32_t k, const float* rays_o,
                                const float* rays_d, int64_t N, int64_t ray_batch_stride, const float* up_host,
-                               float* c2w, void* stream);
+                               float* c2w, float* parts_opt, void* stream);
+
+/* The error metrics the evaluation loop computes per image (pose_estimation/test.py:213-232 with errors.py:3-9, and the "loss"
+ * entry of test.py:241), for Q images in one launch and without a host round trip per image: c2w, gt_c2w [Q,16] row-major,
+ * parts_opt [Q, 8 + k] from iff_pose_from_topk(_batched) or NULL -> summary [Q,4] = (mean weight of the rays the origin filter
+ * kept -- NaN when parts_opt is NULL --, translation error || gt[:3,3] - c2w[:3,3] ||, angular error in degrees
+ * rad2deg(acos(clamp((trace(R_gt R^-1) - 1) / 2, -1, 1))) with the inverse by pivoted LU as torch.linalg.inv, rays kept). */
+int iff_pose_errors(const float* c2w, const float* gt_c2w, const float* parts_opt, int32_t Q, int32_t k, float* summary, void* stream);
 
 #ifdef __cplusplus
 }
