@@ -17,8 +17,8 @@ Workloads (iffnerf_amd/synthetic.py:WORKLOADS, one per BASELINE.json config; syn
 Step = one pass of the hot path over one batch of synthetic queries, COLD: stage A (device-side surface sampler + normals +
 27-ray fans), stage B (20-sample VM march + Ref shading of every ray) and stage C (ray encoder + folded q/k projections,
 softmax over rays, column-sum score, top-100, closed-form pose) all run inside the step; nothing is cached between steps
-but the model tables.  For the cold configs every query of the batch draws its OWN ray set (`--batch`, default 16 queries
-per step and rank); for lego_b64 the 64 queries of a step share one freshly emitted ray set (the reference's eval semantics).
+but the model tables.  For the cold configs every query of the batch draws its OWN ray set (`--batch`, default the workload's:
+32 queries per step and rank on lego16k, 16 / 8 / 2 on truck32k / bicycle64k / lego540k); for lego_b64 the 64 queries of a step share one freshly emitted ray set (the reference's eval semantics).
 `value` counts poses: queries per step x steps / time.  Timing: SETTLE_STEPS - W untimed steps, the W warm-up steps, then EXACTLY K steps
 between two barriers (the settling is there because W = 5 steps are 10 ms of GPU time: not enough for the chip's clocks).
 
@@ -28,9 +28,17 @@ own queries, one all_gather hands every rank all points and folded queries, it e
 query, and two more all_gathers (softmax statistics, top-k candidates) precede the pose solves -- iffnerf_amd/distributed.py.
 Per-rank work does not depend on N, so N = 1 is exactly the single-GPU line.
 
-Output: ONE JSON line on rank 0 with `roofline` for the dominant kernel (duration measured live with events on the launch
-stream; `frac` = ALGORITHMIC flops of SURVEY.md section 8(d) / duration / dense bf16 peak) and `cpu_baseline` (the oracle =
-the reference's PyTorch-CPU op chain, timed on this box's host cores on a bounded sample of the same workload).
+Output: ONE JSON line on rank 0 with `roofline` for the dominant kernel = the longest launch of a step by this run's own event
+timings on the launch stream.  For the fused fan march that is `bound: "lds-gather"`: `frac` = ALGORITHMIC tap bytes of SURVEY.md
+section 8(d) / duration / the LDS read rate (every tap is served from LDS patches); beside it `frac_8d` = the same bytes over the
+8 TB/s HBM peak as section 8(d) prescribes (> 1: NOT a bound -- 540 samples of a fan share <= 12^3 texels, so the per-tap byte count is
+no HBM model) and `frac_hbm_counters` = the HBM-side bytes of the rocprofv3 PMC passes over the same duration and peak (what HBM
+really sees).  For the trunk (`other_kernels`, or the headline object on lego_b64) `bound: "mfma"`, `frac` = algorithmic flops /
+duration / the dense fp16 peak.  `cpu_baseline` = the oracle (the reference's PyTorch-CPU op chain) timed on this box's host cores on
+a bounded sample of the same workload.  Never part of `value`: `warm_poses_per_s`, `image_to_pose_per_s` (rays resident),
+`cold_image_to_pose_per_s` (800x800 RGBA in -> emission -> pose out), and `dropin` -- the route a user of the reference takes:
+`iffnerf_amd.install()`, then `explore_model(model)` + `test_pose_estimation(dataset, id_module, ...)` exactly as
+train_eval_pose_est.py:131-149 calls them.
 """
 from __future__ import annotations
 
@@ -73,6 +81,7 @@ def parse_args():
                     help="matrix-product arithmetic of the encoder / logits (both fp32-accurate; DESIGN.md section 4)")
     ap.add_argument("--trunk-variant", type=int, default=0, help="work split of the fused F16X2 launch (0 = default; tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the explore_model + test_pose_estimation measurement")
     ap.add_argument("--no-instrument", action="store_true", help="skip the per-stage / roofline measurements after the timed loop")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (captured segments + all_gathers) at world size 1, for rehearsal on one GPU")
@@ -167,6 +176,98 @@ def cpu_baseline(ck, idw, tokens_cpu, gen_points, shared_queries, max_seconds=45
                       f"per emitted ray set); median emission {em:.2f} s of {med:.2f} s"}
 
 
+def gather_kernel_entry(name, rays_per_launch, bound, peak, nbytes, ms, hbm_bytes, binding, note, peak_basis):
+    """The roofline object of a gather kernel (the march): `frac` against the roof that serves its taps, and beside it the two HBM
+    readings -- `frac_8d`, SURVEY 8(d)'s definition (algorithmic bytes / time / the 8 TB/s HBM peak), above 1 for the fused fan kernel,
+    i.e. NOT a bound (a fan's 540 samples share <= 12^3 texels staged once in LDS); `frac_hbm_counters`, what HBM really sees: the PMC
+    passes' bytes per launch over this run's launch time and the same peak."""
+    gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": name, "rays_per_launch": rays_per_launch, "bound": bound, "achieved": round(gbs, 1), "peak": round(peak, 1),
+            "unit": "GB/s", "frac": round(gbs / peak, 4),
+            "frac_8d": round(gbs / HBM_PEAK_GBS, 4),
+            "frac_8d_note": "algorithmic bytes / launch time / 8 TB/s as SURVEY 8(d) defines it; > 1 means the per-tap byte count is not an HBM model "
+                            "for this kernel (LDS reuse), not that HBM is exceeded",
+            "frac_hbm_counters": round(hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (hbm_bytes and ms > 0) else None,
+            "traffic": hbm_bytes, "avg_launch_ms": round(ms, 4), "duration_source": "hipEvents on the launch stream, this run (iff_march_shade_timed)",
+            "algorithmic_bytes_per_launch": round(nbytes), "peak_basis": peak_basis, "binding": binding, "note": note}
+
+
+class _QuietStdout:
+    """test_pose_estimation prints its averages (as the reference does); the bench's stdout carries ONE JSON line."""
+
+    def __enter__(self):
+        self._saved = sys.stdout
+        sys.stdout = sys.stderr
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout = self._saved
+
+
+def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=False):
+    """The reference's own call path (train_eval_pose_est.py:131-149), through the module names `iffnerf_amd.install()` registers:
+
+        rays_ori, rays_dirs, rays_rgb = explore_model(nerf_model, gen_points)
+        test_pose_estimation(test_dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, ...)
+
+    on a duck-typed dataset of `n_images` synthetic hw x hw RGBA queries (`all_rgbs` resident in HBM; `host_dataset`: in host
+    memory, every batch crossing PCIe inside the timed call).  DINOv2's published weights are not available offline: the hub
+    loader is pointed at the seeded stand-in with DINOv2 ViT-S/14's module tree (`create_backbone("dino")` itself runs unchanged
+    and serves it through iff_vit_forward).  -> poses/s of the second call (the first also captures the graphs) + parts."""
+    import tempfile
+    import torch
+    import iffnerf_amd
+    from iffnerf_amd import synthetic
+    iffnerf_amd.install(force=True)
+    from pose_estimation.model_utils import explore_model, load_model          # the reference's import lines
+    from pose_estimation import backbone as bb, identification_module as im
+    from pose_estimation.test import test_pose_estimation
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "tensorf_VM.th")
+        torch.save(ck, path)
+        model = load_model(path, device)
+    hub = bb._hub_load
+    bb._hub_load = lambda repo, name: bb.SeededViTS14(0)
+    try:
+        idm = im.IdentificationModule(backbone_type="dino")
+    finally:
+        bb._hub_load = hub
+    idm.load_state_dict({**idm.state_dict(), **idw})
+    idm = idm.to(device).eval()
+
+    class Dataset:
+        pass
+    gen = torch.Generator().manual_seed(17)
+    ds = Dataset()
+    rgba = torch.rand(n_images, hw, hw, 4, generator=gen)
+    rgba[..., 3] = (rgba[..., 3] > 0.2).float()
+    ds.all_rgbs = rgba if host_dataset else rgba.to(device)
+    ds.K = torch.eye(3)[None]
+    ds.all_rays = torch.zeros(n_images, 1, 6)
+    ds.poses = torch.eye(4).repeat(n_images, 1, 1)
+    torch.manual_seed(55176280)                       # the driver's starting_seed (train_eval_pose_est.py:252)
+    explore_model(model, gen_points=gen_points)       # first call: tables re-laid-out, handles created
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    rays = explore_model(model, gen_points=gen_points)
+    torch.cuda.synchronize(device)
+    t_explore = time.perf_counter() - t0
+    up = torch.tensor([0.0, 0.0, 1.0], device=device)
+    with _QuietStdout():
+        t0 = time.perf_counter()
+        test_pose_estimation(ds, idm, *rays, up)      # builds the encoder cache, captures the batch graphs
+        torch.cuda.synchronize(device)
+        t_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        res = test_pose_estimation(ds, idm, *rays, up)
+        torch.cuda.synchronize(device)
+        t_second = time.perf_counter() - t0
+    assert len(res[0]) == n_images and all(len(r["pred_c2w"]) == 4 for r in res[0])
+    return {"poses_per_s": round(n_images / t_second, 2), "images": n_images, "rays": int(rays[0].shape[0]),
+            "explore_model_ms": round(t_explore * 1e3, 3), "first_call_ms": round(t_first * 1e3, 2),
+            "dataset": "host memory (PCIe inside the timed call)" if host_dataset else "resident in HBM"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -200,7 +301,7 @@ def main():
     B = args.batch if args.batch > 0 else wl["queries"]          # queries per step and rank
     ck = synthetic.make_workload_ckpt(args.config)
     idw = synthetic.make_id_weights(seed=99)
-    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd import _lib, hip_identify as H
     gemm_mode = {"auto": H.GEMM_DEFAULT, "bf16x3": H.GEMM_BF16X3, "f16x2": H.GEMM_F16X2}[args.gemm]
     pipe = PosePipeline.from_checkpoints(ck, idw, device, model_up=(0.0, 0.0, 1.0), gemm_mode=gemm_mode,
                                          trunk_variant=args.trunk_variant)
@@ -269,6 +370,16 @@ def main():
     # K = 20 after W = 5 reads 14 650-14 970 poses/s, after W = 100 15 310-15 370, K = 200 after W = 20 15 370-15 450.  The timed
     # region is unchanged: exactly K steps between two barriers; `config.settle_steps` says how many untimed steps came before W.
     settle = max(0, args.settle - args.warmup)
+    # (the driver's literal protocol first -- W warm-up steps, K timed steps, nothing else before them -- reported as
+    # `value_without_settle` so the round-over-round series stays like-for-like)
+    dt_cold = None
+    if settle > 0:
+        run_steps(0, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.warmup, args.steps)
+        barrier()
+        dt_cold = time.perf_counter() - t0
     run_steps(0, settle)
     barrier()
     run_steps(settle, args.warmup)
@@ -278,9 +389,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if sharded:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt, dt_cold or 0.0], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        dt_cold = float(tmax[1].item()) if dt_cold is not None else None
     # the timed work produced valid poses: no sampler run timed out, and a replayed step equals the eager path on the same seed
     for g in graphs:
         g.check()
@@ -323,12 +435,17 @@ def main():
             "config": {"workload": "%s: %s, M=%d tokens, top-%d, cold path (A+B+C every step)" % (args.config, wl["describe"], M_TOKENS, TOPK),
                        "queries_per_step": queries_per_step, "queries_per_step_per_gpu": B if not shared else None,
                        "rays_per_query": n_rays, "steps_in_flight": in_flight, "settle_steps": settle,
+                       "library": os.path.relpath(_lib.LIB_PATH, ROOT), "dev_library": bool(_lib.DEV_LIBRARY),
                        "emissions_per_step": 1 if shared else queries_per_step,
                        "gemm": pipe.idnet.gemm_description(), "launch": launch,
                        "parallelism": "single GPU" if world_size == 1 else
                                       f"every query's rays sharded over {world_size} ranks (RCCL all_gathers over xGMI: "
                                       f"{'statistics, candidates' if shared else 'points + folded queries, statistics, candidates'})"},
         }
+        if dt_cold is not None:
+            result["value_without_settle"] = round(queries_per_step * args.steps / dt_cold, 3)
+            result["value_note"] = ("`value`: K steps timed after %d untimed settling steps + the W warm-up steps (steady clocks); "
+                                    "`value_without_settle`: the same K steps timed right after W warm-up steps only, the protocol of rounds 1-3" % settle)
         if sharded:      # what the process group itself reports (the collectives really ran over this many ranks of this backend)
             result["config"]["rccl_world_size"] = dist.get_world_size()
             result["config"]["collective_backend"] = dist.get_backend()
@@ -340,6 +457,25 @@ def main():
             result["cpu_baseline"] = cpu_baseline(ck, idw, tokens[:4].cpu(), gen_points, B if shared else 1)
         else:
             result["cpu_baseline"] = None
+        if world_size == 1 and not shared and not args.no_instrument and not args.no_dropin:
+            # the route a user of the reference takes (never part of `value`): explore_model + test_pose_estimation through the
+            # installed module names, at this workload's ray count and -- on the headline workload -- at the reference's default
+            # gen_points = 20000 (540 000 rays, pose_estimation/model_utils.py:22-24)
+            graphs.clear()
+            torch.cuda.empty_cache()
+            n_img = 128 if n_rays <= 70000 else 28
+            dr = {"this_workload": dropin_rates(ck, idw, device, gen_points, n_img)}
+            if args.config == "lego16k":
+                dr["host_dataset"] = dropin_rates(ck, idw, device, gen_points, 64, host_dataset=True)
+                dr["reference_default_540k_rays"] = dropin_rates(ck, idw, device, 20000, 28)
+            dr["note"] = ("iffnerf_amd.install(); explore_model(model, gen_points) once, then test_pose_estimation(dataset, id_module, rays_ori, "
+                          "rays_dirs, rays_rgb, model_up) as train_eval_pose_est.py:131-149 calls it, on synthetic 800x800 RGBA queries: images per "
+                          "second of the SECOND call (the first also builds the encoder cache and captures the batch graphs: first_call_ms).  "
+                          "Batches of 32 images (540 000 rays: 7) as captured hipGraphs on two alternating streams, one device->host read per "
+                          "batch; results bit-identical to the image-by-image route (tests/test_hip_eval_loop.py).  Backbone: DINOv2 ViT-S/14's "
+                          "architecture with seeded stand-in weights through iff_vit_forward in the fp32 class")
+            result["dropin"] = dr
+            result["dropin_poses_per_s"] = dr["this_workload"]["poses_per_s"]
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
@@ -411,12 +547,17 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
     # `achieved` = ALGORITHMIC flops / bytes of SURVEY.md section 8(d) over the launch time; `traffic` = HBM-side bytes per launch
     # from the rocprofv3 PMC passes of profiles/ (only while they were collected on these kernel sources and this --config),
     # `hbm_frac_from_counters` = that over the launch time over the 8 TB/s HBM peak.
-    pmc, pmc_name = {}, "profiles/r04_hbm_traffic_%s.json" % args.config
-    try:
-        with open(os.path.join(ROOT, pmc_name)) as fh:
-            pmc = json.load(fh)
-    except (OSError, ValueError):
-        pass
+    # the newest profiles/rNN_hbm_traffic_<config>.json; it counts only while it was collected on the kernel sources benchmarked here
+    pmc, pmc_name = {}, "profiles/r??_hbm_traffic_%s.json" % args.config
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic_%s.json" % args.config)), reverse=True):
+        try:
+            with open(cand) as fh:
+                pmc = json.load(fh)
+            pmc_name = os.path.relpath(cand, ROOT)
+            break
+        except (OSError, ValueError):
+            continue
     fresh = pmc.get("source_sha16") == source_fingerprint() and pmc.get("config") == args.config
     traffic_source = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2x FETCH correction), same kernel sources"
                       % pmc_name if fresh else "null: %s is absent or was measured on other kernel sources (stale)" % pmc_name)
@@ -478,10 +619,7 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                 "mfma_issue_frac is that over the same peak" % products}]
 
     def gather_kernel(name, keys, bound, peak, nbytes, ms, note):
-        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": name, "rays_per_launch": rays_per_launch, "bound": bound, "achieved": round(gbs, 1), "peak": round(peak, 1),
-                "unit": "GB/s", "frac": round(gbs / peak, 4), "traffic": traffic(*keys), "avg_launch_ms": round(ms, 4),
-                "algorithmic_bytes_per_launch": round(nbytes), "peak_basis": peak_basis, "binding": binding(ms, *keys), "note": note}
+        return gather_kernel_entry(name, rays_per_launch, bound, peak, nbytes, ms, traffic(*keys), binding(ms, *keys), note, peak_basis)
 
     plan = pipe.field.march_plan(0, 20)
     if plan in (2, 3):
@@ -584,6 +722,34 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
         result["image_to_pose_per_s"] = image_rate(ImageFrontEnd(net, grid), WQ)
         result["image_to_pose_per_s_bf16_backbone"] = image_rate(ImageFrontEnd(fast, grid), WQ)
         result["image_to_pose_per_s_torch_fp32_backbone"] = image_rate(ImageFrontEnd(stock, grid), 16)      # (MIOpen's first use of a new batch shape takes minutes)
+        # 800 x 800 RGBA in -> emission -> pose out, every image against its OWN freshly drawn ray set: the whole north-star path with
+        # the image side included, one hipGraph per batch of B images, the same number in flight as the timed steps
+        from iffnerf_amd.pipeline import CapturedColdImageQuery
+        CB = min(B, WQ)
+        fe_net = ImageFrontEnd(net, grid)
+        cgraphs = [CapturedColdImageQuery(pipe, fe_net, (CB, 800, 800, 4), gen_points, seed=(9 + g) << 40, k=TOPK) for g in range(4)]
+        rgba_all = torch.cat((imgs_all[:CB], masks_all[:CB, ..., None]), dim=-1).contiguous()
+        for g in cgraphs:
+            g.rgba.copy_(rgba_all)
+        torch.cuda.synchronize(device)
+        for i in range(8):
+            with torch.cuda.stream(wstreams[i % 4]):
+                cgraphs[i % 4].replay()
+        torch.cuda.synchronize(device)
+        tc = time.perf_counter()
+        for i in range(n_i):
+            with torch.cuda.stream(wstreams[i % 4]):
+                cgraphs[i % 4].replay()
+        torch.cuda.synchronize(device)
+        result["cold_image_to_pose_per_s"] = round(n_i * CB / (time.perf_counter() - tc), 2)
+        for g in cgraphs:
+            g.check()
+            assert torch.isfinite(g.c2w).all()
+        result["cold_image_to_pose_note"] = ("%d synthetic 800x800 RGBA queries per captured graph, EACH with its own freshly drawn ray set: composite + "
+                                             "resize / crop / normalise, ViT-S/14 in the fp32 class (stand-in weights: parity unpinned at the DINOv2 boundary), "
+                                             "token assembly, surface sampler, march, encoder + logits, score, top-%d, pose; 4 graphs in flight; never part "
+                                             "of `value`" % (CB, TOPK))
+        del cgraphs
         result["image_to_pose_note"] = ("32 (stock torch backbone: 16) synthetic 800x800 RGBA queries per captured graph: bicubic resize / crop / normalise + ViT-S/14 "
                                         "(DINOv2's architecture, seeded stand-in weights) + token assembly kernel + stage C on resident rays "
                                         "with the cached encoder; 4 graphs in flight; never part of `value`.  image_to_pose_per_s runs the "

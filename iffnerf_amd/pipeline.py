@@ -157,11 +157,12 @@ class PosePipeline:
         return self.identify(tokens, ori, dirs, rgb, k, materialize_map)
 
     # ------------------------------------------------------------------ a batch of cold queries in one set of launches
-    def query_batch(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None):
+    def query_batch(self, tokens, gen_points: int, seed: int, k: int = 100, seed_offset=None, keep=None):
         """``tokens`` [B,M,C+14]: B cold queries, each with its OWN freshly drawn ray set, served by one launch per stage
         (batched sampler, one march over B*27P rays, one encoder/logits launch with grid.y = query, batched score / top-k
         / pose).  Query b equals ``query(tokens[b], gen_points, seed + b * SAMPLER_SEED_STRIDE)`` bit for bit.
-        -> (c2w [B,4,4], idx [B,k], val [B,k])."""
+        ``keep`` [B,M] (``image_frontend.token_assemble``): the mask select of identification_module.py:157-160 applied to the
+        softmax rows.  -> (c2w [B,4,4], idx [B,k], val [B,k])."""
         B, M, C = tokens.shape
         if not self.fold_heads:
             raise RuntimeError("query_batch runs the folded path (fold_heads=True)")
@@ -171,6 +172,9 @@ class PosePipeline:
         ori, dirs, rgb = self.emit_from_samples(samples.reshape(B * gen_points, 3))          # query-major: [B * 27P, 3]
         qf = self.idnet.q_fold(tokens.reshape(B * M, C))
         logits, rmax, rsum = self.idnet.ray_logits_folded_batched(qf, ori, dirs, rgb, B)
+        if keep is not None:
+            from .image_frontend import mask_token_rows
+            mask_token_rows(keep, rmax, rsum)
         score = H.attn_colsum_batched(logits, rmax, rsum, B, write_attention=False)
         idx, val = H.topk_batched(score, k)
         n = ori.shape[0] // B
@@ -509,6 +513,43 @@ class CapturedShardedBatch:
     def replay(self, tokens: Optional[torch.Tensor] = None):
         self.replay_head(tokens)
         return self.replay_tail()
+
+
+class CapturedColdImageQuery:
+    """Image in -> emission -> pose out: B RGBA query images [B,H,W,4], EACH against its own freshly drawn ray set (the north
+    star's "per-query" path with the image side included) as one hipGraph -- ``ImageFrontEnd.tokens_rgba`` (composite, resize /
+    crop, backbone, token assembly) then ``query_batch`` (surface sampler, march, encoder + logits, score, top-k, pose)."""
+
+    def __init__(self, pipe: PosePipeline, frontend, imgs_shape, gen_points: int, seed: int = 0, k: int = 100):
+        dev = pipe.device
+        self.rgba = torch.zeros(imgs_shape, dtype=torch.float32, device=dev)
+        self.rgba[..., 3] = 1.0
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def run():
+            tokens, keep = frontend.tokens_rgba(self.rgba)
+            return pipe.query_batch(tokens, gen_points, seed, k, seed_offset=self.counter, keep=keep)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.counter += 1
+            self.c2w, self.idx, self.val = run()
+            self.sampler_stats = pipe.last_sampler_stats
+
+    def check(self) -> None:
+        check_sampler_stats(self.sampler_stats)
+
+    def replay(self, rgba: Optional[torch.Tensor] = None):
+        if rgba is not None:
+            self.rgba.copy_(rgba, non_blocking=True)
+        self.graph.replay()
+        return self.c2w
 
 
 class CapturedImageQuery:

@@ -1,7 +1,8 @@
 """Mirror of ``pose_estimation/sampling.py`` for the path (stage A and the caller of stage B).
 
 Same function names and signatures as the reference.  Everything runs in libiffnerf_hip:
-the surface sampler is one persistent kernel (``iff_surface_sample``), normals ``iff_point_normals``, the 27-ray fan
+the surface sampler is a chain of short launches behind ``iff_surface_sample`` (its persistent one-launch form is a handle option kept for
+parity tests), normals ``iff_point_normals``, the 27-ray fan
 ``iff_isocell_emit``, ray colours one ``iff_march_shade`` launch (the reference's 10 240-ray chunking is a memory
 workaround of its boolean-compaction formulation and has no effect on results; ``num_viewdirs_per_chunk`` is accepted
 and ignored).  The sampler draws from a device-side counter-based generator seeded from torch's global generator, so

@@ -69,3 +69,19 @@ def test_traffic_figure_is_keyed_on_the_kernel_sources():
         assert j["config"] == cfg and len(j["source_sha16"]) == 16
         for k in ("k5_trunk_h<1, 1, 2>", march):
             assert j["kernels"][k]["hbm_bytes_per_launch"] > 0 and j["kernels"][k]["valu_wave_insts"] > 0, (cfg, k)
+
+
+def test_roofline_object_states_both_hbm_readings():
+    """The march's roofline object prints SURVEY 8(d)'s own fraction (algorithmic bytes / time / 8 TB/s: above 1 for the fused fan
+    kernel, labelled as not a bound) and the HBM fraction from the counters beside the LDS-model `frac` -- round 4's numbers in."""
+    import bench
+    e = bench.gather_kernel_entry("k4f_fan_march<3>", 512352, "lds-gather", bench.LDS_PEAK_GBS, 38260922573, 1.0406, 1284353698, {"lds_busy": 0.6},
+                                  "note", "basis")
+    assert abs(e["frac_8d"] - 4.596) < 0.01 and "not" in e["frac_8d_note"].lower()
+    assert abs(e["frac_hbm_counters"] - 0.1543) < 0.001 and abs(e["frac"] - 0.2338) < 0.001
+    assert e["traffic"] == 1284353698 and e["bound"] == "lds-gather" and e["duration_source"].startswith("hipEvents")
+    stale = bench.gather_kernel_entry("k", 1, "l1-gather", bench.L1_PEAK_GBS, 1e9, 1.0, None, None, "", "")
+    assert stale["frac_hbm_counters"] is None and stale["traffic"] is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ("dropin_poses_per_s", "cold_image_to_pose_per_s", "value_without_settle", "dev_library"):
+        assert '"%s"' % key in src, key
