@@ -36,7 +36,7 @@ class FieldDesc(C.Structure):
         ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
         ("step_size", C.c_float), ("n_samples", C.c_int32), ("near_far", C.c_float * 2),
         ("softplus", C.c_int32), ("unisphere", C.c_int32), ("density_lanes", C.c_int32), ("head_lanes", C.c_int32),
-        ("sampler_persistent", C.c_int32),
+        ("sampler_persistent", C.c_int32), ("fan_waves", C.c_int32),
         ("normal_w", C.c_void_p), ("normal_b", C.c_void_p), ("tint_w", C.c_void_p), ("tint_b", C.c_void_p),
         ("rough_w", C.c_void_p), ("rough_b", C.c_void_p), ("diffuse_w", C.c_void_p), ("diffuse_b", C.c_void_p),
         ("bottleneck_w", C.c_void_p), ("bottleneck_b", C.c_void_p), ("specular_w", C.c_void_p), ("specular_b", C.c_void_p),

@@ -19,7 +19,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libiffnerf_hip.so")
-SOURCES = ["api.hip", "field_kernels.hip", "march_kernels.hip", "fan_march_kernels.hip", "march_grad_kernels.hip", "sampler_kernels.hip", "identify_kernels.hip", "trunk_f16_kernels.hip", "vit_kernels.hip",
+SOURCES = ["api.hip", "field_kernels.hip", "march_kernels.hip", "fan_march_kernels.hip", "fan8_march_kernels.hip", "march_grad_kernels.hip", "sampler_kernels.hip", "identify_kernels.hip", "trunk_f16_kernels.hip", "vit_kernels.hip",
            "pose_kernels.hip", "shard_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]

@@ -123,6 +123,7 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     if (int rc = check_field_dims(G, d->n_density, d->n_app, d->app_dim, d->feature_c, d->density_lanes, d->mask_dims, d->mask_volume != nullptr))
         return rc;
     IFF_REQUIRE(d->head_lanes == 0 || d->head_lanes == 16, "head_lanes = %d: must be 0 (auto) or 16", d->head_lanes);
+    IFF_REQUIRE(d->fan_waves == 0 || d->fan_waves == 4 || d->fan_waves == 8, "fan_waves = %d: must be 0 (auto), 4 or 8", d->fan_waves);
 
     iff_field* f = new iff_field();
     FieldDev& v = f->dev;
@@ -203,6 +204,7 @@ extern "C" int iff_field_create(const iff_field_desc* d, void* stream, iff_field
     v.step_size = d->step_size; v.near = d->near_far[0]; v.far = d->near_far[1];
     v.n_samples = d->n_samples; v.softplus = d->softplus; v.unisphere = d->unisphere;
     v.density_lanes = d->density_lanes; v.head_lanes = d->head_lanes; v.sampler_persistent = d->sampler_persistent ? 1 : 0;
+    v.fan_waves = d->fan_waves;
     v.n_density = d->n_density; v.n_app = d->n_app; v.app_dim = d->app_dim; v.feature_c = d->feature_c;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -956,7 +958,7 @@ extern "C" int iff_merge_candidates(const float* cand_all, int32_t G, int32_t Qt
 //   slab bytes | extra (field: the occupied-voxel list, int32 each)
 // The descriptor struct's size is stored and checked, so a file written by a build with another struct layout is refused
 // rather than misread; IFF_TABLE_FILE_VERSION changes whenever a table's layout does.
-#define IFF_TABLE_FILE_VERSION 2          // 2: the field slab carries the corner-bit occupancy table (FieldDev::cell)
+#define IFF_TABLE_FILE_VERSION 3          // 2: the field slab carries the corner-bit occupancy table (FieldDev::cell); 3: FieldDev::fan_waves
 struct TableFileHeader {
     char magic[8];              // "IFFTABLE"
     uint32_t version, kind;     // kind 1 = field, 2 = idnet
@@ -1071,7 +1073,7 @@ static int validate_field_file(const char* path, const FieldDev& v, size_t slab_
          stored_is(v.head, true, L.head) && stored_is(v.mask, has_mask, L.mask) && stored_is(v.cell, has_mask, L.cell);
     if (!ok) return fail(IFF_ERR_INVALID_ARGUMENT, "%s: the table offsets / slab size do not match the dimensions the file claims", path);
     IFF_REQUIRE(v.n_samples >= 1 && (v.softplus == 0 || v.softplus == 1) && (v.unisphere == 0 || v.unisphere == 1) && v.step_size > 0.0f &&
-                    v.step_size < 1e30f && (v.head_lanes == 0 || v.head_lanes == 16) && (v.sampler_persistent == 0 || v.sampler_persistent == 1),
+                    v.step_size < 1e30f && (v.head_lanes == 0 || v.head_lanes == 16) && (v.sampler_persistent == 0 || v.sampler_persistent == 1) && (v.fan_waves == 0 || v.fan_waves == 4 || v.fan_waves == 8),
                 "%s: implausible march parameters", path);
     IFF_REQUIRE(occ.size() <= L.n_mask, "%s: %zu occupied voxels listed for a mask of %zu", path, occ.size(), L.n_mask);
     for (int i : occ) IFF_REQUIRE(i >= 0 && (size_t)i < L.n_mask, "%s: occupied-voxel index %d outside the mask", path, i);

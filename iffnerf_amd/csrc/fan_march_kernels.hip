@@ -24,6 +24,8 @@
 #include "iff_device.h"
 #include "iff_launch.h"
 #include "march_common.h"
+#include "fan_common.h"
+#include "fan_diag.h"
 
 namespace {
 
@@ -43,134 +45,6 @@ static_assert(BASIS_FLOATS <= PATCH_FLOATS, "basis_mat is staged in the patch bu
 #define FAN_WAVES 3            // waves per SIMD the register budget is set for (three 256-thread workgroups per CU)
 #endif
 typedef uint32_t u32q __attribute__((ext_vector_type(4)));
-// FAN_STAMPS (diagnostic build only): wave w of a tile stores the low word of s_memtime after each phase into the tile's
-// slice of the optional alpha output ([R,20] floats: slot 16 w + k), which then carries no alphas.
-#ifdef FAN_STAMPS
-#define STAMP(k) do { if (a.alpha && lane == 0 && n_live == FR) reinterpret_cast<uint32_t*>(a.alpha)[ray0 * FS + 16 * wave + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
-// FAN_EXIT_AFTER=k (timing / counter builds only): every tile stops after the phase that ends at stamp k -- the vector-instruction count
-// of a phase is the difference of two such builds' SQ_INSTS_VALU (scripts/pmc_fan_phases.sh)
-#ifdef FAN_EXIT_AFTER
-#define FAN_EXIT(k) do { if (FAN_EXIT_AFTER == (k)) return; } while (0)
-#else
-#define FAN_EXIT(k) do { } while (0)
-#endif
-#if defined(FAN_STAMPS) && FAN_STAMPS == 2
-#define ESTAMP(k) STAMP(k)
-#else
-#define ESTAMP(k) do { } while (0)
-#endif
-
-__device__ __forceinline__ f32q splat(float v) { return (f32q)(v); }
-// cross-lane moves as DPP modifiers of vector-ALU instructions (__shfl_xor compiles to ds_bpermute_b32: a round trip through
-// the LDS crossbar per call)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-// sum over the 4 lanes of a quad, in the order of sum4 (iff_device.h): (v + xor1) then (+ xor2)
-__device__ __forceinline__ float sum4_dpp(float v) {
-    v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
-    return v;
-}
-// the value of lane (i xor 4): reverse inside the quad (quad_perm [3,2,1,0]), then mirror the 8-lane half row (row_half_mirror)
-__device__ __forceinline__ float xor4_dpp(float v) { return dpp_mov<0x141>(dpp_mov<0x1B>(v)); }
-// Bilinear / linear combination of tap quarters in the operation order of lerp_plane4 / lerp_line4 (iff_device.h): one multiply and
-// fused multiply-adds per component.  THE LIBRARY IS BUILT WITHOUT PACKED FP32 INSTRUCTIONS (iffnerf_amd/build.py: -packed-fp32-ops;
-// tests/test_isa_rules.py checks the shipped code objects), so these vector expressions compile to one v_mul / v_fma per component.
-// Why: left to itself the compiler turns this function into v_pk_mul_f32 / v_pk_fma_f32 on register pairs with the weight broadcast
-// by op_sel, and THAT code returned wrong sums for the last sixteen lanes of a wave -- rays 6, 7 (+ 8 w) of a tile, waves 0-2 --
-// in 0.7 % of the steps (14 of 2 000 checked, 4 of 480), always in the last ~300 tiles of a march and only while a workgroup of
-// the encoder / logits kernel (k5_trunk_h: fp16 MFMA) shared the CU: with four captured steps in flight the tail of a march runs
-// next to another step's trunk.  Evaluating phase C twice in the same workgroup and comparing catches every event: a transient of
-// the execution, not stale LDS.  What the investigation ("the packed-fp32 fault") excluded: missing waits (the
-// s_waitcnt sequence of the faulty loop was checked load by load), waits / barriers / idle cycles around every LDS access, DPP vs
-// ds_bpermute, occupancy, scratch (none), the matrix-core row order of phase D -- and the instruction FORM: the same products as
-// hand-placed v_pk_mul_f32 / v_pk_fma_f32 (-DFAN_LERP_ASM=1..8 below: op_sel broadcast with a small-integer, equal or 1.0f high
-// half, real (w, w) pairs, the weight as src0 or src1, every destination written over the broadcast pair, every destination
-// disjoint) show 0 events in 6 400 checked steps, next to 18 in 2 480 for the compiler's own packing in the same runs.  So the
-// trigger is the compiler's schedule of packed fp32 code next to MFMA work, not an operand form one could avoid by hand; no packed
-// fp32 instruction is the rule that holds for all ~8 000 the compiler had placed in this library, and it costs nothing measurable
-// (14 590-14 760 poses/s without, 14 590-14 810 with, same box, same run).
-#if defined(FAN_LERP_ASM)
-// Experiment builds of the packed-fp32 investigation (need +packed-fp32-ops; scripts/packed_fp32_forms.sh builds and runs them): the tap combination
-// as hand-placed v_pk_mul_f32 / v_pk_fma_f32 with the weight operand in a chosen form.  FAN_LERP_ASM = 1: op_sel broadcast of the low half, high half = a small integer (what the
-// compiler's own packing leaves there: an LDS address); 2: broadcast, high half = the weight again; 3: broadcast, high half = 1.0f;
-// 4: no op_sel, a real (w, w) pair; 6: broadcast with the weight as src0 (the form of the compositing-weight accumulate);
-// 7: as 1 with every result written OVER the broadcast pair (the destination overlaps the op_sel source); 8: as 1 with every
-// destination disjoint from its sources.
-typedef float f32p __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float opq(float v) { asm volatile("" : "+v"(v)); return v; }
-__device__ __forceinline__ f32p wpair(float w) {
-#if FAN_LERP_ASM == 1 || FAN_LERP_ASM == 6 || FAN_LERP_ASM == 7 || FAN_LERP_ASM == 8
-    return f32p{w, __uint_as_float(0x1200u + 16u * (threadIdx.x & 63u))};
-#elif FAN_LERP_ASM == 3
-    return f32p{w, opq(1.0f)};
-#else
-    return f32p{w, opq(w)};
-#endif
-}
-__device__ __forceinline__ f32p pk_mul_w(f32p x, f32p w) {
-    f32p r;
-#if FAN_LERP_ASM == 4
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(w), "v"(x));
-#elif FAN_LERP_ASM == 7          // the destination IS the broadcast source pair
-    asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[0,1]" : "+v"(w) : "v"(x));
-    r = w;
-#elif FAN_LERP_ASM == 8          // the destination never overlaps a source (early clobber)
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=&v"(r) : "v"(w), "v"(x));
-#else
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(x));
-#endif
-    return r;
-}
-__device__ __forceinline__ f32p pk_fma_w(f32p x, f32p w, f32p c) {
-    f32p r;
-#if FAN_LERP_ASM == 4
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(w), "v"(c));
-#elif FAN_LERP_ASM == 6
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(x), "v"(c));
-#elif FAN_LERP_ASM == 7
-    asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[1,0,1]" : "+v"(w) : "v"(x), "v"(c));
-    r = w;
-#elif FAN_LERP_ASM == 8
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=&v"(r) : "v"(x), "v"(w), "v"(c));
-#else
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(w), "v"(c));
-#endif
-    return r;
-}
-__device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
-    const f32p w0 = wpair(pw[0]), w1 = wpair(pw[1]), w2 = wpair(pw[2]), w3 = wpair(pw[3]);
-    f32p lo = pk_mul_w(f32p{nw.x, nw.y}, w0), hi = pk_mul_w(f32p{nw.z, nw.w}, w0);
-    lo = pk_fma_w(f32p{ne.x, ne.y}, w1, lo); hi = pk_fma_w(f32p{ne.z, ne.w}, w1, hi);
-    lo = pk_fma_w(f32p{sw.x, sw.y}, w2, lo); hi = pk_fma_w(f32p{sw.z, sw.w}, w2, hi);
-    lo = pk_fma_w(f32p{se.x, se.y}, w3, lo); hi = pk_fma_w(f32p{se.z, se.w}, w3, hi);
-    return f32q{lo.x, lo.y, hi.x, hi.y};
-}
-__device__ __forceinline__ f32q lerp_line_q(f32q lo_, f32q hi_, const float lw[2]) {
-    const f32p w0 = wpair(lw[0]), w1 = wpair(lw[1]);
-    f32p lo = pk_mul_w(f32p{lo_.x, lo_.y}, w0), hi = pk_mul_w(f32p{lo_.z, lo_.w}, w0);
-    lo = pk_fma_w(f32p{hi_.x, hi_.y}, w1, lo); hi = pk_fma_w(f32p{hi_.z, hi_.w}, w1, hi);
-    return f32q{lo.x, lo.y, hi.x, hi.y};
-}
-#else
-__device__ __forceinline__ f32q lerp_plane_q(f32q nw, f32q ne, f32q sw, f32q se, const float pw[4]) {
-    f32q r = nw * splat(pw[0]);
-    r = __builtin_elementwise_fma(ne, splat(pw[1]), r);
-    r = __builtin_elementwise_fma(sw, splat(pw[2]), r);
-    r = __builtin_elementwise_fma(se, splat(pw[3]), r);
-    return r;
-}
-__device__ __forceinline__ f32q lerp_line_q(f32q lo, f32q hi, const float lw[2]) {
-    f32q r = lo * splat(lw[0]);
-    return __builtin_elementwise_fma(hi, splat(lw[1]), r);
-}
-#endif
-
 // ---- coalesced patch fetch: chunk = one 16-B piece; a patch row (12 texels) is one contiguous run of the table.
 // `fast` = the patch lies inside the table (no clamping).  Byte offset of chunk `chunk` of a C-channel plane patch:
 template <int C>
@@ -215,239 +89,6 @@ __device__ __forceinline__ RecView read_rec(const uint32_t* rec) {
     return unpack_rec(*reinterpret_cast<const u32q*>(rec), *reinterpret_cast<const u32q*>(rec + 4));
 }
 
-// Ref.forward (models/ref.py:103-152, normals=None) for one ray by EIGHT lanes (`sub` = the lane's index in the group): the per-ray
-// part of the head after the two matrix products (bottleneck rows and the ten small-head rows, phase E of the fused kernel) --
-// activations, reflection, integrated directional encoding (ref_utils.py:82-112), the specular layer, sigmoid and sRGB.
-// `sb` = this ray's LDS row: [0, fc) the bottleneck outputs (bias added), [fc, fc + 10) scratch for the small heads; `F` = the ray's
-// feature row; `small` = the head up to bott_w (the four small heads), `tail` = the head from spec_w on (spec_w, spec_b, ide_mat),
-// both in LDS.
-// The arithmetic is ref_shade_group16's (iff_device.h), operation for operation: that kernel spreads the specular sum of a ray
-// over 16 lanes (lane l takes the encoding pairs l, l + 16 and the bottleneck features l + 16 t) and adds the lanes by butterfly
-// (xor 1, 2, 4, 8); here lane `sub` carries the partial sums l = sub and l = sub + 8, the butterfly runs over xor 1, 2, 4 on each
-// and the two results are added -- the xor-8 step -- so both forms return the same bits.  The three colour channels are
-// finished by sub = 0, 1, 2; the return value is this lane's channel (sub < 3).
-__device__ __forceinline__ float ref_head_oct(const float* small, const HeadOff& ho, int fc, float* sb, const float* F, const float* tail,
-                                             const float d[3], int sub) {
-    // the ten small-head rows (normal 0-2, tint 3-5, diffuse 6-8, roughness 9), rows sub and sub + 8 on this lane: the fmaf chain,
-    // bias add and activation of ref_shade_group16, computed once per ray and handed round the group through the ray's LDS row
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int row = sub + 8 * u;
-        if (row < 10) {
-            const int blk = row / 3, o = row - 3 * blk;                       // blk 0 normal, 1 tint, 2 diffuse, 3 roughness
-            const int w_off = blk == 0 ? ho.normal_w : (blk == 1 ? ho.tint_w : (blk == 2 ? ho.diffuse_w : ho.rough_w));
-            const int b_off = blk == 0 ? ho.normal_b : (blk == 1 ? ho.tint_b : (blk == 2 ? ho.diffuse_b : ho.rough_b));
-            const float* wr = small + w_off + o * 28;
-            float acc = 0.0f;
-#pragma unroll
-            for (int k4 = 0; k4 < 28; k4 += 4) {
-                const f32q w4 = *reinterpret_cast<const f32q*>(wr + k4), f4 = *reinterpret_cast<const f32q*>(F + k4);
-                acc = fmaf(w4[0], f4[0], acc); acc = fmaf(w4[1], f4[1], acc); acc = fmaf(w4[2], f4[2], acc);
-                acc = fmaf(w4[3], k4 + 3 == 27 ? 0.0f : f4[3], acc);           // column 27 of the row is the shaded flag, not a feature
-            }
-            const float raw = acc + small[b_off + o];
-            const float x = raw + (blk == 2 ? -1.0986122886681098f : -1.0f);     // diffuse: - ln 3; roughness: - 1
-            float mine = raw;
-            if (blk == 3) mine = softplusf_(x);
-            else if (blk != 0) mine = sigmoidf_(blk == 1 ? raw : x);
-            sb[fc + row] = mine;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the eight lanes of a ray are lanes of one wave
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float nr[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) nr[o] = sb[fc + o];
-    const int ch = sub < 3 ? sub : 0;                            // this lane's colour channel (sub < 3; the others repeat channel 0 and drop it)
-    const float tint_c = sb[fc + 3 + ch], diff_c = sb[fc + 6 + ch];
-    const float rough = sb[fc + 9];
-    float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
-    float n[3] = {-(nr[0] / nn), -(nr[1] / nn), -(nr[2] / nn)};
-    float v[3] = {-d[0], -d[1], -d[2]};
-    float ndv = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
-    float r[3] = {2.0f * ndv * n[0] - v[0], 2.0f * ndv * n[1] - v[1], 2.0f * ndv * n[2] - v[2]};
-    float dot = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
-    const int K = fc + 39, KL = ho.spec_ld;
-    const float* spec_w = tail;                                 // [3][KL]
-    const float* spec_b = tail + (ho.spec_b - ho.spec_w);
-    const float* ide_mat = tail + (ho.ide_mat - ho.spec_w);     // [9][19]
-    float part[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    float zp[9];
-    zp[0] = 1.0f;
-#pragma unroll
-    for (int k = 1; k < 9; ++k) zp[k] = zp[k - 1] * r[2];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int i = sub + 8 * u;                              // pairs sub, sub + 8, sub + 16: partial sums l = i & 15
-        if (i < 19) {
-            const int l = (i < 2) ? 1 : (i < 5) ? 2 : (i < 10) ? 4 : 8;
-            const int m = i - ((i < 2) ? 0 : (i < 5) ? 2 : (i < 10) ? 5 : 10);
-            float pr = 1.0f, pi = 0.0f;
-            for (int q = 0; q < m; ++q) {
-                float t = pr * r[0] - pi * r[1];
-                pi = pr * r[1] + pi * r[0];
-                pr = t;
-            }
-            float poly = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) poly = fmaf(zp[k], ide_mat[k * 19 + i], poly);
-            const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
-            const float re = pr * poly * att, im = pi * poly * att;
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-                part[o][u & 1] = fmaf(spec_w[o * KL + fc + 2 * i], re, fmaf(spec_w[o * KL + fc + 2 * i + 1], im, part[o][u & 1]));
-        }
-    }
-    // bottleneck features j = 16 t + sub + 8 u into partial sum u, t ascending.  All LDS reads of a batch of two t are issued
-    // before the batch's first fmaf (one read-to-use round trip per batch, not per feature)
-#pragma unroll 4
-    for (int j0 = 0; j0 < fc; j0 += 32) {
-        float b[4], wv[3][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = j0 + 8 * q + sub;                     // q = 2 t' + u
-            b[q] = sb[j];
-#pragma unroll
-            for (int o = 0; o < 3; ++o) wv[o][q] = spec_w[o * KL + j];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int o = 0; o < 3; ++o) part[o][q & 1] = fmaf(wv[o][q], b[q], part[o][q & 1]);
-    }
-    float ps[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const float first = fmaf(spec_w[o * KL + K - 1], dot, part[o][0]) + spec_b[o];
-        float lo = sub == 0 ? first : part[o][0], hi = part[o][1];
-        lo += dpp_mov<0xB1>(lo); hi += dpp_mov<0xB1>(hi);       // xor 1
-        lo += dpp_mov<0x4E>(lo); hi += dpp_mov<0x4E>(hi);       // xor 2
-        lo += xor4_dpp(lo); hi += xor4_dpp(hi);                 // xor 4
-        ps[o] = lo + hi;                                        // xor 8
-    }
-    const float sg = sigmoidf_(ch == 0 ? ps[0] : (ch == 1 ? ps[1] : ps[2]));
-    float c = srgbf_(tint_c * sg + diff_c);
-    c = fminf(fmaxf(c, 0.0f), 1.0f);
-    return c * 1.002f - 0.001f;
-}
-
-// The same head for one ray by FOUR lanes (`sub` = the lane's index in the quad): the fused kernel's phase E runs it in TWO of the
-// tile's four waves (32 ray slots x 4 lanes) and lets the other two leave -- the per-ray part of the head is mostly arithmetic every
-// lane of a ray repeats (normalisation, reflection, the powers of r_z, the final sigmoid / sRGB), so a wave-level instruction serves
-// 16 rays instead of 8 and the tile issues ~40 % fewer vector instructions for the phase.  Bit for bit ref_head_oct /
-// ref_shade_group16: lane `sub` carries the FOUR partial sums l = sub + 4 p of the sixteen (pairs i = l, then l + 16; bottleneck
-// features l + 16 t, t ascending), the butterfly runs xor 1, 2 across the quad's lanes on each, and the xor-4 and xor-8 steps are the
-// additions (p0 + p1) + (p2 + p3); the ten small-head rows are rows sub, sub + 4, sub + 8.
-__device__ __forceinline__ float ref_head_quad(const float* small, const HeadOff& ho, int fc, float* sb, const float* F, const float* tail,
-                                              const float d[3], int sub) {
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int row = sub + 4 * u;
-        if (row < 10) {
-            const int blk = row / 3, o = row - 3 * blk;
-            const int w_off = blk == 0 ? ho.normal_w : (blk == 1 ? ho.tint_w : (blk == 2 ? ho.diffuse_w : ho.rough_w));
-            const int b_off = blk == 0 ? ho.normal_b : (blk == 1 ? ho.tint_b : (blk == 2 ? ho.diffuse_b : ho.rough_b));
-            const float* wr = small + w_off + o * 28;
-            float acc = 0.0f;
-#pragma unroll
-            for (int k4 = 0; k4 < 28; k4 += 4) {
-                const f32q w4 = *reinterpret_cast<const f32q*>(wr + k4), f4 = *reinterpret_cast<const f32q*>(F + k4);
-                acc = fmaf(w4[0], f4[0], acc); acc = fmaf(w4[1], f4[1], acc); acc = fmaf(w4[2], f4[2], acc);
-                acc = fmaf(w4[3], k4 + 3 == 27 ? 0.0f : f4[3], acc);
-            }
-            const float raw = acc + small[b_off + o];
-            const float x = raw + (blk == 2 ? -1.0986122886681098f : -1.0f);
-            float mine = raw;
-            if (blk == 3) mine = softplusf_(x);
-            else if (blk != 0) mine = sigmoidf_(blk == 1 ? raw : x);
-            sb[fc + row] = mine;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the four lanes of a ray are lanes of one wave
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float nr[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) nr[o] = sb[fc + o];
-    const int ch = sub < 3 ? sub : 0;
-    const float tint_c = sb[fc + 3 + ch], diff_c = sb[fc + 6 + ch];
-    const float rough = sb[fc + 9];
-    float nn = fmaxf(sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), 1e-12f);
-    float n[3] = {-(nr[0] / nn), -(nr[1] / nn), -(nr[2] / nn)};
-    float v[3] = {-d[0], -d[1], -d[2]};
-    float ndv = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
-    float r[3] = {2.0f * ndv * n[0] - v[0], 2.0f * ndv * n[1] - v[1], 2.0f * ndv * n[2] - v[2]};
-    float dot = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
-    const int K = fc + 39, KL = ho.spec_ld;
-    const float* spec_w = tail;
-    const float* spec_b = tail + (ho.spec_b - ho.spec_w);
-    const float* ide_mat = tail + (ho.ide_mat - ho.spec_w);
-    float part[3][4];
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) part[o][q] = 0.0f;
-    float zp[9];
-    zp[0] = 1.0f;
-#pragma unroll
-    for (int k = 1; k < 9; ++k) zp[k] = zp[k - 1] * r[2];
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        const int i = sub + 4 * u;                              // pairs sub + 4 p (p = u < 4: partial p), then sub + 16 (partial 0)
-        if (i < 19) {
-            const int l = (i < 2) ? 1 : (i < 5) ? 2 : (i < 10) ? 4 : 8;
-            const int m = i - ((i < 2) ? 0 : (i < 5) ? 2 : (i < 10) ? 5 : 10);
-            float pr = 1.0f, pi = 0.0f;
-            for (int q = 0; q < m; ++q) {
-                float t = pr * r[0] - pi * r[1];
-                pi = pr * r[1] + pi * r[0];
-                pr = t;
-            }
-            float poly = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) poly = fmaf(zp[k], ide_mat[k * 19 + i], poly);
-            const float att = expf(-(0.5f * (float)(l * (l + 1))) * rough);
-            const float re = pr * poly * att, im = pi * poly * att;
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-                part[o][u & 3] = fmaf(spec_w[o * KL + fc + 2 * i], re, fmaf(spec_w[o * KL + fc + 2 * i + 1], im, part[o][u & 3]));
-        }
-    }
-    // bottleneck features j = 16 t + sub + 4 p into partial sum p, t ascending; the LDS reads of a t are issued before its fmafs
-#pragma unroll 4
-    for (int j0 = 0; j0 < fc; j0 += 16) {
-        float b[4], wv[3][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = j0 + 4 * q + sub;
-            b[q] = sb[j];
-#pragma unroll
-            for (int o = 0; o < 3; ++o) wv[o][q] = spec_w[o * KL + j];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int o = 0; o < 3; ++o) part[o][q] = fmaf(wv[o][q], b[q], part[o][q]);
-    }
-    float ps[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const float first = fmaf(spec_w[o * KL + K - 1], dot, part[o][0]) + spec_b[o];
-        float t[4] = {sub == 0 ? first : part[o][0], part[o][1], part[o][2], part[o][3]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            t[q] += dpp_mov<0xB1>(t[q]);                        // xor 1
-            t[q] += dpp_mov<0x4E>(t[q]);                        // xor 2
-        }
-        ps[o] = (t[0] + t[1]) + (t[2] + t[3]);                  // xor 4, xor 8
-    }
-    const float sg = sigmoidf_(ch == 0 ? ps[0] : (ch == 1 ? ps[1] : ps[2]));
-    float c = srgbf_(tint_c * sg + diff_c);
-    c = fminf(fmaxf(c, 0.0f), 1.0f);
-    return c * 1.002f - 0.001f;
-}
-
 // MODE 2: the whole march of a tile (density, compositing, appearance, basis_mat) -> feature rows.  MODE 3: MODE 2 + the Ref head and
 // the background blend (phase E): the tile leaves the kernel as colours, no feature rows and no second launch.
 template <int MODE>
@@ -461,19 +102,6 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     __shared__ float s_ray[FR * 8];
     __shared__ int s_box[8];
     const int tid = threadIdx.x;
-    // Two experiment builds behind DESIGN.md section 4 ("where it stands"); never defined in the product:
-    //   -DFAN_PAD_LDS=bytes  LDS nobody uses, so that fewer tiles fit a CU (30000: two, 50000: one): 0.98 / 1.30 / 2.35 ms per launch
-    //   -DFAN_SLEEP=n        every wave idles n x 64 clocks first (holds its slot, uses no unit): +4.1 k / 8.2 k / 16.4 k clocks on a
-    //                        tile of 89.8 k cost +3.5 / 6.6 / 12.2 % -- three quarters of what pure latency-boundness would cost
-#ifdef FAN_PAD_LDS
-    __shared__ int s_pad[FAN_PAD_LDS / 4];
-    if (a.R < 0) s_pad[threadIdx.x] = 1;
-    if (a.R < -1) a.counts[0] = s_pad[(threadIdx.x * 7) % (FAN_PAD_LDS / 4)];
-#endif
-#ifdef FAN_SLEEP
-#pragma unroll
-    for (int i = 0; i < FAN_SLEEP / 64; ++i) __builtin_amdgcn_s_sleep(64);
-#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int g = tid >> 3, h = (tid >> 2) & 1, c = tid & 3;     // ray of the tile, sub-group, texel quarter
     const bool grp_on = g < FR;
@@ -737,11 +365,9 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
             shmask |= (sh ? 1u : 0u) << s;
             if (writer) {
                 recs[s * REC] = __float_as_uint(w);
-
 #ifndef FAN_STAMPS
                 if (a.alpha) a.alpha[r_glob * FS + s] = alpha;
 #endif
-
             }
         }
         if (writer) {
@@ -774,7 +400,8 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
             __builtin_amdgcn_sched_barrier(0);
             STAMP(6 + 2 * i);
             const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
-            auto accumulate = [&](float (&acc)[36]) {
+            {
+            float (&acc)[36] = accp;
             unsigned m = mymask;
             // the record of the next sample is read one trip ahead
             u32q na = {0u, 0u, 0u, 0u}, nb = {0u, 0u, 0u, 0u};
@@ -808,22 +435,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
                     acc[12 * j + 4 * i + 3] = fmaf(rv.w, pr.w, acc[12 * j + 4 * i + 3]);
                 }
             }
-            };
-            accumulate(accp);
-#ifdef FAN_CHECK_TWICE
-            {
-                float accq[36];
-#pragma unroll
-                for (int q = 0; q < 36; ++q) accq[q] = 0.0f;
-                accumulate(accq);
-                bool bad = false;
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) bad = bad || (accq[12 * j + 4 * i + e4] != accp[12 * j + 4 * i + e4]);
-                if (bad) accp[4 * i] = __builtin_nanf("");        // poison: the ray's features become NaN, its colour 0 (the final clamp)
             }
-#endif
             STAMP(7 + 2 * i);
             FAN_EXIT(7 + 2 * i);
         }
@@ -1086,9 +698,6 @@ __global__ void __launch_bounds__(NT) k_ref_shade_oct(FieldDev f, const float* _
 // most that of the uncontracted step and the end-point argument of phase 0 holds unchanged.
 bool fan_march_eligible(const FieldDev& f, int mode, int S) {
     if (mode != 0 || S != FS || f.n_density != 16 || f.n_app != 48 || f.app_dim != 27) return false;
-#ifdef FAN_ELIGIBLE_ALWAYS          // experiment builds: every point-centred march through the fan kernel (its gather path when a box does not fit)
-    return true;
-#endif
     for (int ax = 0; ax < 3; ++ax) {
         const float scale = f.unisphere ? 1.0f : f.inv_aabb[ax];            // d(normalised coordinate) / d(world coordinate), at most
         const float texels = 10.0f * f.step_size * scale * 0.5f * (float)(f.grid[ax] - 1);

@@ -34,6 +34,7 @@ struct FieldDev {
     int density_lanes;          // 0 auto, 1 or 4 forced (iff_field_desc.density_lanes)
     int head_lanes;             // 0 auto, 16 = the vector form of the Ref head launches (iff_field_desc.head_lanes)
     int sampler_persistent;     // 1: the surface sampler as one persistent launch (iff_field_desc.sampler_persistent)
+    int fan_waves;              // 0 auto, 4 / 8: the fused fan kernel that serves the point-centred march (iff_field_desc.fan_waves)
     int n_density, n_app, app_dim, feature_c;
 };
 

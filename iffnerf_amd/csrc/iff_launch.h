@@ -38,6 +38,10 @@ hipError_t launch_ref_shade_oct(const FieldDev& f, const float* dirs, int dir_st
 bool march_head_fused(const FieldDev& f);
 bool fan_march_eligible(const FieldDev& f, int mode, int S);
 hipError_t launch_fan_march(const FieldDev& f, const MarchArgs& a, int variant, hipStream_t s);
+// fan8_march_kernels.hip (the eight-wave form: DMA-staged patches, 12- and 22-texel boxes)
+int fan8_patch_side(const FieldDev& f, int mode, int S);
+hipError_t launch_fan8_march(const FieldDev& f, const MarchArgs& a, int variant, hipStream_t s);
+int fan_kernel_for(const FieldDev& f, int mode, int S);
 size_t march_grad_workspace_bytes(int64_t R, int S);
 hipError_t launch_march_grad(const FieldDev& f, const float* rays, int ray_cols, int64_t R, int mode, int S,
                              const float* g_feat, int g_feat_ld, const float* g_acc, float* g_rays, void* ws, size_t ws_bytes,

@@ -405,7 +405,23 @@ size_t march_workspace_bytes(int64_t R, int S) { return march_feat_offset(R, S) 
 // 0 = the general kernels, 2 = the fused fan kernel (iff_field_desc.density_lanes != 0 names one of the general kernels and
 // therefore keeps them: what the parity tests compare the fan kernel with).
 int march_plan(const FieldDev& f, int mode, int S) {
-    return (f.density_lanes == 0 && fan_march_eligible(f, mode, S)) ? 2 : 0;
+    return (f.density_lanes == 0 && fan_kernel_for(f, mode, S) != 0) ? 2 : 0;
+}
+
+// Which fused fan kernel serves a march: 0 none, 4 = k4f_fan_march (four waves per fan, 12-texel boxes), 8 = k4g_fan_march (eight
+// waves per fan, 12- or 22-texel boxes).  iff_field_desc.fan_waves names one; left at 0 the 22-texel boxes take the only kernel that
+// stages them and the 12-texel boxes the one FAN12_DEFAULT_WAVES names (the faster on MI355X: DESIGN.md section 4).
+#ifndef FAN12_DEFAULT_WAVES
+#define FAN12_DEFAULT_WAVES 4
+#endif
+int fan_kernel_for(const FieldDev& f, int mode, int S) {
+    const int side = fan8_patch_side(f, mode, S);
+    const bool four = fan_march_eligible(f, mode, S);
+    if (f.fan_waves == 4) return four ? 4 : 0;
+    if (f.fan_waves == 8) return side ? 8 : 0;
+    if (side == 12 && four) return FAN12_DEFAULT_WAVES;
+    if (side) return 8;
+    return four ? 4 : 0;
 }
 
 // the colours call of the fused plan also runs the Ref head in the fan kernel
@@ -446,7 +462,7 @@ hipError_t launch_march(const FieldDev& f, const float* rays, int ray_cols, int6
     size_t lds = (size_t)f.app_dim * 3 * f.n_app * sizeof(float);
     const bool fuse_head = fan == 2 && !feat_out && march_head_fused(f);
     if (fan) {
-        e = launch_fan_march(f, a, fuse_head ? 3 : 2, s);
+        e = fan_kernel_for(f, mode, S) == 8 ? launch_fan8_march(f, a, fuse_head ? 3 : 2, s) : launch_fan_march(f, a, fuse_head ? 3 : 2, s);
         if (e != hipSuccess) return e;
     } else if (mode == 0 && S <= 32) {
         const int64_t tiles12 = (R + 19) / 20;

@@ -42,6 +42,12 @@ template <> struct VT<1> {
     typedef _Float16 e; typedef f16x8 v8; typedef f16x4 v4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
+// Accuracy of the split: hi carries 11 significant bits; lo = fp16(v - hi) carries 11 more WHILE IT IS A NORMAL fp16, i.e. for |v| >= 2^-3
+// (lo ~ 2^-11 |v| >= 2^-14).  Below that lo is an fp16 subnormal with an absolute resolution of 2^-24: the pair then represents v to
+// 2^-25 ABSOLUTE instead of 2^-22 relative -- activations are not rescaled the way the weights are (their hi planes sit in [2^13, 2^14)).
+// That is below fp32's own resolution of the O(1) values these operands are mixed with (LayerNorm outputs, softmax probabilities
+// that sum to 1, GELU outputs), and it relies on v_mfma_f32_32x32x16_f16 multiplying fp16 subnormals exactly (it does not flush them:
+// tests/test_hip_image_side.py::test_native_vit_small_activations holds the 1e-4 bound with every LayerNorm output scaled by 2^-7).
 __device__ __forceinline__ void split_h(float v, _Float16& hi, _Float16& lo) {
     v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
     hi = (_Float16)v;

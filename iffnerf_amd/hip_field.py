@@ -29,7 +29,7 @@ class FieldHandle:
                  mask_volume: Optional[torch.Tensor], mask_aabb: Optional[torch.Tensor],
                  density_shift: float, distance_scale: float, weight_thres: float, step_size: float, n_samples: int,
                  near_far, softplus: bool = True, unisphere: bool = False, density_lanes: int = 0, head_lanes: int = 0,
-                 sampler_persistent: bool = False):
+                 sampler_persistent: bool = False, fan_waves: int = 0):
         self._h = None
         L = _lib.lib()
         device = torch.device(device)
@@ -74,6 +74,7 @@ class FieldHandle:
         d.density_lanes = int(density_lanes)          # 0 = auto; 1 / 4 force a gather form (include/iffnerf_hip.h)
         d.head_lanes = int(head_lanes)                # 0 = auto; 16 = the vector form of the Ref head launches
         d.sampler_persistent = int(bool(sampler_persistent))      # the one-launch form of the surface sampler (parity tests)
+        d.fan_waves = int(fan_waves)                  # 0 = auto; 4 / 8 name the fused fan kernel (include/iffnerf_hip.h)
         for field, key in (("normal", "normal_mlp.0"), ("tint", "tint_color_mlp.0"), ("rough", "roughness_mlp.0"),
                            ("diffuse", "diffuse_color_mlp.0"), ("bottleneck", "bottleneck_mlp"),
                            ("specular", "specular_mlp.0")):
@@ -357,7 +358,8 @@ def isocell_emit(cells: torch.Tensor, points: torch.Tensor, normals: torch.Tenso
     return (ori, dirs, rays6) if want_rays6 else (ori, dirs)
 
 
-def field_handle_from_ckpt(ckpt: dict, device, density_lanes: int = 0, head_lanes: int = 0, sampler_persistent: bool = False) -> FieldHandle:
+def field_handle_from_ckpt(ckpt: dict, device, density_lanes: int = 0, head_lanes: int = 0, sampler_persistent: bool = False,
+                           fan_waves: int = 0) -> FieldHandle:
     """Build a handle straight from a checkpoint dictionary (TensorBase.save layout); used by tests and bench."""
     from .models.tensorBase import derive_step
     kw = ckpt["kwargs"]
@@ -382,4 +384,4 @@ def field_handle_from_ckpt(ckpt: dict, device, density_lanes: int = 0, head_lane
         weight_thres=kw.get("rayMarch_weight_thres", 1e-4), step_size=float(step), n_samples=n_samples,
         near_far=kw.get("near_far", (2.0, 6.0)), softplus=kw.get("fea2denseAct", "softplus") == "softplus",
         unisphere=kw.get("contraction_type", "aabb") == "unisphere", density_lanes=density_lanes, head_lanes=head_lanes,
-        sampler_persistent=sampler_persistent)
+        sampler_persistent=sampler_persistent, fan_waves=fan_waves)

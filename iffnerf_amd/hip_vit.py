@@ -144,30 +144,52 @@ class _NativeForwardFeatures:
 
     def __init__(self, module: torch.nn.Module, grid, patch: int, precision: str = "fp32"):
         self.module, self.grid, self.patch, self.precision = module, (int(grid[0]), int(grid[1])), int(patch), precision
-        self._handle: Optional[ViTHandle] = None
+        self._handles: Dict[tuple, ViTHandle] = {}        # one iff_vit per input grid (the position table is interpolated per grid)
         self._key = None
 
     # a handle is a device resource of THIS process: copies and pickles of the module start without one
     def __getstate__(self):
-        return {"module": self.module, "grid": self.grid, "patch": self.patch, "precision": self.precision, "_handle": None, "_key": None}
+        return {"module": self.module, "grid": self.grid, "patch": self.patch, "precision": self.precision, "_handles": {}, "_key": None}
+
+    @property
+    def _handle(self) -> Optional[ViTHandle]:
+        return self._handles.get(self.grid)
+
+    def close(self):
+        for h in self._handles.values():
+            h.close()
+        self._handles = {}
 
     def stock(self, x, *args, **kwargs):
         """The module's own (class-level) ``forward_features``: stock torch ops."""
         return type(self.module).forward_features(self.module, x, *args, **kwargs)
 
-    def _vit(self, device) -> ViTHandle:
+    def _vit(self, device, grid=None) -> ViTHandle:
+        grid = self.grid if grid is None else (int(grid[0]), int(grid[1]))
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
-        if self._handle is None or self._key != key:
-            if self._handle is not None:
-                self._handle.close()
-            self._handle, self._key = ViTHandle(self.module.state_dict(), device, self.grid, self.patch, precision=self.precision), key
-        return self._handle
+        if self._key != key:
+            self.close()
+            self._key = key
+        if grid not in self._handles:
+            self._handles[grid] = ViTHandle(self.module.state_dict(), device, grid, self.patch, precision=self.precision)
+        return self._handles[grid]
+
+    MAX_TOKENS = 288          # csrc/api.hip iff_vit_create: 1 + gh * gw tokens per image at most
 
     def __call__(self, x, masks=None, *args, **kwargs):
         if not isinstance(x, torch.Tensor) or masks is not None or args or kwargs:
             return self.stock(x, masks, *args, **kwargs)          # token masking / list inputs: DINOv2's training-side forms
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.module.parameters())):
             return self.stock(x)
+        if x.is_cuda and x.dim() == 4:
+            # any input whose sides are multiples of the patch size is served, each grid by its own handle (the hub module accepts
+            # them all: it interpolates its position table, and so does ViTHandle); grids beyond the kernels' token budget run the
+            # module's own forward ON THE GPU.  CPU tensors raise: libiffnerf_hip has no CPU path (tests/test_abi.py).
+            gh, gw = x.shape[-2] // self.patch, x.shape[-1] // self.patch
+            if (gh * self.patch, gw * self.patch) != tuple(x.shape[-2:]) or 1 + gh * gw > self.MAX_TOKENS:
+                return self.stock(x)
+            tok, cls = self._vit(x.device, (gh, gw)).forward(x, want_cls=True)
+            return {"x_norm_clstoken": cls, "x_norm_patchtokens": tok}
         tok, cls = self._vit(x.device).forward(x, want_cls=True)
         return {"x_norm_clstoken": cls, "x_norm_patchtokens": tok}
 
@@ -194,8 +216,7 @@ def restore_stock(module: torch.nn.Module) -> torch.nn.Module:
     """Undo ``serve_natively``: ``forward_features`` is the class's method again."""
     cur = module.__dict__.get("forward_features")
     if isinstance(cur, _NativeForwardFeatures):
-        if cur._handle is not None:
-            cur._handle.close()
+        cur.close()
         object.__delattr__(module, "forward_features")
     return module
 

@@ -47,13 +47,13 @@ class PosePipeline:
 
     @classmethod
     def from_checkpoints(cls, field_ckpt: dict, id_weights: Dict[str, torch.Tensor], device, model_up=(0.0, 0.0, 1.0),
-                         fold_heads: bool = True, gemm_mode: Optional[int] = None, trunk_variant: int = 0):
+                         fold_heads: bool = True, gemm_mode: Optional[int] = None, trunk_variant: int = 0, fan_waves: int = 0):
         if gemm_mode is None:
             # IFF_GEMM_F16X2 plans its power-of-two scales for ray origins within 64 scene units (include/iffnerf_hip.h); rays start
             # on the surface inside the scene box, so a larger box keeps the range-free 3xBF16 arithmetic
             extent = float(torch.as_tensor(field_ckpt["kwargs"]["aabb"]).abs().max())
             gemm_mode = H.GEMM_DEFAULT if extent <= H.F16_ORIGIN_BOUND else H.GEMM_BF16X3
-        return cls(field_handle_from_ckpt(field_ckpt, device), H.IdNetHandle(id_weights, device, gemm_mode, trunk_variant),
+        return cls(field_handle_from_ckpt(field_ckpt, device, fan_waves=fan_waves), H.IdNetHandle(id_weights, device, gemm_mode, trunk_variant),
                    jitter_scale_from_kwargs(field_ckpt["kwargs"], "alphaMask.aabb" in field_ckpt), model_up, fold_heads)
 
     def save_tables(self, field_path: str, idnet_path: str) -> None:

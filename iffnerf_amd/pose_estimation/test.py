@@ -115,8 +115,11 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
 
     n_full = n // B
     if n_full:
-        key = (B, H_, W_, C_, up)
+        # a captured batch holds the addresses of the backbone's kernel tables too: keyed on its parameters' identity + version
+        backbone_key = tuple((p.data_ptr(), p._version) for p in id_module.image_preprocessing_net.parameters())
+        key = (B, H_, W_, C_, up, backbone_key)
         if key not in session.graphs:
+            session.graphs.clear()                       # at most one batch shape's graphs (and their logits buffers) stay alive
             session.graphs[key] = [CapturedEvalBatch(id_module, session, (B, H_, W_, C_), up) for _ in range(2 if n_full > 1 else 1)]
         slots = session.graphs[key]
         cur = torch.cuda.current_stream(device)

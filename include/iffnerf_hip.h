@@ -103,6 +103,13 @@ typedef struct iff_field_desc {
     int32_t sampler_persistent;      /* 0: the surface sampler (pose_estimation/sampling.py:509-532) as a chain of short launches;
                                         1: ONE persistent launch with in-kernel grid barriers (the same samples bit for bit; then
                                         iff_surface_sample_residency bounds the launches that may be in flight).  For parity tests. */
+    int32_t fan_waves;               /* which fused fan kernel serves the point-centred march (TensorBase.forward with sample_point_color,
+                                        tensorBase.py:775-917, :623-638) where one applies: 0 = choose (boxes of <= 12 texels: the form
+                                        measured faster on MI355X; boxes of <= 22 texels -- unisphere scenes, tensorBase.py:361-365 --:
+                                        the eight-wave kernel, the only one that stages them), 4 = the four-wave kernel with
+                                        register-staged patches (12-texel boxes only), 8 = the eight-wave kernel with DMA-staged
+                                        patches.  alpha / acc / depth / sample counters are the same bits in every form; for A/B and
+                                        parity tests. */
     /* Ref head, models/ref.py:69-101 (nn.Linear layouts [out,in]) */
     const float* normal_w;  const float* normal_b;    /* [3,app_dim],[3] */
     const float* tint_w;    const float* tint_b;      /* [3,app_dim],[3] */

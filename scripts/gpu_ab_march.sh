@@ -1,8 +1,11 @@
 #!/bin/bash
-# Dev aid: GPU suite on the in-tree library, then the march alone and the default bench under each given development build, same box.
-set -u
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_hip_field.py tests/test_hip_fullsize.py tests/test_hip_dropin.py -m gpu -q -x > gpurun_out/ab_pytest.log 2>&1; rc=$?; tail -n 4 gpurun_out/ab_pytest.log
-if [ $rc -ne 0 ]; then exit 1; fi
-bash scripts/gpu_ab.sh "$@"
-bash scripts/gpu_ab_bench.sh "$@"
+# same-box A/B of the fused fan kernels on the march alone: bash scripts/gpu_ab_march.sh [config ...]   (run on the GPU box)
+# FAN_WAVES=4: k4f_fan_march (four waves per fan, register-staged patches); 8: k4g_fan_march (eight waves, DMA-staged); 0: the handle's choice
+set -e
+for cfg in "${@:-lego16k}"; do
+  for rep in 1 2; do
+    for w in 4 8 0; do
+      FAN_WAVES=$w python scripts/time_march.py $cfg 2>/dev/null | tail -1
+    done
+  done
+done

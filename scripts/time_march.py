@@ -10,7 +10,8 @@ from iffnerf_amd.hip_field import isocell_emit
 cfg = sys.argv[1] if len(sys.argv) > 1 else "lego16k"
 wl = synthetic.WORKLOADS[cfg]
 dev = torch.device("cuda:0")
-pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(cfg), synthetic.make_id_weights(seed=99), dev)
+pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(cfg), synthetic.make_id_weights(seed=99), dev,
+                                     fan_waves=int(os.environ.get("FAN_WAVES", "0")))      # 4 / 8: name the fused fan kernel (iff_field_desc.fan_waves)
 QB, P = wl["queries"] if not wl["shared_rays"] else 1, wl["gen_points"]
 samples, _, _ = pipe.field.surface_sample_batched(QB, P, pipe.rho, 4, 200, seed=5000)
 samples = samples.reshape(QB * P, 3)
@@ -41,7 +42,7 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 c = out[4].double().sum(0)
-print(json.dumps({"config": cfg, "plan": pipe.field.march_plan(0, 20), "lib": os.environ.get("IFF_LIB_PATH", "in-tree"), "rays": rays.shape[0],
+print(json.dumps({"config": cfg, "fan_waves": int(os.environ.get("FAN_WAVES", "0")), "plan": pipe.field.march_plan(0, 20), "lib": os.environ.get("IFF_LIB_PATH", "in-tree"), "rays": rays.shape[0],
                   "stage_ms": [round(t, 4) for t in tot], "march_ms": round(e0.elapsed_time(e1) / n, 4),
                   "valid_per_ray": round(c[0].item() / rays.shape[0], 2), "shaded_per_ray": round(c[1].item() / rays.shape[0], 2),
                   "rgb_sum": float(out[0].double().sum())}))

@@ -282,3 +282,60 @@ def test_fan_march_equals_the_general_kernels(dev):
                 acc = fused[2].reshape(-1, 1)
                 want = (c * acc + torch.tensor(bg, device=c.device) * (1.0 - acc)).clamp(0.0, 1.0)
                 assert torch.equal(fused[0], want), (which, over, tuple(rays.shape), bg, float((fused[0] - want).abs().max()))
+
+
+def test_eight_wave_fan_kernel_equals_the_other_forms(dev):
+    """k4g_fan_march (eight waves per fan, patches by global -> LDS DMA into two buffers, sixteen lanes per ray; iff_field_desc.fan_waves
+    = 8) against the general kernels and the four-wave fan kernel: the per-sample arithmetic is shared, so alpha, acc, depth and the
+    (valid, shaded) counters are EQUAL to both; the colours differ only by the order in which a ray's sample chains and the quarter
+    sums of basis_mat are added.  Both patch sizes: 12-texel boxes (aabb scenes, one pass per 48-channel plane) and 22-texel boxes
+    (unisphere contraction at the reference's step_ratio 0.5: a fan spans up to 21 texels; 16-channel slices, twelve passes), staged
+    fans, ragged tiles, arbitrary rays (the in-kernel gather path), fans at the table faces (zero-padded taps)."""
+    from iffnerf_amd import synthetic
+    from iffnerf_amd.hip_field import field_handle_from_ckpt
+    from iffnerf_amd.pipeline import PosePipeline
+    g = torch.Generator().manual_seed(32)
+    uni = dict(contraction_type="unisphere", density_shift=0.0, density_offset=-10.0, peak=20.0, aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)),
+               near_far=(0.01, 1.4), blob_sigma=0.30, mask_radius=0.62)
+    for which, over, side in (("small", {}, 12), ("tiny", {}, 12), ("small", dict(grid=(300, 280, 260), mask_res=(60, 56, 52)), 12),
+                              ("small", dict(step_ratio=0.25, **uni), 12),
+                              ("small", dict(grid=(96, 96, 96), mask_res=(40, 36, 44), step_ratio=0.5, **uni), 22),
+                              ("small", dict(grid=(64, 64, 64), mask_res=(20, 18, 16), step_ratio=0.5, **uni), 22)):      # patches that run over the table edge (clamped rows / columns)
+        # (unisphere: the step is the MEAN grid unit, so ten steps are ten texels only on a cubic grid -- configs/bicycle.txt: 640^3)
+        ck = util.ckpt(which, **over)
+        pipe = PosePipeline.from_checkpoints(ck, synthetic.make_id_weights(seed=99), dev)
+        gen = field_handle_from_ckpt(ck, dev, density_lanes=1)
+        f8 = field_handle_from_ckpt(ck, dev, fan_waves=8)
+        f4 = field_handle_from_ckpt(ck, dev, fan_waves=4)
+        h16 = field_handle_from_ckpt(ck, dev, head_lanes=16, fan_waves=8)         # the eight-wave kernel without its head phase + the head launch
+        assert f8.march_plan(0, 20) == 3 and h16.march_plan(0, 20) == 2 and gen.march_plan(0, 20) == 0
+        assert f4.march_plan(0, 20) == (3 if side == 12 else 0)                    # the four-wave kernel stages 12-texel boxes only
+        cases = []
+        for P in (75, 9, 1):
+            ori, dirs, _ = pipe.emit(P, seed=23 + P)
+            cases.append(torch.cat((ori, dirs), -1).contiguous())
+        cases.append(cases[0][:27 * 3 + 11].contiguous())                      # a ragged last tile
+        for R in (540, 37):                                                    # arbitrary rays: the gather path
+            o = (torch.rand(R, 3, generator=g) - 0.5) * 2.0
+            cases.append(torch.cat((o, torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)), -1).to(dev))
+        cases.append(torch.cat((cases[0][:54], cases[4][:27], cases[0][54:108])).contiguous())     # staged and gathered tiles in one launch
+        for rays in cases:
+            a = f8.march(rays, 0, 20, want_alpha=True, want_counts=True)
+            b = gen.march(rays, 0, 20, want_alpha=True, want_counts=True)
+            for x, y, what in zip(a[1:5], b[1:5], ("depth", "acc", "alpha", "counts")):
+                assert torch.equal(x, y), (which, over, tuple(rays.shape), what, int((x != y).sum()))
+            close(a[0], b[0].cpu(), 2e-6, what=f"rgb {which} {tuple(rays.shape)}")
+            fa, fb = f8.march_features(rays, 0, 20)[0], gen.march_features(rays, 0, 20)[0]
+            close(fa, fb.cpu(), 2e-5, 2e-6, what="weighted features")
+            assert torch.equal(fa[:, 27], fb[:, 27])
+            if side == 12:
+                c4 = f4.march(rays, 0, 20, want_alpha=True, want_counts=True)
+                for x, y in zip(a[1:5], c4[1:5]):
+                    assert torch.equal(x, y)
+                close(a[0], c4[0].cpu(), 2e-6, what="rgb vs the four-wave kernel")
+            for bg in ((0.0, 0.0, 0.0), (1.0, 0.5, 0.25)):
+                fused = f8.march(rays, 0, 20, bg=bg)
+                assert torch.equal(h16.march(rays, 0, 20, bg=bg)[0], fused[0])     # the fused head == the separate 16-lane head launch
+            again = f8.march(rays, 0, 20, want_alpha=True, want_counts=True)       # and the launch is deterministic
+            for x, y in zip(a[:5], again[:5]):
+                assert torch.equal(x, y)

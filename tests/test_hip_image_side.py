@@ -228,6 +228,53 @@ def test_native_vit_matches_the_fp32_torch_module(dev):
         vit.forward(torch.zeros(1, 3, 200, 224, device=dev))
 
 
+def test_native_vit_small_activations(dev):
+    """The fp32 class splits an operand into two fp16 pieces; for |v| < 2^-3 the low piece is an fp16 SUBNORMAL (csrc/vit_kernels.hip
+    split_h).  Move every matrix product's activations there -- LayerNorm gains and biases times 2^-7, the weights that consume them
+    times 2^7, exact rescalings that leave the network's function unchanged -- and the tokens must still agree with fp32 torch on the
+    same (rescaled) module to 1e-4: the matrix cores multiply fp16 subnormals, they do not flush them."""
+    from iffnerf_amd.hip_vit import ViTHandle
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    net, grid, C = create_standin_backbone(seed=4)
+    net = net.to(dev)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        plain = net.forward_features(x)["x_norm_patchtokens"]
+        for b in net.blocks:
+            for ln, lin in ((b.norm1, b.attn.qkv), (b.norm2, b.mlp.fc1)):
+                ln.weight.mul_(2.0 ** -7), ln.bias.mul_(2.0 ** -7), lin.weight.mul_(2.0 ** 7)
+        ref = net.forward_features(x)["x_norm_patchtokens"]
+        small = float(net.blocks[0].norm1(torch.randn(4, 384, device=dev)).abs().max())
+    assert small < 2.0 ** -3                                   # the GEMM inputs really sit in the subnormal-lo range
+    torch.testing.assert_close(ref, plain, atol=2e-5 * float(plain.abs().max()), rtol=0)          # same function (power-of-two rescaling)
+    tok = ViTHandle(net.state_dict(), dev).forward(x)
+    scale = float(ref.abs().max())
+    assert torch.isfinite(tok).all() and float((tok - ref).abs().max()) <= 1e-4 * scale
+
+
+def test_native_backbone_serves_other_grids(dev):
+    """The installed forward_features serves every input the hub module serves: another multiple-of-14 size gets its own handle
+    (position table interpolated to that grid), a size that is no multiple of the patch or beyond the kernels' token budget runs the
+    module's own forward on the GPU, a CPU tensor raises (no CPU path)."""
+    from iffnerf_amd.hip_vit import serve_natively
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    net, grid, C = create_standin_backbone(seed=6)
+    net = serve_natively(net.to(dev), grid)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for hw in ((224, 224), (196, 168), (112, 224)):
+            x = torch.randn(2, 3, *hw, generator=gen).to(dev)
+            got = net.forward_features(x)["x_norm_patchtokens"]
+            want = type(net).forward_features(net, x)["x_norm_patchtokens"]
+            assert got.shape == want.shape == (2, (hw[0] // 14) * (hw[1] // 14), 384)
+            assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) and not torch.equal(got, want)      # native, not stock
+        assert len(net.__dict__["forward_features"]._handles) == 3
+        big = torch.randn(1, 3, 252, 252, generator=gen).to(dev)                  # 325 tokens: beyond the kernels' budget -> the module's own forward
+        assert torch.equal(net.forward_features(big)["x_norm_patchtokens"], type(net).forward_features(net, big)["x_norm_patchtokens"])
+        with pytest.raises(RuntimeError, match="GPU"):
+            net.forward_features(torch.zeros(1, 3, 224, 224))
+
+
 def test_native_resize_crop_normalize_matches_the_torch_formulation(dev):
     """iff_image_resize_crop (one kernel: antialiased bicubic / bilinear resize of the shorter edge, centre crop, normalisation,
     channels-first) against the mirrored module's F.interpolate(antialias=True) + crop + normalise -- the torchvision transforms of
