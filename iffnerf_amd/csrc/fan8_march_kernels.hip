@@ -126,25 +126,66 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
     const bool slot_on = rs < FR;
     const int64_t ray0 = (int64_t)blockIdx.x * FR;
     const int n_live = (int)min((int64_t)FR, a.R - ray0);
-    const bool live = rs < n_live;
-    // this lane's ray (the sixteen lanes of a slot read the same 28 bytes)
-    float ro[3] = {0.0f, 0.0f, 0.0f}, rd[3] = {0.0f, 0.0f, 1.0f}, rlast = 0.0f;
-    if (live) {
-        const float* rp = a.rays + (ray0 + rs) * a.ray_cols;
-        ro[0] = rp[0]; ro[1] = rp[1]; ro[2] = rp[2]; rd[0] = rp[3]; rd[1] = rp[4]; rd[2] = rp[5];
-        rlast = rp[a.ray_cols - 1];
-    }
-    if (slot_on && p == 0 && c == 0) {
-        float* sr = s_ray + rs * 8;
-        sr[0] = ro[0]; sr[1] = ro[1]; sr[2] = ro[2]; sr[3] = rd[0]; sr[4] = rd[1]; sr[5] = rd[2]; sr[6] = 0.0f; sr[7] = rlast;
+    __shared__ int s_box[8];
+    __shared__ uint32_t s_sh[32];                       // shaded-sample mask of every ray slot (written by the compositing wave)
+    // the rays to LDS for the later phases (compositing, gather path, head): one thread per ray
+    if (tid < 32) {
+        float* sr = s_ray + tid * 8;
+        if (tid < n_live) {
+            const float* rp = a.rays + (ray0 + tid) * a.ray_cols;
+            sr[0] = rp[0]; sr[1] = rp[1]; sr[2] = rp[2]; sr[3] = rp[3]; sr[4] = rp[4]; sr[5] = rp[5];
+            sr[6] = 0.0f; sr[7] = rp[a.ray_cols - 1];
+        } else {
+            sr[0] = sr[1] = sr[2] = 0.0f; sr[3] = sr[4] = 0.0f; sr[5] = 1.0f; sr[6] = sr[7] = 0.0f;
+        }
     }
     STAMP(0);
+    // ---------------------------------------------------------------------------------------------------- phase A, first half
+    // the 540 samples flat over the 512 threads: thread t takes sample t (ray t / 20), and the last 28 samples go to lanes 0 .. 27 of
+    // wave 7 (wave 0 reduces the box meanwhile).  Everything of a record that does not need the box is computed here, in registers.
+    struct Pre { uint32_t flags; int t0[3]; float w1[3]; bool any; };
+    auto sample_pre = [&](int t) {
+        Pre r;
+        r.flags = 0u; r.any = false;
+        r.t0[0] = r.t0[1] = r.t0[2] = 0; r.w1[0] = r.w1[1] = r.w1[2] = 0.0f;
+        const int ry = t / FS, s = t - ry * FS;
+        if (ry < n_live) {
+            const float* rp = a.rays + (ray0 + ry) * a.ray_cols;
+            const float z = z_of(f, 0, FS, 0.0f, s);
+            const float pt[3] = {rp[0] + rp[3] * z, rp[1] + rp[4] * z, rp[2] + rp[5] * z};
+            if (inside_aabb(f, pt)) {
+                float xn[3];
+                field_normalize(f, pt, xn);
+                const bool occ = f.mask ? mask_occupied(f, pt, xn) : true;
+                r.any = true;
+                r.flags = occ ? REC_VALID : 0u;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    // axis_tap (iff_device.h), with the zero padding kept as flags
+                    const int size = f.grid[ax];
+                    const float x = unnorm(xn[ax], size);
+                    const float fx = floorf(x);
+                    r.w1[ax] = x - fx;
+                    const bool ok = (x > -2.0f) && (x < (float)(size + 1));
+                    const int i0 = ok ? (int)fx : -2, i1 = i0 + 1;
+                    const int t0 = min(max(i0, 0), size - 1), t1 = min(max(i1, 0), size - 1);
+                    const bool z0 = !(i0 >= 0 && i0 < size), z1 = !(i1 >= 0 && i1 < size);
+                    r.t0[ax] = t0;
+                    r.flags |= (uint32_t)(((t1 - t0) << 5) | (z0 ? 64 : 0) | (z1 ? 128 : 0)) << (8 * ax);
+                    if (z0 || z1) r.flags |= REC_PAD;
+                }
+            }
+        }
+        return r;
+    };
+    const Pre pre0 = sample_pre(tid);
+    Pre pre1;
+    pre1.any = false;
+    if (wave == 7 && lane < NSMP - NT) pre1 = sample_pre(NT + lane);
     // ---------------------------------------------------------------------------------------------------- phase 0: the box
-    // x(s) is monotone in s along a ray, hence the taps of a ray's samples lie between the taps of its two end points: 54 points,
-    // reduced by EVERY wave for itself (no LDS, no barrier; all waves get the same box).
-    int lo[3];
-    bool fits = true, inner = true;
-    {
+    // x(s) is monotone in s along a ray, hence the taps of a ray's samples lie between the taps of its two end points: 54 points
+    // in wave 0, reduced by DPP + readlane.
+    if (wave == 0) {
         int blo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, bhi[3] = {-1, -1, -1};
         const int rl = lane % FR;
         if (lane < 2 * FR && rl < n_live) {
@@ -167,20 +208,26 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         }
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            lo[ax] = wave_min(blo[ax]);
-            const int hi = wave_max(bhi[ax]);
-            fits = fits && (hi - lo[ax] + 1 <= FP);
-            inner = inner && (lo[ax] + FP <= f.grid[ax]);
+            const int l = wave_min(blo[ax]), h = wave_max(bhi[ax]);
+            if (lane == 0) { s_box[ax] = l; s_box[3 + ax] = h; }
         }
-        if (n_live <= 0) fits = false;
+    }
+    __syncthreads();
+    int lo[3];
+    bool fits = n_live > 0, inner = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        lo[ax] = __builtin_amdgcn_readfirstlane(s_box[ax]);
+        const int hi = __builtin_amdgcn_readfirstlane(s_box[3 + ax]);
+        fits = fits && (hi - lo[ax] + 1 <= FP);
+        inner = inner && (lo[ax] + FP <= f.grid[ax]);
     }
     // ---------------------------------------------------------------------------------------------------- the DMA of a pass
     // A pass image is [plane rows][PITCH][SL] then [line rows][SL] (NDP = 1, density: three such images of 16 channels, the planes
     // first); chunk L = 512 round + tid is one 16-B piece of it.  The decomposition of an appearance-geometry chunk is the same
-    // in every pass: computed once (q [0:3], column [4:8], row [9:13], line flag 14, valid 15).
-    uint32_t prep[G::NR];
-#pragma unroll
-    for (int r = 0; r < G::NR; ++r) {
+    // in every pass (q [0:3], column [4:8], row [9:13], line flag 14, valid 15); it is recomputed per pass from the thread index -- held in
+    // registers through the kernel it was spilled, and a reload in front of a DMA waits for every DMA in flight.
+    auto chunk_of = [&](int r) -> uint32_t {
         const int L = NT * r + tid;
         constexpr int CPT = SLC / 4, NPL = G::PLANE / 4;
         uint32_t e = 0u;
@@ -192,8 +239,8 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
             const int l = L - NPL, rz = l / CPT, qq = l - rz * CPT;
             e = (uint32_t)qq | ((uint32_t)rz << 9) | (1u << 14) | (1u << 15);
         }
-        prep[r] = e;
-    }
+        return e;
+    };
     // table of `C` channels per texel, channels [ch0, ch0 + SLC) of it, plane axes (pa, pb), line axis pv
     auto dma_slice = [&](const float* ptab, const float* ltab, int C, int ch0, int pa, int pb, int pv, float* buf) {
         const int Ga = f.grid[pa], Gb = f.grid[pb], Gv = f.grid[pv];
@@ -201,7 +248,7 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         const char* lbase = reinterpret_cast<const char*>(ltab + (size_t)lo[pv] * C + ch0);
 #pragma unroll
         for (int r = 0; r < G::NR; ++r) {
-            const uint32_t e = prep[r];
+            const uint32_t e = chunk_of(r);
             if (e & (1u << 15)) {
                 const int qq = e & 15u, rx = (e >> 4) & 31u, ry = (e >> 9) & 31u;
                 const char* src;
@@ -224,24 +271,21 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         for (int r = 0; r < G::NR; ++r) {
             const int L = NT * r + tid;
             if (L < G::NCH) {
-                const char* src = nullptr;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {                       // (static plane index: no runtime-indexed lo[] / grid[])
-                    const int pa = mat_a(i), pb = mat_b(i), pv = vec_ax(i);
-                    const int Ga = f.grid[pa], Gb = f.grid[pb], Gv = f.grid[pv];
-                    const int rem = L - i * NPL1, l = L - 3 * NPL1 - i * NLN1;
-                    if (rem >= 0 && rem < NPL1) {
-                        const int texel = rem >> 2, qq = rem & 3;
-                        const int ry = texel / PITCH, rx = min(texel - ry * PITCH, FP - 1);
-                        const int row = inner ? lo[pb] + ry : min(lo[pb] + ry, Gb - 1), col = inner ? lo[pa] + rx : min(lo[pa] + rx, Ga - 1);
-                        src = reinterpret_cast<const char*>(f.dplane[i] + ((size_t)row * Ga + col) * 16 + 4 * qq);
-                    }
-                    if (l >= 0 && l < NLN1) {
-                        const int rz = l >> 2, qq = l & 3;
-                        const int row = inner ? lo[pv] + rz : min(lo[pv] + rz, Gv - 1);
-                        src = reinterpret_cast<const char*>(f.dline[i] + (size_t)row * 16 + 4 * qq);
-                    }
-                }
+                const bool is_line = L >= 3 * NPL1;
+                const int Lr = is_line ? L - 3 * NPL1 : L;
+                const int per = is_line ? NLN1 : NPL1;
+                const int i = (Lr >= per ? 1 : 0) + (Lr >= 2 * per ? 1 : 0);                 // plane / line index
+                const int rem = Lr - i * per, texel = rem >> 2, qq = rem & 3;
+                // the plane's / line's parameters by selects (no runtime-indexed lo[] / grid[]): plane i spans (a, b) = (0,1),(0,2),(1,2), line i runs along 2 - i
+                const int Ga = i == 2 ? f.grid[1] : f.grid[0], Gb = i == 0 ? f.grid[1] : f.grid[2];
+                const int la = i == 2 ? lo[1] : lo[0], lb = i == 0 ? lo[1] : lo[2];
+                const int Gv = i == 0 ? f.grid[2] : (i == 1 ? f.grid[1] : f.grid[0]), lv = i == 0 ? lo[2] : (i == 1 ? lo[1] : lo[0]);
+                const float* ptab = i == 0 ? f.dplane[0] : (i == 1 ? f.dplane[1] : f.dplane[2]);
+                const float* ltab = i == 0 ? f.dline[0] : (i == 1 ? f.dline[1] : f.dline[2]);
+                const int ry = texel / PITCH, rx = min(texel - ry * PITCH, FP - 1);
+                const int row = is_line ? (inner ? lv + texel : min(lv + texel, Gv - 1)) : (inner ? lb + ry : min(lb + ry, Gb - 1));
+                const int col = inner ? la + rx : min(la + rx, Ga - 1);
+                const float* src = is_line ? ltab + ((size_t)row * 16 + 4 * qq) : ptab + (((size_t)row * Ga + col) * 16 + 4 * qq);
                 dma16(src, buf + (NT * r + 64 * wave) * 4);
             }
         }
@@ -264,52 +308,20 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
     };
     if (fits) issue_pass(0);
     STAMP(1);
-    // ---------------------------------------------------------------------------------------------------- phase A: records
-    // sixteen lanes per ray: lane l16 takes the samples l16 and, for l16 < 4, 16 + l16
-    {
-        const int l16 = 4 * p + c;
-        bool occ[2] = {true, true};
-        if (f.mask) {
+    // ---------------------------------------------------------------------------------------------------- phase A, second half
+    // the tap indices relative to the box, packed; the records to LDS
+    auto write_rec = [&](int t, const Pre& r) {
+        u32q rec = {0u, 0u, 0u, 0u};
+        if (r.any) {
+            uint32_t packed = r.flags;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int s = min(l16 + 16 * k, FS - 1);
-                const float z = z_of(f, 0, FS, 0.0f, s);
-                const float pt[3] = {ro[0] + rd[0] * z, ro[1] + rd[1] * z, ro[2] + rd[2] * z};
-                occ[k] = mask_occupied(f, pt);
-            }
+            for (int ax = 0; ax < 3; ++ax) packed |= (uint32_t)((r.t0[ax] - lo[ax]) & 31) << (8 * ax);
+            rec.x = packed; rec.y = __float_as_uint(r.w1[0]); rec.z = __float_as_uint(r.w1[1]); rec.w = __float_as_uint(r.w1[2]);
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int s = l16 + 16 * k;
-            if (s < FS && slot_on) {
-                const float z = z_of(f, 0, FS, 0.0f, s);
-                const float pt[3] = {ro[0] + rd[0] * z, ro[1] + rd[1] * z, ro[2] + rd[2] * z};
-                u32q rec = {0u, 0u, 0u, 0u};
-                if (live && inside_aabb(f, pt)) {
-                    float xn[3];
-                    field_normalize(f, pt, xn);
-                    uint32_t packed = occ[k] ? REC_VALID : 0u;
-                    float w1[3];
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        // axis_tap (iff_device.h), with the zero padding kept as flags
-                        const int size = f.grid[ax];
-                        const float x = unnorm(xn[ax], size);
-                        const float fx = floorf(x);
-                        w1[ax] = x - fx;
-                        const bool ok = (x > -2.0f) && (x < (float)(size + 1));
-                        const int i0 = ok ? (int)fx : -2, i1 = i0 + 1;
-                        const int t0 = min(max(i0, 0), size - 1), t1 = min(max(i1, 0), size - 1);
-                        const bool z0 = !(i0 >= 0 && i0 < size), z1 = !(i1 >= 0 && i1 < size);
-                        packed |= (uint32_t)(((t0 - lo[ax]) & 31) | ((t1 - t0) << 5) | (z0 ? 64 : 0) | (z1 ? 128 : 0)) << (8 * ax);
-                        if (z0 || z1) packed |= REC_PAD;
-                    }
-                    rec.x = packed; rec.y = __float_as_uint(w1[0]); rec.z = __float_as_uint(w1[1]); rec.w = __float_as_uint(w1[2]);
-                }
-                *reinterpret_cast<u32q*>(s_rec + (rs * FS + s) * 4) = rec;
-            }
-        }
-    }
+        *reinterpret_cast<u32q*>(s_rec + t * 4) = rec;
+    };
+    write_rec(tid, pre0);
+    if (wave == 7 && lane < NSMP - NT) write_rec(NT + lane, pre1);
     STAMP(2);
     // ---------------------------------------------------------------------------------------------------- phase B: density
     // quad p of a ray takes the samples s = 4 k + p (k = 0 .. 4): in trip k the four quads of the ray -- one ds_read_b128 lane group --
@@ -366,16 +378,18 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         }
     } else if (fits) {
         // one plane per pass: the five partial sums of the quad's samples stay in registers across the passes (select chains, no
-        // runtime-indexed array)
+        // runtime-indexed array); the record of the next sample is read one trip ahead
         float part[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int dp = 0; dp < NDP; ++dp) {
             land_and_sync();
             issue_pass(dp + 1);
             const float* buf = (dp & 1) ? s_buf1 : s_buf0;
+            u32q nrec = *reinterpret_cast<const u32q*>(s_rec + t0 * 4);
 #pragma unroll 1
             for (int k = 0; k < 5; ++k) {
-                const RecView rv = unpack_rec(*reinterpret_cast<const u32q*>(s_rec + (t0 + 4 * k) * 4));
+                const RecView rv = unpack_rec(nrec);
+                nrec = *reinterpret_cast<const u32q*>(s_rec + (t0 + 4 * min(k + 1, 4)) * 4);
                 const float before = k == 0 ? part[0] : (k == 1 ? part[1] : (k == 2 ? part[2] : (k == 3 ? part[3] : part[4])));
                 const float after = density_terms(buf, rv, dp, before);
 #pragma unroll
@@ -384,21 +398,18 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         }
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
-            const int k = round == 0 ? c : 4;
-            const bool valid = (s_rec[(t0 + 4 * k) * 4] & REC_VALID) != 0u;
-            const float mine = k == 0 ? part[0] : (k == 1 ? part[1] : (k == 2 ? part[2] : (k == 3 ? part[3] : part[4])));
             // the quad's four lanes finish four different samples: each needs the sum of ITS sample's four quarter partials
             float feat = 0.0f;
+            bool valid = false;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int ks = round == 0 ? kk : 4;
                 const float pk = ks == 0 ? part[0] : (ks == 1 ? part[1] : (ks == 2 ? part[2] : (ks == 3 ? part[3] : part[4])));
                 const bool vk = (s_rec[(t0 + 4 * ks) * 4] & REC_VALID) != 0u;
                 const float fk = sum4_dpp(vk ? pk : 0.0f);
-                if (kk == c || round == 1) feat = fk;
+                if (kk == c || round == 1) { feat = fk; valid = vk; }
             }
-            (void)mine;
-            finish(k, feat, valid, round == 0 || c == 0);
+            finish(round == 0 ? c : 4, feat, valid, round == 0 || c == 0);
         }
     } else {
         // the gather path: the taps of a valid sample where the general kernels read them (density_partial: the same chain)
@@ -414,8 +425,9 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
                 const bool valid = (s_rec[(t0 + 4 * k) * 4] & REC_VALID) != 0u;
                 float v = 0.0f;
                 if (valid) {
+                    const float* sr = s_ray + (slot_on ? rs : 0) * 8;
                     const float z = z_of(f, 0, FS, 0.0f, 4 * k + p);
-                    const float pt[3] = {ro[0] + rd[0] * z, ro[1] + rd[1] * z, ro[2] + rd[2] * z};
+                    const float pt[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
                     float xn[3];
                     field_normalize(f, pt, xn);
                     v = density_partial(f, xn, c);
@@ -428,17 +440,18 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
     }
     STAMP(4);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the alphas are in LDS; no vector-memory wait: the first appearance patch stays in flight
-    // the transmittance product of the ray (tensorBase.py:27-32), all sixteen lanes alike
-    unsigned shmask = 0u;
-    {
-        const int tb = (slot_on ? rs : 0) * FS;
+    // the transmittance product of the rays (tensorBase.py:27-32): one lane per ray in wave 0 -- the chain is serial per ray, and
+    // run by the sixteen lanes of every slot it cost every wave its instructions; the other waves go on to the next barrier
+    if (wave == 0 && lane < FR) {
+        const int ry = lane, tb = ry * FS;
+        const int64_t r_glob = ray0 + ry;
+        const bool rlive = ry < n_live;
         float run_T = 1.0f, run_acc = 0.0f, run_depth = 0.0f;
         int run_valid = 0, run_app = 0;
-        const bool writer = live && p == 0 && c == 0;
-        const int64_t r_glob = ray0 + rs;
+        unsigned sh_bits = 0u;
         float al[FS];
 #pragma unroll
-        for (int s = 0; s < FS; ++s) al[s] = s_w[tb + s];           // every alpha of the ray is read before the first weight is written
+        for (int s = 0; s < FS; ++s) al[s] = s_w[tb + s];
         if (a.counts) {
 #pragma unroll
             for (int s = 0; s < FS; ++s) run_valid += (s_rec[(tb + s) * 4] & REC_VALID) ? 1 : 0;
@@ -453,30 +466,29 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
             run_depth += w * z;
             const bool sh = w > f.weight_thres;                                     // tensorBase.py:851
             run_app += sh ? 1 : 0;
-            shmask |= (sh ? 1u : 0u) << s;
-            if (writer) {
-                s_w[tb + s] = w;          // (the sixteen lanes of a ray are lanes of one wave: their reads above precede this store)
+            sh_bits |= (sh ? 1u : 0u) << s;
+            s_w[tb + s] = w;
 #ifndef FAN_STAMPS
-                if (a.alpha) a.alpha[r_glob * FS + s] = alpha;
+            if (rlive && a.alpha) a.alpha[r_glob * FS + s] = alpha;
 #endif
-            }
         }
-        if (writer) {
-            if (MODE == 3) s_ray[rs * 8 + 6] = run_acc;             // phase E blends with it
+        s_sh[ry] = rlive ? sh_bits : 0u;
+        if (rlive) {
+            if (MODE == 3) s_ray[ry * 8 + 6] = run_acc;             // phase E blends with it
             a.acc[r_glob] = run_acc;
-            a.depth[r_glob] = run_depth + (1.0f - run_acc) * rlast;
+            a.depth[r_glob] = run_depth + (1.0f - run_acc) * s_ray[ry * 8 + 7];
             if (a.counts) { a.counts[r_glob * 2] = run_valid; a.counts[r_glob * 2 + 1] = run_app; }
         }
     }
+    if (wave == 0 && lane >= FR && lane < 32) s_sh[lane] = 0u;
     STAMP(5);
-    if (!live) shmask = 0u;
-    const bool any = shmask != 0u;
-    const unsigned mymask = shmask & (0x11111u << p);                 // this quad's shaded samples: s = p mod 4
+    // (the masks are read behind the barrier that opens the first appearance pass / the gather path)
     // ---------------------------------------------------------------------------------------------------- phase C: appearance
     // accp[12 j + 4 i + e]: the weighted product sum of channel 16 j + 4 c + e of plane i over this quad's samples
     float accp[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) accp[i] = 0.0f;
+    unsigned shmask = 0u, mymask = 0u;                     // the ray's shaded samples, this quad's of them (s = p mod 4)
     f32q pre[2];                                           // basis_mat for phase D: requested during the last pass
     auto fetch_basis = [&]() {
         constexpr int NB = 27 * 144 / 4;                   // 972 pieces
@@ -488,12 +500,66 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         for (int ap = 0; ap < 3 * NSL; ++ap) {
             const int n = NDP + ap, i = ap / NSL, js = ap - i * NSL;
             land_and_sync();                               // the weights are written (ap = 0) / the other buffer has been read; this patch landed
+            if (ap == 0) { shmask = s_sh[rs]; mymask = shmask & (0x11111u << p); }
             if (ap + 1 < 3 * NSL) issue_pass(n + 1);
             STAMP(6 + (ap < 4 ? ap : 4));
             const float* buf = (n & 1) ? s_buf1 : s_buf0;
             const int ax_a = mat_a(i), ax_b = mat_b(i), ax_v = vec_ax(i);
             unsigned m = mymask;
             const int tb = (slot_on ? rs : 0) * FS;
+            if constexpr (QPP == 1) {
+                // one 16-channel quarter per pass: 24 registers of taps per trip, so the taps of the NEXT shaded sample are requested
+                // before this one's are combined, and the record after that is on its way (three LDS round trips overlapped per trip)
+                const int j = js;
+                struct Trip { f32q t[6]; float pw[4], lw[2], w; };
+                auto pop = [&]() { const int s = __ffs((int)m) - 1; m &= m - 1u; return s; };
+                auto request = [&](const u32q rec, float w, Trip& T) {
+                    const RecView rv = unpack_rec(rec);
+                    const float* P = buf + ((rv.r[ax_b] * PITCH + rv.r[ax_a]) * SLC + 4 * c);
+                    const int da = rv.d[ax_a] * SLC, db = rv.d[ax_b] * (PITCH * SLC);
+                    const float* L = buf + G::PLANE + (rv.r[ax_v] * SLC + 4 * c);
+                    T.t[0] = *reinterpret_cast<const f32q*>(P); T.t[1] = *reinterpret_cast<const f32q*>(P + da);
+                    T.t[2] = *reinterpret_cast<const f32q*>(P + db); T.t[3] = *reinterpret_cast<const f32q*>(P + db + da);
+                    T.t[4] = *reinterpret_cast<const f32q*>(L); T.t[5] = *reinterpret_cast<const f32q*>(L + rv.d[ax_v] * SLC);
+                    T.pw[0] = rv.wt[ax_b][0] * rv.wt[ax_a][0]; T.pw[1] = rv.wt[ax_b][0] * rv.wt[ax_a][1];
+                    T.pw[2] = rv.wt[ax_b][1] * rv.wt[ax_a][0]; T.pw[3] = rv.wt[ax_b][1] * rv.wt[ax_a][1];
+                    T.lw[0] = rv.wt[ax_v][0]; T.lw[1] = rv.wt[ax_v][1];
+                    T.w = w;
+                };
+                auto combine = [&](const Trip& T) {
+                    const f32q pr = lerp_plane_q(T.t[0], T.t[1], T.t[2], T.t[3], T.pw) * lerp_line_q(T.t[4], T.t[5], T.lw);
+                    accp[12 * j + 4 * i + 0] = fmaf(T.w, pr.x, accp[12 * j + 4 * i + 0]);
+                    accp[12 * j + 4 * i + 1] = fmaf(T.w, pr.y, accp[12 * j + 4 * i + 1]);
+                    accp[12 * j + 4 * i + 2] = fmaf(T.w, pr.z, accp[12 * j + 4 * i + 2]);
+                    accp[12 * j + 4 * i + 3] = fmaf(T.w, pr.w, accp[12 * j + 4 * i + 3]);
+                };
+                Trip A, B;
+                u32q rec = {0u, 0u, 0u, 0u};
+                float wn = 0.0f;
+                bool hA = m != 0u;
+                if (hA) { const int s = pop(); rec = *reinterpret_cast<const u32q*>(s_rec + (tb + s) * 4); wn = s_w[tb + s]; request(rec, wn, A); }
+                bool pending = m != 0u;
+                if (pending) { const int s = pop(); rec = *reinterpret_cast<const u32q*>(s_rec + (tb + s) * 4); wn = s_w[tb + s]; }
+                while (hA) {
+                    const bool hB = pending;
+                    if (hB) {
+                        request(rec, wn, B);
+                        pending = m != 0u;
+                        if (pending) { const int s = pop(); rec = *reinterpret_cast<const u32q*>(s_rec + (tb + s) * 4); wn = s_w[tb + s]; }
+                    }
+                    combine(A);
+                    hA = false;
+                    if (hB) {
+                        hA = pending;
+                        if (hA) {
+                            request(rec, wn, A);
+                            pending = m != 0u;
+                            if (pending) { const int s = pop(); rec = *reinterpret_cast<const u32q*>(s_rec + (tb + s) * 4); wn = s_w[tb + s]; }
+                        }
+                        combine(B);
+                    }
+                }
+            } else {
             // the record and weight of the next sample are read one trip ahead
             u32q na = {0u, 0u, 0u, 0u};
             float nw = 0.0f;
@@ -531,19 +597,22 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
                     accp[12 * j + 4 * i + 3] = fmaf(w, pr.w, accp[12 * j + 4 * i + 3]);
                 }
             }
+            }
             if (ap + 1 == 3 * NSL) fetch_basis();          // no DMA is in flight any more: plain loads
         }
     } else {
         // the gather path: a tile whose samples do not fit one patch reads its taps where the general kernels do
         __syncthreads();                                   // the weights are written
+        shmask = s_sh[rs]; mymask = shmask & (0x11111u << p);
         unsigned m = mymask;
         const int tb = (slot_on ? rs : 0) * FS;
+        const float* sr = s_ray + (slot_on ? rs : 0) * 8;          // (the ray from LDS: its registers are not kept through phase C)
         while (m) {
             const int s = __ffs((int)m) - 1;
             m &= m - 1u;
             const float w = s_w[tb + s];
             const float z = z_of(f, 0, FS, 0.0f, s);
-            const float pt[3] = {ro[0] + rd[0] * z, ro[1] + rd[1] * z, ro[2] + rd[2] * z};
+            const float pt[3] = {sr[0] + sr[3] * z, sr[1] + sr[4] * z, sr[2] + sr[5] * z};
             float xn[3];
             field_normalize(f, pt, xn);
 #pragma unroll
@@ -563,15 +632,20 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
     // the 144 weighted products as one 32 x 32 x 144 product on the fp32 matrix cores -- the four-wave kernel's phase D: k split
     // over waves 0 .. 3, the four partial tiles added in a fixed order.
     {
-        const int half = 8 * (gi >> 1), par = gi & 1;
-        int src[4];
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) src[pp] = 4 * (half + 2 * pp + ((__popc(pp) & 1) ^ par)) + c;
+        // the ray's quads are {0, 3 | 5, 6} or {1, 2 | 4, 7} of a 32-lane half (two DPP rows of four quads): first the partner inside
+        // the row -- one quad to the left for quads 0, 2, 4, 6 of the half (row_ror 4), one to the right for the others (row_ror 12) --,
+        // then the pair sum two quads on in the OTHER row (one ds_bpermute): (p0 + p1) + (p2 + p3) on every lane of the ray
+        const bool left = ((q & 7) == 0) || ((q & 7) == 2) || ((q & 7) == 4) || ((q & 7) == 6);
+        const int other = (((lane + 8) & 15) | ((lane & 16) ^ 16) | (lane & 32)) << 2;      // byte index for ds_bpermute
 #pragma unroll
         for (int i = 0; i < 36; ++i) {
-            const float v0 = __shfl(accp[i], src[0], 64), v1 = __shfl(accp[i], src[1], 64);
-            const float v2 = __shfl(accp[i], src[2], 64), v3 = __shfl(accp[i], src[3], 64);
-            accp[i] = (v0 + v1) + (v2 + v3);
+            const float a4 = dpp_mov<0x124>(accp[i]), a12 = dpp_mov<0x12C>(accp[i]);       // row_ror:4, row_ror:12
+            accp[i] = accp[i] + (left ? a4 : a12);
+        }
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(other, __builtin_bit_cast(int, accp[i])));
+            accp[i] = (p < 2) ? accp[i] + o : o + accp[i];
         }
     }
     constexpr int DLD = 33;                            // operand rows padded: conflict-free ds_read_b32 down a column of k
@@ -653,7 +727,7 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         const float* pp = s_pool + ry * 32 + o;
         s_feat[ry * 28 + o] = (pp[0] + pp[32 * 32]) + (pp[2 * 32 * 32] + pp[3 * 32 * 32]);
     }
-    if (slot_on && p == 0 && c == 0) s_feat[rs * 28 + 27] = any ? 1.0f : 0.0f;
+    if (slot_on && p == 0 && c == 0) s_feat[rs * 28 + 27] = shmask != 0u ? 1.0f : 0.0f;
     if (MODE == 3 && tid < 5 * 28) s_feat[FR * 28 + tid] = 0.0f;             // rows 27..31 of the matrix operand
     STAMP(13);
     __syncthreads();
