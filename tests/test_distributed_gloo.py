@@ -1,4 +1,4 @@
-"""CPU-only, world_size 2 over gloo: the ray-sharded exchange of iffnerf_amd/distributed.py.
+"""CPU-only, world_size 2 and 8 over gloo: the ray-sharded exchange of iffnerf_amd/distributed.py.
 
 Each rank takes a contiguous block of surface points (27-ray fans), computes its local logits / statistics with the
 oracle (the GPU ranks use the HIP kernels for that part), and runs the product's exchange + merge code.  The merged
@@ -24,9 +24,8 @@ def _free_port():
     return p
 
 
-def _inputs():
-    g = torch.Generator().manual_seed(11)
-    P = 75                                   # 2025 rays; not divisible by 2 -> ragged shards
+def _inputs(P=75):
+    g = torch.Generator().manual_seed(11)   # P = 75: 2025 rays, not divisible by 2 -> ragged shards; P = 593 over 8 ranks: 75 + 7 x 74 points
     ori = (torch.randn(P, 3, generator=g) * 0.4).repeat_interleave(27, dim=0)
     dirs = torch.nn.functional.normalize(torch.randn(P * 27, 3, generator=g), dim=-1)
     rgb = torch.rand(P * 27, 3, generator=g)
@@ -34,14 +33,48 @@ def _inputs():
     return P, ori, dirs, rgb, tokens, synthetic.make_id_weights(seed=99)
 
 
-def _worker(rank, world_size, port, out_dir):
+def _planted_ties(rank, world_size, k):
+    """Candidate lists whose values TIE across ranks: every rank offers the same k values (1 - j/64, exactly representable), rank r
+    under the global indices 1000 r + j -- and under 1000 (7 - r) + j in a second query, so the index order is not the rank order.
+    The merged top-k must hold, for each value, the copies with the LOWEST global indices (torch.topk's order on one GPU: value
+    descending, lower index first), identically on every rank and on every repetition."""
+    j = torch.arange(k)
+    val = (1.0 - j.float() / 64.0).repeat(2, 1)
+    idx = torch.stack((1000 * rank + j, 1000 * (world_size - 1 - rank) + j)).to(torch.int64)
+    pay = torch.stack((idx.float(), val), dim=-1)                      # the payload names its owner: it must travel with it
+    first = D.merge_topk(val, idx, pay, k)
+    again = D.merge_topk(val, idx, pay, k)
+    for a, b in zip(first, again):
+        assert torch.equal(a, b), "the merge is not reproducible"
+    mval, midx, mpay = first
+    per_value = k // world_size                                        # k = 100, 8 ranks: 12 full values + 4 copies of the 13th
+    for q in range(2):
+        want_val, want_idx = [], []
+        for jj in range(k):
+            for r in range(world_size):                                # ascending global index for this value: 1000 r' + jj
+                want_val.append(1.0 - jj / 64.0), want_idx.append(1000 * r + jj)
+        assert mval[q].tolist() == want_val[:k] and midx[q].tolist() == want_idx[:k], (rank, q)
+        assert torch.equal(mpay[q][:, 0], midx[q].float()) and torch.equal(mpay[q][:, 1], mval[q])
+    assert per_value >= 1
+    # the softmax statistics: ranks added in rank order, so every rank holds the same bits -- compared through an all_gather of the result
+    g = torch.Generator().manual_seed(100 + rank)
+    rmax, rsum = torch.randn(37, generator=g) * 20.0, torch.rand(37, generator=g) * 1000.0 + 1.0
+    gmax, gsum = D.merge_row_stats(rmax, rsum)
+    both = D._all_gather_stack(torch.stack((gmax, gsum)))
+    for r in range(world_size):
+        assert torch.equal(both[r], both[0]), "ranks disagree on the merged statistics"
+    return mval, midx
+
+
+def _worker(rank, world_size, port, out_dir, P=75):
     from oracle import identify as oid
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
-        torch.set_num_threads(2)
-        P, ori, dirs, rgb, tokens, w = _inputs()
+        torch.set_num_threads(1 if world_size > 2 else 2)
+        P, ori, dirs, rgb, tokens, w = _inputs(P)
+        tie_val, tie_idx = _planted_ties(rank, world_size, 100)
         Q, M, _ = tokens.shape
         k = 100
         lo, hi = D.shard_points(P, rank, world_size)
@@ -80,7 +113,8 @@ def _worker(rank, world_size, port, out_dir):
         pay = pay_m
         counts = [(D.shard_points(P, r, world_size)[1] - D.shard_points(P, r, world_size)[0]) * 27 for r in range(world_size)]
         full = D.gather_scores(torch.stack(scores), counts)
-        torch.save({"val": val, "idx": idx, "pay": pay, "full": full}, os.path.join(out_dir, f"rank{rank}.pt"))
+        torch.save({"val": val, "idx": idx, "pay": pay, "full": full, "tie_val": tie_val, "tie_idx": tie_idx, "block": (lo, hi)},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -102,6 +136,36 @@ def test_sharded_exchange_equals_single_process(tmp_path):
         assert r0["idx"][q].tolist() == idx.tolist(), "global top-100 must equal the single-process top-100"
         torch.testing.assert_close(r0["val"][q], val, rtol=2e-4, atol=1e-9)
         assert torch.equal(r0["pay"][q][:, :3], ori[idx]) and torch.equal(r0["pay"][q][:, 3:], dirs[idx])
+
+
+@pytest.mark.timeout(600)
+def test_sharded_exchange_at_world_size_8(tmp_path):
+    """The rank count BASELINE configs 4-5 name: 593 surface points (lego16k's) over 8 ranks -- one block of 75 points and seven of
+    74 -- through the product's exchange + merge code with the oracle as the local work; planted cross-rank ties (_planted_ties);
+    every rank must hold the same bits, and the merged top-100 must be the single-process top-100."""
+    from oracle import identify as oid
+    world_size, P = 8, 593
+    port = _free_port()
+    mp.spawn(_worker, args=(world_size, port, str(tmp_path), P), nprocs=world_size, join=True)
+    P, ori, dirs, rgb, tokens, w = _inputs(P)
+    ranks = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world_size)]
+    sizes = [b["block"][1] - b["block"][0] for b in ranks]
+    assert sizes == [75] + [74] * 7 and ranks[0]["block"][0] == 0 and ranks[-1]["block"][1] == P
+    for r in ranks[1:]:
+        for key in ("val", "idx", "pay", "full", "tie_val", "tie_idx"):
+            assert torch.equal(ranks[0][key], r[key]), f"ranks disagree on {key}"
+    r0 = ranks[0]
+    for q in range(tokens.shape[0]):
+        idx, val, score, _ = oid.test_image(w, tokens[q], ori, dirs, rgb, 100)
+        torch.testing.assert_close(r0["full"][q], score, rtol=2e-4, atol=1e-9)
+        # the sharded scores differ from the single-process ones by fp32 rounding of the statistics merge: the lists agree up to
+        # near-ties of THOSE scores; ordered by the sharded scores themselves the list must be exactly torch.topk's
+        tv, ti = torch.topk(r0["full"][q], 100)
+        assert torch.equal(r0["val"][q], tv)
+        same_order = torch.argsort(r0["full"][q], descending=True, stable=True)[:100]
+        assert r0["idx"][q].tolist() == same_order.tolist(), "value descending, lower global index first"
+        assert len(set(r0["idx"][q].tolist()) ^ set(idx.tolist())) <= 2
+        assert torch.equal(r0["pay"][q][:, :3], ori[r0["idx"][q]]) and torch.equal(r0["pay"][q][:, 3:], dirs[r0["idx"][q]])
 
 
 def test_shard_points_partition():
