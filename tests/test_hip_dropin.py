@@ -240,14 +240,16 @@ def test_concurrent_captured_steps_reproduce_the_eager_path(dev, config, rounds)
             assert torch.equal(idx, g.idx) and torch.equal(val, g.val) and torch.equal(c2w, g.c2w), (r, i, float((val - g.val).abs().max()))
 
 
-@pytest.mark.parametrize("config,rounds", [("truck32k", 150), ("lego16k", 100)])
+@pytest.mark.parametrize("config,rounds", [("truck32k", 150), ("lego16k", 100), ("bicycle64k", 40), ("lego540k", 20)])
 def test_concurrent_stage_outputs_reproduce_the_eager_kernels(dev, config, rounds):
     """The stage-level form of the check above (what found the packed-fp32 fault: scripts/replay_vs_eager_stages.py ONLY=trunk): four
     captured graphs in flight, each the cold emission of a batch (sampler, normals, emit, the fan march) FOLLOWED BY the trunk launch
     on static rays, so that the tail of every march runs next to another graph's fp16-MFMA workgroups; after every round each graph's
     ray colours, depth, opacity and its logits are recomputed eagerly from the graph's OWN surface samples and compared bit for bit.
     A final pose or a top-100 list can hide a colour that is off by 1e-3 -- this cannot.  600 / 400 steps: the compiler's packed
-    fp32 build showed 14 events per 2 000."""
+    fp32 build showed 14 events per 2 000.  Every workload the bench can run is soaked: bicycle64k marches on the eight-wave fan kernel
+    (patches by global -> LDS DMA: a transfer still in flight when a buffer is read would show here), lego540k at the reference's
+    default 540 000 rays per query."""
     from iffnerf_amd.hip_field import isocell_emit
     from iffnerf_amd.pipeline import PosePipeline
     wl = synthetic.WORKLOADS[config]
