@@ -623,16 +623,20 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
 
     plan = pipe.field.march_plan(0, 20)
     if plan in (2, 3):
+        fan_waves, fan_side = pipe.field.fan_kernel(0, 20)
+        fan_name = pipe.field.fan_kernel_name(0, 20)
         kernels.append(gather_kernel(
-            "k4f_fan_march<3> (TensorBase.forward, fused per 27-ray fan: density, compositing, appearance, basis_mat, Ref head, blend)" if plan == 3 else
-            "k4f_fan_march<2> (TensorBase.forward up to the Ref head, fused per 27-ray fan: density, compositing, appearance, basis_mat)",
-            ("k4f_fan_march<%d>" % plan,), "lds-gather", LDS_PEAK_GBS, bytes_a + bytes_b - rays_per_launch * 2 * 20 * 4,
+            fan_name + (" (TensorBase.forward, fused per 27-ray fan: density, compositing, appearance, basis_mat, Ref head, blend)" if plan == 3 else
+                        " (TensorBase.forward up to the Ref head, fused per 27-ray fan: density, compositing, appearance, basis_mat)"),
+            (fan_name,), "lds-gather", LDS_PEAK_GBS, bytes_a + bytes_b - rays_per_launch * 2 * 20 * 4,
             march_launch_ms[1],
             "algorithmic bytes = 1184 B per valid sample + 3456 B per shaded sample (SURVEY 8d) x the kernel's own sample counters + "
-            "rays in / features out.  The table patches a fan touches are staged once in LDS (coalesced row segments: `traffic` is "
-            "what crosses the L2's memory side) and every tap is an LDS read, so the roof is the LDS read rate, 256 B/clk per CU.  "
-            "No unit of the CU is saturated (`binding`): the launch is paced by the instruction streams of its 12 waves per CU (one wave "
-            "alone issues a vector instruction every ~6 clocks; 1 / 2 / 3 workgroups per CU run it in 2.35 / 1.30 / 0.98 ms); DESIGN.md section 4"))
+            "rays in / features out.  The table patches a fan touches are staged once in LDS (%s; `traffic` is what crosses the L2's "
+            "memory side) and every tap is an LDS read, so the roof `frac` prices is the LDS read rate, 256 B/clk per CU.  SURVEY 8(d)'s own "
+            "HBM roof is `frac_8d` (> 1: void for this kernel -- a fan's 540 samples share one box of texels) and `frac_hbm_counters` what "
+            "HBM really sees; no unit of the CU is saturated (`binding`): DESIGN.md section 4"
+            % ("coalesced row segments through registers, %d-texel boxes" % fan_side if fan_waves == 4 else
+               "global -> LDS DMA into two buffers, %d-texel boxes%s" % (fan_side, ", one 16-channel slice per pass" if fan_side == 22 else ""))))
     else:
         kernels.append(gather_kernel(
             "k4b_appearance12<27> (appearance gather of TensorBase.forward)", ("k4b_appearance12<27>", "k4b_appearance<27, true, 16>"),

@@ -87,6 +87,7 @@ SIGNATURES = {
     "iff_march_workspace": (_SZ, [_VP, _I64, _I32, _I32]),
     "iff_march_default_samples": (_I32, [_VP, _I32]),
     "iff_march_plan": (_I32, [_VP, _I32, _I32]),
+    "iff_march_fan_kernel": (C.c_int, [_VP, _I32, _I32, _VP, _VP]),
     "iff_march_shade": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, c_float_p, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_march_features": (C.c_int, [_VP, _VP, _I32, _I64, _I32, _I32, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_march_grad_workspace": (_SZ, [_VP, _I64, _I32, _I32]),

@@ -298,6 +298,15 @@ extern "C" int32_t iff_march_plan(const iff_field* f, int32_t mode, int32_t n_sa
     return (plan == IFF_MARCH_PLAN_FAN && march_head_fused(f->dev)) ? IFF_MARCH_PLAN_FAN_HEAD : plan;
 }
 
+extern "C" int iff_march_fan_kernel(const iff_field* f, int32_t mode, int32_t n_samples, int32_t* waves, int32_t* patch_side) {
+    IFF_REQUIRE(f && waves && patch_side, "iff_march_fan_kernel: null argument");
+    const int S = march_samples(f, mode, n_samples);
+    const int plan = march_plan(f->dev, mode, S);
+    *waves = plan == IFF_MARCH_PLAN_FAN ? fan_kernel_for(f->dev, mode, S) : 0;
+    *patch_side = *waves == 8 ? fan8_patch_side(f->dev, mode, S) : (*waves == 4 ? 12 : 0);
+    return 0;
+}
+
 extern "C" size_t iff_march_workspace(const iff_field* f, int64_t R, int32_t mode, int32_t n_samples) {
     if (!f || R <= 0) return 0;
     return march_workspace_bytes(R, march_samples(f, mode, n_samples));

@@ -220,6 +220,23 @@ class FieldHandle:
         """``iff_march_plan``: 0 the general kernels, 2 the fused fan kernel + the Ref head launch, 3 the fan kernel with the head fused in."""
         return int(_lib.lib().iff_march_plan(self._h, int(mode), int(n_samples)))
 
+    def fan_kernel(self, mode: int = MARCH_POINT, n_samples: int = -1):
+        """``iff_march_fan_kernel``: (waves per fan, patch side) of the fused fan kernel that serves this march -- (4, 12): k4f_fan_march,
+        (8, 12) / (8, 22): k4g_fan_march<12, 1> / <22, 3>, (0, 0): the general kernels."""
+        w, side = C.c_int32(), C.c_int32()
+        check(_lib.lib().iff_march_fan_kernel(self._h, int(mode), int(n_samples), C.byref(w), C.byref(side)), "iff_march_fan_kernel")
+        return int(w.value), int(side.value)
+
+    def fan_kernel_name(self, mode: int = MARCH_POINT, n_samples: int = -1) -> str:
+        """The kernel as rocprofv3 prints it (profiles/*.csv)."""
+        w, side = self.fan_kernel(mode, n_samples)
+        plan = self.march_plan(mode, n_samples)
+        if w == 4:
+            return "k4f_fan_march<%d>" % plan
+        if w == 8:
+            return "k4g_fan_march<%d, %d, %d>" % (side, 1 if side == 12 else 3, plan)
+        return ""
+
     def march(self, rays: torch.Tensor, mode: int, n_samples: int = -1, bg=(0.0, 0.0, 0.0), want_alpha: bool = True,
               want_counts: bool = False, stage_ms: Optional[list] = None):
         """stage_ms: pass an empty list to run the instrumented (synchronous) variant; it receives the 3 launch times."""

@@ -193,6 +193,11 @@ int32_t iff_march_default_samples(const iff_field* f, int32_t mode);
 #define IFF_MARCH_PLAN_FAN      2
 #define IFF_MARCH_PLAN_FAN_HEAD 3
 int32_t iff_march_plan(const iff_field* f, int32_t mode, int32_t n_samples);
+/* Which fused fan kernel iff_march_plan's IFF_MARCH_PLAN_FAN(_HEAD) means on this handle (TensorBase.forward with sample_point_color,
+ * models/tensorBase.py:775-917, :623-638): *waves = 4 (k4f_fan_march: four waves per 27-ray fan, register-staged 12-texel patches),
+ * 8 (k4g_fan_march: eight waves per fan, patches by global -> LDS DMA) or 0 (the general kernels); *patch_side = 12 or 22 texels
+ * (22: unisphere scenes, tensorBase.py:361-365).  iff_field_desc.fan_waves names one; this reports the choice (bench.py's roofline). */
+int iff_march_fan_kernel(const iff_field* f, int32_t mode, int32_t n_samples, int32_t* waves, int32_t* patch_side);
 int iff_march_shade(const iff_field* f, const float* rays, int32_t ray_cols, int64_t R, int32_t mode,
                     int32_t n_samples, const float* bg_host, float* rgb, float* depth, float* acc,
                     float* alpha_opt, int32_t* counts_opt, void* workspace, size_t workspace_bytes, void* stream);
