@@ -82,6 +82,9 @@ def parse_args():
     ap.add_argument("--trunk-variant", type=int, default=0, help="work split of the fused F16X2 launch (0 = default; tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the explore_model + test_pose_estimation measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip everything that is never part of `value` (warm path, image -> pose, cold image -> pose, drop-in route): the kernel "
+                         "statistics of such a run hold the cold step's launches only (profiles/*_inflight1_*.csv)")
     ap.add_argument("--no-instrument", action="store_true", help="skip the per-stage / roofline measurements after the timed loop")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (captured segments + all_gathers) at world size 1, for rehearsal on one GPU")
@@ -457,7 +460,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(ck, idw, tokens[:4].cpu(), gen_points, B if shared else 1)
         else:
             result["cpu_baseline"] = None
-        if world_size == 1 and not shared and not args.no_instrument and not args.no_dropin:
+        if world_size == 1 and not shared and not args.no_instrument and not args.no_dropin and not args.no_extras:
             # the route a user of the reference takes (never part of `value`): explore_model + test_pose_estimation through the
             # installed module names, at this workload's ray count and -- on the headline workload -- at the reference's default
             # gen_points = 20000 (540 000 rays, pose_estimation/model_utils.py:22-24)
@@ -661,7 +664,7 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
                               "traffic": shade_tr if shade_name.startswith("k_ref_shade_oct") else traffic("k_ref_shade<27, true>"),
                               "note": "Ref head per ray (ref.py:103-152): bottleneck on the fp32 matrix cores, the rest vector ALU from LDS-staged weights, no roofline"}
     result["roofline"]["other_kernels"] = others
-    if world_size == 1 and not shared:
+    if world_size == 1 and not shared and not args.no_extras:
         # warm path (rays resident: the reference's eval semantics, train_eval_pose_est.py:131-149): stage C only, 16 query
         # images per graph against one resident ray set whose encoder output is cached per model (SURVEY 8f-2:
         # PosePipeline.make_resident, built once, outside the timed loop), 4 graphs in flight

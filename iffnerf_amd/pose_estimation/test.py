@@ -29,6 +29,7 @@ from .errors import compute_angular_error, compute_translation_error  # noqa: F4
 INERF_ITERS = 800      # reference test.py:204
 INERF_BATCH = 1024     # pose_estimation's default batch_size (inerf/estimate_pose_inerf.py:31), which test.py:196-209 leaves alone
 EVAL_BATCH = 32        # images per batch of the batched route (one captured hipGraph per full batch)
+EVAL_SLOTS = 2         # captured batches in flight, each on its own stream (the chip is full at two: bench.py, image -> pose)
 LOGITS_BUDGET_BYTES = 4 << 30     # a batch's [B * 256, N] fp32 logits stay below this (540 000 rays: 7 images per batch)
 TOPK = 100             # rays_to_output of reference :90
 
@@ -120,7 +121,7 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
         key = (B, H_, W_, C_, up, backbone_key)
         if key not in session.graphs:
             session.graphs.clear()                       # at most one batch shape's graphs (and their logits buffers) stay alive
-            session.graphs[key] = [CapturedEvalBatch(id_module, session, (B, H_, W_, C_), up) for _ in range(2 if n_full > 1 else 1)]
+            session.graphs[key] = [CapturedEvalBatch(id_module, session, (B, H_, W_, C_), up) for _ in range(min(EVAL_SLOTS, n_full))]
         slots = session.graphs[key]
         cur = torch.cuda.current_stream(device)
         for s in slots:

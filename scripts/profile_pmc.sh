@@ -19,7 +19,7 @@ run() {   # name, rocprof args...
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $name timed out: stopping"; exit $rc; fi
 }
 BENCH_EXTRA="--steps 60 --warmup 10" run stats --kernel-trace --stats
-BENCH_EXTRA="--steps 60 --warmup 10 --in-flight 1" run stats_if1 --kernel-trace --stats
+BENCH_EXTRA="--steps 60 --warmup 10 --in-flight 1 --no-extras" run stats_if1 --kernel-trace --stats
 export BENCH_EXTRA="--in-flight 1 --no-instrument"
 run sq1 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
 run sq2 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_BUSY_CYCLES

@@ -87,7 +87,7 @@ def main():
             js["kernels"][k] = e
     json.dump(js, open(f"{out}_hbm_traffic.json", "w"), indent=1, sort_keys=True)
     for k in js["kernels"]:
-        if any(t in k for t in ("k4f", "k4b", "k4a", "k5_trunk", "k_ref_shade", "k6_", "k_surface", "k_score")):
+        if any(t in k for t in ("k4f", "k4g", "k4b", "k4a", "k5_trunk", "k_ref_shade", "k6_", "k_surface", "k_score")):
             print(k, js["kernels"][k])
 
 

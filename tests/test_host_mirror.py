@@ -302,3 +302,28 @@ def test_inerf_host_pieces(golden):
     from iffnerf_amd.inerf.estimate_pose_inerf import pose_estimation
     with pytest.raises(RuntimeError, match="OpenCV"):
         pose_estimation(torch.eye(4), np.zeros((4, 4, 4), np.float32), torch.eye(3), None, device="cpu")
+
+
+def test_lazy_attention_map_computes_on_first_use_only():
+    """``IdentificationModule.test_image`` returns its [M,N] attention map as a ``LazyAttentionMap`` (reference
+    identification_module.py:165-166 materialises it per image; pose_estimation/test.py reads it only under a loss function): nothing is
+    computed until something reads it, every tensor use -- attribute, index, operator, torch function -- sees the tensor, and the thunk runs
+    once.  Host logic only: the thunk here is a stand-in for the kernel calls (tests/test_hip_eval_loop.py checks the real one)."""
+    from iffnerf_amd.pose_estimation.identification_module import LazyAttentionMap
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return torch.softmax(torch.arange(12.0).reshape(3, 4), dim=-1)
+
+    a = LazyAttentionMap(thunk)
+    assert not a.is_materialized and not calls and "not computed" in repr(a)
+    assert a.shape == (3, 4) and a.is_materialized and len(calls) == 1              # an attribute read computes it
+    want = torch.softmax(torch.arange(12.0).reshape(3, 4), dim=-1)
+    assert torch.equal(a.sum(0), want.sum(0)) and torch.equal(torch.sum(a, dim=0), want.sum(0))     # method and torch function
+    assert torch.equal(a[1], want[1]) and len(a) == 3 and torch.equal(a * 2.0, want * 2.0) and torch.equal(2.0 * a, want * 2.0)
+    assert torch.equal(torch.stack([row for row in a]), want) and torch.equal(a @ torch.ones(4), want @ torch.ones(4))
+    assert torch.equal(torch.cat((a, a)), torch.cat((want, want)))                  # inside a container argument of a torch function
+    assert len(calls) == 1 and a.materialize() is a.materialize()
+    b = LazyAttentionMap(thunk)
+    assert bool((b >= 0).all()) and len(calls) == 2                                  # a comparison computes it too
