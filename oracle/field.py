@@ -94,6 +94,23 @@ def field_from_ckpt(ckpt: dict) -> Field:
     )
 
 
+def field_as_float64(f: Field) -> Field:
+    """The same field with every table, weight and bound held in float64 -- the REFEREE of the full-size tests (which of two fp32
+    evaluations is nearer the exact value of the reference's formulas), not a restatement of anything the reference runs."""
+    import dataclasses
+    up = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+    changes = {}
+    for fl in dataclasses.fields(f):
+        v = getattr(f, fl.name)
+        if torch.is_tensor(v):
+            changes[fl.name] = up(v)
+        elif isinstance(v, list):
+            changes[fl.name] = [up(t) for t in v]
+        elif isinstance(v, dict):
+            changes[fl.name] = {k: up(t) for k, t in v.items()}
+    return dataclasses.replace(f, **changes)          # __post_init__ re-derives step_size and friends from the float64 aabb
+
+
 # ----------------------------------------------------------------------------- coordinates
 def contract_power(x: torch.Tensor, alpha: float = -1.5) -> torch.Tensor:
     """utils.py:139-146 (power_transformation)."""
@@ -138,7 +155,7 @@ def density_feature(f: Field, xn: torch.Tensor) -> torch.Tensor:
     """tensoRF.py:216-235.  xn: normalised [n,3] -> [n]."""
     planes, lines = _vm_coords(xn)
     n = xn.shape[0]
-    out = torch.zeros((n,))
+    out = torch.zeros((n,), dtype=xn.dtype)
     for i in range(3):
         p = F.grid_sample(f.density_plane[i], planes[[i]], align_corners=True).view(-1, n)
         l = F.grid_sample(f.density_line[i], lines[[i]], align_corners=True).view(-1, n)
@@ -175,7 +192,7 @@ def compute_alpha(f: Field, xyz: torch.Tensor, length: float = 1) -> torch.Tenso
         keep = mask_sample(f, xyz) > 0
     else:
         keep = torch.ones_like(xyz[:, 0], dtype=torch.bool)
-    sigma = torch.zeros(xyz.shape[:-1])
+    sigma = torch.zeros(xyz.shape[:-1], dtype=xyz.dtype)
     if keep.any():
         sigma[keep] = feature2density(f, density_feature(f, normalize_coord(f, xyz[keep])))
     return 1 - torch.exp(-sigma * length).view(xyz.shape[:-1])
@@ -208,7 +225,7 @@ def sample_slab(f: Field, o: torch.Tensor, d: torch.Tensor, n_samples: int = -1)
 def alpha_compositing(sigma: torch.Tensor, dist: torch.Tensor):
     """tensorBase.py:23-35 (raw2alpha)."""
     alpha = 1.0 - torch.exp(-sigma * dist)
-    trans = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1), 1.0 - alpha + 1e-10], -1), -1)
+    trans = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1, dtype=alpha.dtype), 1.0 - alpha + 1e-10], -1), -1)
     return alpha, alpha * trans[:, :-1], trans[:, -1:]
 
 
@@ -282,22 +299,22 @@ def march(f: Field, rays: torch.Tensor, mode: str = "point", n_samples: int = -1
         bad = ~valid
         bad[valid] |= ~m
         valid = ~bad
-    sigma = torch.zeros(pts.shape[:-1])
+    sigma = torch.zeros(pts.shape[:-1], dtype=pts.dtype)
     if valid.any():
         pts = normalize_coord(f, pts)
         sigma[valid] = feature2density(f, density_feature(f, pts[valid]))
     alpha, weight, _ = alpha_compositing(sigma, dists * f.distance_scale)
     shade = weight > f.weight_thres
-    feats = torch.zeros((*pts.shape[:2], f.basis.shape[0]))
+    feats = torch.zeros((*pts.shape[:2], f.basis.shape[0]), dtype=pts.dtype)
     if shade.any():
         feats[shade] = app_feature(f, pts[shade])
     consider = shade.any(dim=-1)
     acc = torch.sum(weight, -1)
     ray_feat = torch.sum(weight[..., None] * feats, -2)
-    rgb = torch.zeros((d.shape[0], 3))
+    rgb = torch.zeros((d.shape[0], 3), dtype=d.dtype)
     rgb[consider] = ref_shade(f.head, d[consider], ray_feat[consider])
     if bg_color is None:
-        bg_color = torch.ones(3) if white_bg else torch.zeros(3)
+        bg_color = torch.ones(3, dtype=d.dtype) if white_bg else torch.zeros(3, dtype=d.dtype)
     rgb = (rgb * acc[..., None] + bg_color * (1.0 - acc[..., None])).clamp(0, 1)
     depth = torch.sum(weight * z, -1)
     depth = depth + (1.0 - acc) * rays[..., -1]
