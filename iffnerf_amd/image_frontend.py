@@ -57,10 +57,19 @@ def mask_token_rows(keep: torch.Tensor, row_max: torch.Tensor, row_sumexp: torch
               "iff_mask_token_rows")
 
 
-def resize_crop(src: torch.Tensor, resize_size: int, crop_size: int, cubic: bool, mean=None, std=None) -> torch.Tensor:
+def _into(out, like: torch.Tensor, shape) -> torch.Tensor:
+    """The caller's output buffer (a captured graph's static input), checked, or a fresh one."""
+    if out is None:
+        return like.new_empty(shape)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or out.device != like.device or not out.is_contiguous():
+        raise RuntimeError(f"out must be a contiguous fp32 tensor of shape {tuple(shape)} on {like.device}")
+    return out
+
+
+def resize_crop(src: torch.Tensor, resize_size: int, crop_size: int, cubic: bool, mean=None, std=None, out=None) -> torch.Tensor:
     """``iff_image_resize_crop``: channels-last images [Q,H,W,C] -> the centre ``crop_size`` window of the antialiased resize whose
     shorter edge is ``resize_size`` (torchvision Resize + CenterCrop of identification_module.py:36-61), normalised, channels-first
-    [Q,C,crop,crop].  ``crop_size`` None keeps the whole resized image."""
+    [Q,C,crop,crop] (written into ``out`` when given).  ``crop_size`` None keeps the whole resized image."""
     if not src.is_cuda:
         raise RuntimeError("images must live on the GPU; libiffnerf_hip has no CPU path")
     x = src.detach().to(torch.float32).contiguous()
@@ -71,7 +80,7 @@ def resize_crop(src: torch.Tensor, resize_size: int, crop_size: int, cubic: bool
         rh, rw = max(1, int(resize_size * H / W)), resize_size
     ch, cw = (rh, rw) if crop_size is None else (crop_size, crop_size)
     top, left = int(round((rh - ch) / 2.0)), int(round((rw - cw) / 2.0))
-    out = x.new_empty(Q, Cc, ch, cw)
+    out = _into(out, x, (Q, Cc, ch, cw))
     m = None if mean is None else fvec(mean)
     s = None if std is None else fvec(std)
     with torch.cuda.device(x.device):
@@ -83,7 +92,7 @@ def resize_crop(src: torch.Tensor, resize_size: int, crop_size: int, cubic: bool
 RESIZE_RGB_ON_WHITE, RESIZE_ALPHA = 1, 2          # include/iffnerf_hip.h IFF_RESIZE_*
 
 
-def resize_crop_rgba(src: torch.Tensor, resize_size: int, crop_size, mode: int, cubic: bool, mean=None, std=None) -> torch.Tensor:
+def resize_crop_rgba(src: torch.Tensor, resize_size: int, crop_size, mode: int, cubic: bool, mean=None, std=None, out=None) -> torch.Tensor:
     """``iff_image_resize_crop_rgba``: RGBA images [Q,H,W,4] -> the resized / cropped / normalised colour composited on white
     [Q,3,crop,crop] (``RESIZE_RGB_ON_WHITE``: pose_estimation/test.py:77-81 folded into the resize) or alpha channel [Q,1,crop,crop]
     (``RESIZE_ALPHA``) -- the images never exist as separate RGB / mask tensors."""
@@ -99,7 +108,7 @@ def resize_crop_rgba(src: torch.Tensor, resize_size: int, crop_size, mode: int, 
         rh, rw = max(1, int(resize_size * H / W)), resize_size
     ch, cw = (rh, rw) if crop_size is None else (crop_size, crop_size)
     top, left = int(round((rh - ch) / 2.0)), int(round((rw - cw) / 2.0))
-    out = x.new_empty(Q, 3 if mode == RESIZE_RGB_ON_WHITE else 1, ch, cw)
+    out = _into(out, x, (Q, 3 if mode == RESIZE_RGB_ON_WHITE else 1, ch, cw))
     m = None if mean is None else fvec(mean)
     s = None if std is None else fvec(std)
     with torch.cuda.device(x.device):
@@ -159,12 +168,33 @@ class ImageFrontEnd:
         """RGBA query images [Q,H,W,4] as the evaluation loop holds them (pose_estimation/test.py:75-81) -> (tokens, keep): the
         composite on white and the alpha mask are taken inside the two resize launches.  Equals ``tokens(rgb * a + (1 - a), a)``
         bit for bit."""
-        xin = resize_crop_rgba(rgba, self.resize_size, self.crop_size, RESIZE_RGB_ON_WHITE, True, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD)
+        return self.tokens_from_preprocessed(*self.preprocess(rgba))
+
+    # The two halves of ``tokens_rgba`` / ``tokens(imgs, None)``, for a caller that keeps the second half in a captured graph: the
+    # first half is the only part that reads the full-size images, so run eagerly it takes them WHERE THEY LIE (a slice of the
+    # dataset's own tensor) and the graph's static inputs are the 224 x 224 results, not a copy of 32 images of 800 x 800 x 4.
+    @torch.no_grad()
+    def preprocess(self, imgs: torch.Tensor, out=None):
+        """imgs [Q,H,W,4] (RGBA) or [Q,H,W,3] -> (xin [Q,3,crop,crop] normalised, alpha [Q,1,crop,crop] or None), written into
+        ``out = (xin, alpha)`` when given.  Native preprocessing only."""
+        if not self.native_preprocess:
+            raise RuntimeError("ImageFrontEnd.preprocess is the iff_image_resize_crop path (native_preprocess=True)")
+        o_x, o_m = (None, None) if out is None else out
+        if imgs.shape[-1] == 4:
+            xin = resize_crop_rgba(imgs, self.resize_size, self.crop_size, RESIZE_RGB_ON_WHITE, True, IMAGENET_DEFAULT_MEAN,
+                                   IMAGENET_DEFAULT_STD, out=o_x)
+            return xin, resize_crop_rgba(imgs, self.resize_size, self.crop_size, RESIZE_ALPHA, False, out=o_m)
+        return resize_crop(imgs, self.resize_size, self.crop_size, True, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, out=o_x), None
+
+    @torch.no_grad()
+    def tokens_from_preprocessed(self, xin: torch.Tensor, alpha: Optional[torch.Tensor]):
+        """(xin, alpha) of ``preprocess`` -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw])."""
         if self.backbone_autocast is None:
             feats = self.backbone.forward_features(xin)["x_norm_patchtokens"]
         else:
             with torch.autocast(device_type="cuda", dtype=self.backbone_autocast):
                 feats = self.backbone.forward_features(xin)["x_norm_patchtokens"]
-        m = resize_crop_rgba(rgba, self.resize_size, self.crop_size, RESIZE_ALPHA, False)
-        mg = resize_crop(m.permute(0, 2, 3, 1), self.grid[0], None, False).reshape(rgba.shape[0], -1)
+        mg = None
+        if alpha is not None:
+            mg = resize_crop(alpha.permute(0, 2, 3, 1), self.grid[0], None, False).reshape(xin.shape[0], -1)
         return token_assemble(feats, self.grid, mg, 0.1)

@@ -10,7 +10,8 @@ serves the images in BATCHES through one set of launches per batch -- composite 
 (``iff_image_resize_crop_rgba``), DINOv2's forward (``iff_vit_forward``), token assembly, folded query projection, logits against
 the ray encoder's cached output (``iff_ray_cache_build`` once per (weights, ray set), ``iff_logits_from_cache`` per batch), softmax
 / column sums / top-100, the closed-form pose (``iff_pose_from_topk_batched``) and the error metrics (``iff_pose_errors``) -- with
-full batches replayed as captured hipGraphs on two alternating streams and ONE device->host read per batch.  Every number equals,
+full batches replayed as captured hipGraphs on two alternating streams (the resize launches stay outside the graph and read the
+batch where the dataset holds it) and ONE device->host read per batch.  Every number equals,
 bit for bit, what the image-by-image route below returns (tests/test_hip_eval_loop.py): both run the same kernels, whose per-row
 arithmetic does not depend on the batch.  Image by image is the route of everything a batch cannot serve: an arbitrary backbone
 module (``IdentificationModule.serves_batches``), replaced preprocessing, the iNeRF refinement of reference :196-211
@@ -50,43 +51,65 @@ def _record(sequence_id, img_idx, summary_row, c2w_rows, gt_rows):
             "pred_c2w": c2w_rows, "gt_c2w": gt_rows}
 
 
-def eval_batch(id_module, session, images, gt_poses, model_up, k=TOPK):
-    """images [B,H,W,4] (RGBA) or [B,H,W,3], gt_poses [B,4,4] -> (c2w [B,4,4], summary [B,4]) on the device, nothing read back.
-    The body of reference :71-232 for B images: the launches of ``IdentificationModule.test_image`` + pose solve + error metrics."""
+def _eval_from_tokens(id_module, session, tokens, keep, gt_poses, model_up, k):
     from .. import hip_identify as H
-    tokens, keep = id_module.static_tokens(images, None)
     score, _ = id_module.scores_static(tokens, keep, session, want_map=False)
     idx, val = H.topk_batched(score, k)
     c2w, parts = H.pose_from_topk_batched(idx, val, session.ori, session.dirs, model_up, want_parts=True)
     return c2w, H.pose_errors(c2w, gt_poses, parts)
 
 
+def eval_batch(id_module, session, images, gt_poses, model_up, k=TOPK):
+    """images [B,H,W,4] (RGBA) or [B,H,W,3], gt_poses [B,4,4] -> (c2w [B,4,4], summary [B,4]) on the device, nothing read back.
+    The body of reference :71-232 for B images: the launches of ``IdentificationModule.test_image`` + pose solve + error metrics."""
+    tokens, keep = id_module.static_tokens(images, None)
+    return _eval_from_tokens(id_module, session, tokens, keep, gt_poses, model_up, k)
+
+
 class CapturedEvalBatch:
-    """``eval_batch`` for a fixed batch shape as one hipGraph with its own stream, static inputs (``images``, ``gt``) and pinned host
-    outputs: ``submit`` copies a batch in, replays and starts the read-back; ``collect`` waits for it."""
+    """``eval_batch`` for a fixed batch shape, in two parts on the slot's own stream.  EAGER: the resize launches, the only ones that
+    read the full-size images -- they take a device-resident batch where it lies (a slice of the dataset's tensor: no copy of
+    B x H x W x 4 floats into a static buffer; 328 MB per 32 images of 800 x 800) and write the graph's static inputs, the
+    normalised 224 x 224 crops and alpha planes.  CAPTURED (one hipGraph): backbone, tokens, logits against the cached encoder
+    output, softmax statistics, column sums, top-k, pose solve, error metrics.  ``submit`` runs both and starts the read-back into
+    pinned host memory; ``collect`` waits for it.  The launches are those of ``eval_batch``, in the same order per buffer."""
 
     def __init__(self, id_module, session, shape, model_up, k=TOPK):
         dev = session.ori.device
+        self.fe = id_module.frontend()
         self.stream = torch.cuda.Stream(device=dev)
-        self.images = torch.zeros(shape, dtype=torch.float32, device=dev)
-        self.images[..., -1] = 1.0 if shape[-1] == 4 else 0.0
+        self.shape = tuple(shape)
+        self.staging = None                               # a host-resident (or non-fp32) dataset passes through here
+        images = torch.zeros(shape, dtype=torch.float32, device=dev)
+        images[..., -1] = 1.0 if shape[-1] == 4 else 0.0
         self.gt = torch.eye(4, device=dev).repeat(shape[0], 1, 1)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):            # warm-up outside capture (handles, workspaces, allocator)
+            self.xin, self.alpha = self.fe.preprocess(images)
             for _ in range(2):
-                eval_batch(id_module, session, self.images, self.gt, model_up, k)
+                self._tail(id_module, session, model_up, k)
         torch.cuda.synchronize(dev)
+        del images
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream):
-            self.c2w, self.summary = eval_batch(id_module, session, self.images, self.gt, model_up, k)
+            self.c2w, self.summary = self._tail(id_module, session, model_up, k)
         self.host_c2w = torch.empty(self.c2w.shape, dtype=torch.float32, pin_memory=True)
         self.host_summary = torch.empty(self.summary.shape, dtype=torch.float32, pin_memory=True)
         self.done = torch.cuda.Event()
         self.pending = None
 
+    def _tail(self, id_module, session, model_up, k):
+        tokens, keep = self.fe.tokens_from_preprocessed(self.xin, self.alpha)
+        return _eval_from_tokens(id_module, session, tokens, keep, self.gt, model_up, k)
+
     def submit(self, images, gt, tag):
         with torch.cuda.stream(self.stream):
-            self.images.copy_(images, non_blocking=True)
+            if not (images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()):
+                if self.staging is None:
+                    self.staging = torch.empty(self.shape, dtype=torch.float32, device=self.xin.device)
+                self.staging.copy_(images, non_blocking=True)
+                images = self.staging
+            self.fe.preprocess(images, out=(self.xin, self.alpha))
             self.gt.copy_(gt, non_blocking=True)
             self.graph.replay()
             self.host_c2w.copy_(self.c2w, non_blocking=True)
@@ -166,8 +189,9 @@ def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, mode
     if _batchable(dataset, id_module, rays_ori, inerf_refinement):
         with torch.no_grad():
             rows = _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id)
+        gt_rows = dataset.poses.detach().cpu().tolist()               # one read for the whole dataset, not one per image
         for img_idx, (summary, c2w) in enumerate(rows):
-            results.append((summary, _record(sequence_id, img_idx, summary, c2w, dataset.poses[img_idx].cpu().tolist())))
+            results.append((summary, _record(sequence_id, img_idx, summary, c2w, gt_rows[img_idx])))
     else:
         for img_idx in range(n_images):
             pose = dataset.poses[img_idx].to(device, non_blocking=True)
