@@ -327,3 +327,22 @@ def test_lazy_attention_map_computes_on_first_use_only():
     assert len(calls) == 1 and a.materialize() is a.materialize()
     b = LazyAttentionMap(thunk)
     assert bool((b >= 0).all()) and len(calls) == 2                                  # a comparison computes it too
+
+
+def test_front_end_output_buffers_are_checked():
+    """The eval loop hands the resize launches the captured graph's static inputs (ImageFrontEnd.preprocess(out=...)): a buffer of the
+    wrong shape, dtype or layout must be refused on the host, before any pointer reaches the library -- and CPU images fail loudly
+    (no CPU path)."""
+    from iffnerf_amd import image_frontend as fe
+    like = torch.zeros(2, 8, 8, 4)
+    ok = torch.empty(2, 3, 4, 4)
+    assert fe._into(ok, like, (2, 3, 4, 4)) is ok
+    assert fe._into(None, like, (2, 3, 4, 4)).shape == (2, 3, 4, 4)
+    for bad in (torch.empty(2, 3, 4, 5), torch.empty(2, 3, 4, 4, dtype=torch.float64), torch.empty(2, 4, 4, 3).permute(0, 3, 1, 2)):
+        with pytest.raises(RuntimeError, match="out must be"):
+            fe._into(bad, like, (2, 3, 4, 4))
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        fe.resize_crop_rgba(like, 4, 4, fe.RESIZE_RGB_ON_WHITE, True)
+    front = fe.ImageFrontEnd(torch.nn.Identity(), native_preprocess=False)
+    with pytest.raises(RuntimeError, match="native_preprocess"):
+        front.preprocess(like)
