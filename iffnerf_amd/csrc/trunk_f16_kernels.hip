@@ -38,9 +38,10 @@ __device__ inline void split_h(float v, _Float16& hi, _Float16& lo) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // Four accumulator values -> the hi/lo halves of min(relu(acc inv + bias) s, H_MAX), with `is` = inv s and `bs` = bias s (s is a
-// power of two: relu(fma(acc, inv, bias)) s == relu(fma(acc, inv s, bias s)) bit for bit in the normal range).  Packed-pair
-// instructions throughout: v_pk_fma_f32, v_med3_f32 (relu and the clamp in one), v_cvt_pk_f16_f32, v_pk_add_f32 -- 4 vector
-// instructions per value where the scalar formulation compiles to 7.
+// power of two: relu(fma(acc, inv, bias)) s == relu(fma(acc, inv s, bias s)) bit for bit in the normal range).  Written on
+// register pairs: v_med3_f32 is the relu and the clamp in one, v_cvt_pk_f16_f32 converts two values per instruction; the pair-wise
+// fma / subtract compile to two scalar instructions each, not to v_pk_fma_f32 / v_pk_add_f32 -- the library is built without packed
+// fp32 arithmetic (iffnerf_amd/build.py, fan_common.h; tests/test_isa_rules.py holds the line).
 __device__ __forceinline__ void relu_split_quad(float a0, float a1, float a2, float a3, f32x2 is, f32x2 bs01, f32x2 bs23, f16x4& hi, f16x4& lo) {
     f32x2 t01 = __builtin_elementwise_fma(f32x2{a0, a1}, is, bs01);
     f32x2 t23 = __builtin_elementwise_fma(f32x2{a2, a3}, is, bs23);
@@ -251,8 +252,9 @@ struct __attribute__((packed, aligned(4))) f4uh { float x, y, z, w; };     // 16
 // column = one token) -> logits (acc qs + rc) / divisor into `dst_row` (= logits + token N), and the tile's softmax partial
 // (max, sum exp) of that token over the rays < N.  (acc qs + rc) / divisor is correctly rounded (qs is a power of two, so acc qs is
 // exact): quotient estimate by the reciprocal, exact remainder, one correction.  Tiles that lie wholly inside N (all but the last)
-// take the packed form: v_pk_fma_f32 / v_pk_mul_f32 on register pairs, no per-ray bound checks; the values, the maximum and the
-// ORDER of the sum are those of the masked form, so a row's statistics do not depend on which form served a tile.
+// take the pair-wise form (register pairs, no per-ray bound checks; scalar fma / mul under the library's no-packed-fp32 build); the
+// values, the maximum and the ORDER of the sum are those of the masked form, so a row's statistics do not depend on which form
+// served a tile.
 template <int RG>
 __device__ __forceinline__ float2 logits_tile_epilogue(f32x16 (&acc)[RG], float qs, float rc, float divisor, float inv_div, bool tok_ok,
                                               float* __restrict__ dst_row, int64_t row0, int64_t N, int lh) {
