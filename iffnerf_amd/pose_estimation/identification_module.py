@@ -62,6 +62,7 @@ class RaySession:
         self.n_rays = self.ori.shape[0]
         self.cache = self.net.build_ray_cache(self.ori, self.dirs, rays_rgb)
         self.graphs = {}
+        self.logits_budget = 0           # bytes of logits per captured batch, fixed when the first graphs are made
 
     def serves(self, module, rays_ori, rays_dir, rays_rgb) -> bool:
         same = all(r() is t and t._version == v for r, t, v in zip(self._refs, (rays_ori, rays_dir, rays_rgb), self._versions))

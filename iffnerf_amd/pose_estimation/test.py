@@ -31,7 +31,10 @@ INERF_ITERS = 800      # reference test.py:204
 INERF_BATCH = 1024     # pose_estimation's default batch_size (inerf/estimate_pose_inerf.py:31), which test.py:196-209 leaves alone
 EVAL_BATCH = 32        # images per batch of the batched route (one captured hipGraph per full batch)
 EVAL_SLOTS = 2         # captured batches in flight, each on its own stream (the chip is full at two: bench.py, image -> pose)
-LOGITS_BUDGET_BYTES = 4 << 30     # a batch's [B * 256, N] fp32 logits stay below this (540 000 rays: 7 images per batch)
+LOGITS_BUDGET_BYTES = 9 << 30     # a batch's [B * 256, N] fp32 logits stay below this (540 000 rays: 17 images per batch; measured
+#                                   images/s at 7 / 17 / 32 per batch: 1 660 / 1 830 / 1 830, scripts/time_dropin_540k.py) and below
+#                                   an eighth of the HBM that is free when the graphs are made (two slots, each a graph pool + its
+#                                   warm-up's blocks: at most half of it)
 TOPK = 100             # rays_to_output of reference :90
 
 
@@ -128,7 +131,9 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
     device = rays_ori.device
     n, H_, W_, C_ = dataset.all_rgbs.shape
     session = id_module.ray_session(rays_ori, rays_dirs, rays_rgb)
-    B = max(1, min(EVAL_BATCH, LOGITS_BUDGET_BYTES // (256 * 4 * max(session.n_rays, 1))))
+    budget = min(LOGITS_BUDGET_BYTES, torch.cuda.mem_get_info(device)[0] // 8) if not session.graphs else session.logits_budget
+    session.logits_budget = budget                      # (the batch size of graphs that exist stands: their memory is no longer "free")
+    B = max(1, min(EVAL_BATCH, budget // (256 * 4 * max(session.n_rays, 1))))
     up = tuple(float(v) for v in torch.as_tensor(model_up).detach().cpu().reshape(-1).tolist())
     out = [None] * n
 
