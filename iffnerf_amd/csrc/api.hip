@@ -827,8 +827,8 @@ extern "C" int iff_logits_from_cache(const iff_idnet* n, const void* cache, int6
     float* qscale = (float*)((char*)part + up256a(n_blk64 * n_tb * 256 * 8));
     IFF_HIP(launch_trunk_h_logits_cached(n->dev, cache, N, qf, M, divisor, logits, Qf, qscale, part, (hipStream_t)stream));
     if (row_max) {
-        const int rpw = trunk_h_rays_per_wg(n->dev.trunk_variant);
-        IFF_HIP(launch_merge_stats(part, (int)((N + rpw - 1) / rpw), (int)(n_tb * 256), M, 1, row_max, row_sumexp, (hipStream_t)stream));
+        // (the partials are per 64-ray block whatever tile the launch used)
+        IFF_HIP(launch_merge_stats(part, (int)n_blk64, (int)(n_tb * 256), M, 1, row_max, row_sumexp, (hipStream_t)stream));
     }
     return 0;
 }

@@ -1155,8 +1155,7 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
         return hipSuccess;
     }
     const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
-    const int rays_per_wg = n.trunk_f16 ? trunk_h_rays_per_wg(n.trunk_variant) : TR;
-    const int64_t n_blk = (N + rays_per_wg - 1) / rays_per_wg;
+    const int64_t n_blk = (N + TR - 1) / TR;             // softmax partials per token: one per 64-ray block in every form of the launch
     if (B > 65535) return hipErrorInvalidValue;
     char* base = (char*)ws;
     __bf16* Qf = (__bf16*)base;

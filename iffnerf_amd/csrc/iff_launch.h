@@ -106,6 +106,7 @@ hipError_t launch_frag_order(const void* Wp, void* Wf, int Kp, hipStream_t s);
 // trunk_f16_kernels.hip
 hipError_t launch_frag_order_h(const float* W, int ld, int col0, int ncols, int nks, float scale, void* Wf, hipStream_t s);
 int trunk_h_rays_per_wg(int variant);
+int trunk_h_cached_variant(int variant);
 hipError_t launch_trunk_h_features(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, int B, float* h3,
                                    hipStream_t s);
 hipError_t launch_trunk_h_cache(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, void* planes,

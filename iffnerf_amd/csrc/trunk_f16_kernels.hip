@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
             a.qscale += qb * (size_t)a.Mpad;
             a.rowc += qb * (size_t)a.M * a.rowc_ld;
             a.logits += qb * (size_t)a.M * N;
-            a.part += qb * (size_t)gridDim.x * a.Mpad;
+            a.part += qb * (size_t)((N + 63) / 64) * a.Mpad;       // partials are per 64-RAY BLOCK whatever the tile (below)
         } else if (MODE == 0) {
             a.h3 += qb * N * HC;
         }
@@ -568,8 +568,18 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
                 const bool tok_ok = tok < a.M;
                 const float rc = tok_ok ? a.rowc[(size_t)tok * a.rowc_ld] : 0.0f;
                 const float qs = a.qscale[tok];
-                const float2 st = logits_tile_epilogue<RG>(acc[tg], qs, rc, divisor, inv_div, tok_ok, a.logits + (size_t)tok * N, row0, N, lh);
-                if (lh == 0) a.part[(size_t)blockIdx.x * a.Mpad + tok] = st;
+                // one softmax partial per 64-RAY BLOCK, computed as the 64-ray tile computes it: a 128-ray tile (RG = 4) leaves two,
+                // so the merged row statistics -- and with them every score -- do not depend on the tile a launch was given
+                static_assert(RG % 2 == 0, "tiles are whole 64-ray blocks");
+#pragma unroll
+                for (int hb = 0; hb < RG / 2; ++hb) {
+                    const int64_t r0 = row0 + 64 * hb;
+                    if (r0 < N) {                                     // (wave-uniform; only the last tile of a ray set can lack its second block)
+                        const float2 st = logits_tile_epilogue<2>(*reinterpret_cast<f32x16 (*)[2]>(&acc[tg][2 * hb]), qs, rc, divisor, inv_div, tok_ok,
+                                                                  a.logits + (size_t)tok * N, r0, N, lh);
+                        if (lh == 0) a.part[((size_t)blockIdx.x * (RG / 2) + hb) * a.Mpad + tok] = st;
+                    }
+                }
             }
         }
 #ifdef TRUNK_STAMPS
@@ -777,6 +787,12 @@ __global__ void __launch_bounds__(1024, 4) k5_trunk_h2(TrunkHArgs a, int64_t n_t
 //          2 -> 8 waves x 32 features, 128 rays (half the weight stream per ray);
 //          3 -> the logits launches as k5_trunk_h2: sixteen waves, two 64-ray tiles one stage apart (the work split of 0 per tile)
 int trunk_h_rays_per_wg(int variant) { return variant == 2 ? 128 : 64; }
+// The logits launch against CACHED encoder planes (MODE 3) has no encoder to feed: what a workgroup streams is the query planes,
+// 256 KB per 256-token block whatever its rays, so twice the rays per workgroup halve that stream per logit -- variant 2 unless the
+// handle names a form of its own (1: four waves, 3: two tiles a stage apart).  Measured (scripts/time_warm.py, same box):
+// 32 queries x 16 011 rays 67 000 -> 72 600 poses/s, 8 x 540 000 rays 2 460 -> 2 680; the fused launch (MODE 1) keeps 64 rays,
+// where the second accumulator set of the encoder makes 128 rays the slower form.  The results are the same bits either way.
+int trunk_h_cached_variant(int variant) { return variant == 0 ? 2 : variant; }
 
 // workgroups per ray tile for the token blocks of a logits launch: enough that tiles x ray sets x split fills the chip's
 // workgroup slots about twice (2 per CU), never more than the blocks there are; `recompute`: every split workgroup of the
@@ -867,7 +883,8 @@ hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, i
     a.planes = (_Float16*)const_cast<void*>(planes);
     a.Qf = (const uint4*)Qf; a.qscale = qscale; a.rowc = qf + HC; a.rowc_ld = n.qf_ld; a.M = M; a.divisor = divisor;
     a.logits = logits; a.part = part; a.Mpad = Mpad;
-    const int TR = trunk_h_rays_per_wg(n.trunk_variant);
+    const int variant = trunk_h_cached_variant(n.trunk_variant);
+    const int TR = trunk_h_rays_per_wg(variant);
     const int64_t tiles = (N + TR - 1) / TR;
-    return launch_variant<3>(n.trunk_variant, dim3((unsigned)tiles, 1u, token_split(tiles, 1, n_tb, false)), a, s);
+    return launch_variant<3>(variant, dim3((unsigned)tiles, 1u, token_split(tiles, 1, n_tb, false)), a, s);
 }

@@ -269,11 +269,12 @@ typedef struct iff_idnet_desc {
     int32_t fea;                    /* 384 */
     int32_t img_fea;                /* 398 = 384 + 14 */
     int32_t gemm_mode;              /* IFF_GEMM_* */
-    int32_t trunk_variant;          /* work split of the fused F16X2 launch: 0 = choose; 1 = 8 waves x 64 rays per workgroup,
-                                       2 = 4 waves x 64 rays (two workgroups per CU), 3 = 8 waves x 128 rays, 4 = two half-
-                                       workgroups of 4 waves one stage apart (matrix-core and vector stages side by side).
-                                       Logits are the same bits in every form; the softmax partials of form 4 are merged in
-                                       another order (row statistics equal to fp32 rounding). */
+    int32_t trunk_variant;          /* work split of the F16X2 logits launches: 0 = choose (the fused launch: form 1; the launch
+                                       against cached encoder planes, iff_logits_from_cache: form 3, which halves the query-plane
+                                       stream per logit); 1 = 8 waves x 64 rays per workgroup (cached planes: as 0), 2 = 4 waves
+                                       x 64 rays, 3 = 8 waves x 128 rays, 4 = sixteen waves on two 64-ray tiles one stage apart
+                                       (matrix-core and vector stages side by side).  Logits, softmax statistics and scores are
+                                       the same bits in every form: the partials are per 64-ray block whatever the tile. */
     const float* l1_w; const float* l1_b;   /* ray_preprocessor.mlp.0   [feature_c,141] */
     const float* l2_w; const float* l2_b;   /* ray_preprocessor.mlp.2   [feature_c,feature_c] */
     const float* l3_w; const float* l3_b;   /* ray_preprocessor.mlp2.0  [feature_c,feature_c+141] */

@@ -1,5 +1,5 @@
 """Warm path (rays resident, encoder cached): Q query images per captured graph (QS=16,32,64), 4 graphs in flight -> poses/s, on
-the workload CONFIG (lego16k).  Dev aid."""
+the workload CONFIG (lego16k); TRUNK_VARIANT=1..4 names the work split of the logits launch.  Dev aid."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,8 @@ from iffnerf_amd.pipeline import PosePipeline
 dev = torch.device("cuda:0")
 CFG = os.environ.get("CONFIG", "lego16k")
 wl = synthetic.WORKLOADS[CFG]
-pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(CFG), synthetic.make_id_weights(seed=99), dev)
+pipe = PosePipeline.from_checkpoints(synthetic.make_workload_ckpt(CFG), synthetic.make_id_weights(seed=99), dev,
+                                     trunk_variant=int(os.environ.get("TRUNK_VARIANT", "0")))      # iff_idnet_desc.trunk_variant (1..4)
 ori, dirs, rgb = pipe.emit(wl["gen_points"], seed=42)
 resident = pipe.make_resident(ori, dirs, rgb)
 for Q in [int(x) for x in os.environ.get("QS", "16,32,64").split(",")]:
@@ -30,4 +31,4 @@ for Q in [int(x) for x in os.environ.get("QS", "16,32,64").split(",")]:
     run(8); torch.cuda.synchronize()
     n = 60
     t0 = time.perf_counter(); run(n); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"queries_per_graph": Q, "warm_poses_per_s": round(n * Q / dt, 1), "ms_per_graph": round(dt / n * 1e3, 4)}), flush=True)
+    print(json.dumps({"config": CFG, "trunk_variant": int(os.environ.get("TRUNK_VARIANT", "0")), "queries_per_graph": Q, "warm_poses_per_s": round(n * Q / dt, 1), "ms_per_graph": round(dt / n * 1e3, 4)}), flush=True)

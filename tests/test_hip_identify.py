@@ -443,19 +443,20 @@ def test_token_side_products_agree_across_row_counts(net, dev):
 
 
 def test_two_tile_trunk_form_is_bit_identical(dev):
-    """iff_idnet_desc.trunk_variant = 4 (k5_trunk_h2: sixteen waves, two 64-ray tiles one stage apart -- the matrix-core and the
-    vector stages of a CU side by side) against the default eight-wave form: logits, softmax row statistics and the cached-encoder
-    path are the same bits (an odd tile count and a ragged last tile included)."""
+    """Every iff_idnet_desc.trunk_variant (1: eight waves x 64 rays; 2: four waves; 3: 128-ray tiles; 4: k5_trunk_h2, sixteen waves on
+    two 64-ray tiles one stage apart) and both launches (fused; against cached encoder planes, which runs 128-ray tiles by default):
+    logits, softmax row statistics -- their partials are per 64-ray block whatever the tile -- are the same bits (odd tile counts,
+    a ragged last tile and a 128-ray tile without its second block included)."""
     from iffnerf_amd import hip_identify as H
     w = synthetic.make_id_weights(seed=99)
     g = torch.Generator().manual_seed(4)
-    for B, N, M in ((3, 64 * 5 + 17, 256), (1, 64 * 4, 137), (2, 1000, 300)):
+    for B, N, M in ((3, 64 * 5 + 17, 256), (1, 64 * 4, 137), (2, 1000, 300), (1, 64 * 4 + 10, 100)):
         o = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev)
         d = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1).to(dev)
         c = torch.rand(B, N, 3, generator=g).to(dev)
         tok = torch.stack([synthetic.make_tokens(M, 384, seed=20 + q) for q in range(B)]).to(dev)
         outs = []
-        for var in (1, 4):
+        for var in (1, 2, 3, 4):
             net = H.IdNetHandle(w, dev, gemm_mode=H.GEMM_F16X2, trunk_variant=var)
             qf = net.q_fold(tok.reshape(B * M, -1))
             fused = net.ray_logits_folded_batched(qf, o.reshape(-1, 3), d.reshape(-1, 3), c.reshape(-1, 3), B)
@@ -463,5 +464,6 @@ def test_two_tile_trunk_form_is_bit_identical(dev):
             outs.append((fused, cached))
             for x, y in zip(cached, net.ray_logits_folded(qf[:M], o[0], d[0], c[0])):
                 assert torch.equal(x, y)
-        for x, y in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
-            assert torch.equal(x, y), (B, N, M)
+        for other in outs[1:]:                  # every work split: logits AND row statistics, the same bits (partials per 64-ray block)
+            for x, y in zip(outs[0][0] + outs[0][1], other[0] + other[1]):
+                assert torch.equal(x, y), (B, N, M)
