@@ -207,7 +207,7 @@ class _QuietStdout:
         sys.stdout = self._saved
 
 
-def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=False):
+def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=False, object_mask=False):
     """The reference's own call path (train_eval_pose_est.py:131-149), through the module names `iffnerf_amd.install()` registers:
 
         rays_ori, rays_dirs, rays_rgb = explore_model(nerf_model, gen_points)
@@ -216,7 +216,10 @@ def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=Fal
     on a duck-typed dataset of `n_images` synthetic hw x hw RGBA queries (`all_rgbs` resident in HBM; `host_dataset`: in host
     memory, every batch crossing PCIe inside the timed call).  DINOv2's published weights are not available offline: the hub
     loader is pointed at the seeded stand-in with DINOv2 ViT-S/14's module tree (`create_backbone("dino")` itself runs unchanged
-    and serves it through iff_vit_forward).  -> poses/s of the second call (the first also captures the graphs) + parts."""
+    and serves it through iff_vit_forward).  -> poses/s of the second call (the first also captures the graphs) + parts.
+    `object_mask`: the alpha channel is a disc over a third of the image (an object on a transparent background, as the lego renders
+    are) instead of noise that keeps every token: the reference deletes the tokens off the object before the attention
+    (identification_module.py:157-160) and the loop stops at their count (iff_token_assemble_compact)."""
     import tempfile
     import torch
     import iffnerf_amd
@@ -243,7 +246,11 @@ def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=Fal
     gen = torch.Generator().manual_seed(17)
     ds = Dataset()
     rgba = torch.rand(n_images, hw, hw, 4, generator=gen)
-    rgba[..., 3] = (rgba[..., 3] > 0.2).float()
+    if object_mask:
+        yy, xx = torch.meshgrid(torch.arange(hw, dtype=torch.float32), torch.arange(hw, dtype=torch.float32), indexing="ij")
+        rgba[..., 3] = (((yy - hw / 2) ** 2 + (xx - hw / 2) ** 2) <= (0.33 * hw) ** 2).float()
+    else:
+        rgba[..., 3] = (rgba[..., 3] > 0.2).float()
     ds.all_rgbs = rgba if host_dataset else rgba.to(device)
     ds.K = torch.eye(3)[None]
     ds.all_rays = torch.zeros(n_images, 1, 6)
@@ -266,7 +273,8 @@ def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=Fal
         torch.cuda.synchronize(device)
         t_second = time.perf_counter() - t0
     assert len(res[0]) == n_images and all(len(r["pred_c2w"]) == 4 for r in res[0])
-    return {"poses_per_s": round(n_images / t_second, 2), "images": n_images, "rays": int(rays[0].shape[0]),
+    kept = idm.static_tokens(ds.all_rgbs[:8].to(device), None, compact=True)[2].float().mean().item()
+    return {"poses_per_s": round(n_images / t_second, 2), "images": n_images, "rays": int(rays[0].shape[0]), "tokens_kept_per_image": round(kept, 1),
             "explore_model_ms": round(t_explore * 1e3, 3), "first_call_ms": round(t_first * 1e3, 2),
             "dataset": "host memory (PCIe inside the timed call)" if host_dataset else "resident in HBM"}
 
@@ -471,12 +479,17 @@ def main():
             if args.config == "lego16k":
                 dr["host_dataset"] = dropin_rates(ck, idw, device, gen_points, 64, host_dataset=True)
                 dr["reference_default_540k_rays"] = dropin_rates(ck, idw, device, 20000, 68)
+                dr["object_mask"] = dropin_rates(ck, idw, device, gen_points, n_img, object_mask=True)
+                dr["reference_default_540k_rays_object_mask"] = dropin_rates(ck, idw, device, 20000, 68, object_mask=True)
             dr["note"] = ("iffnerf_amd.install(); explore_model(model, gen_points) once, then test_pose_estimation(dataset, id_module, rays_ori, "
                           "rays_dirs, rays_rgb, model_up) as train_eval_pose_est.py:131-149 calls it, on synthetic 800x800 RGBA queries: images per "
                           "second of the SECOND call (the first also builds the encoder cache and captures the batch graphs: first_call_ms).  "
                           "Batches of 32 images (540 000 rays: 17) as captured hipGraphs on two alternating streams, one device->host read per "
                           "batch; results bit-identical to the image-by-image route (tests/test_hip_eval_loop.py).  Backbone: DINOv2 ViT-S/14's "
-                          "architecture with seeded stand-in weights through iff_vit_forward in the fp32 class")
+                          "architecture with seeded stand-in weights through iff_vit_forward in the fp32 class.  *_object_mask: the same calls on images "
+                          "whose alpha is a disc over a third of the image instead of noise that keeps all 256 tokens: about half the tokens are "
+                          "off the object, the reference deletes them before the attention (identification_module.py:157-160) and the loop "
+                          "stops at their count on the device (iff_token_assemble_compact, iff_logits_from_cache_rows, iff_attn_colsum_rows)")
             result["dropin"] = dr
             result["dropin_poses_per_s"] = dr["this_workload"]["poses_per_s"]
     if sharded:

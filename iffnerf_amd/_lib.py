@@ -21,7 +21,7 @@ PRODUCT_LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
 LIB_PATH = os.environ.get("IFF_LIB_PATH") or PRODUCT_LIB_PATH
 DEV_LIBRARY = os.path.abspath(LIB_PATH) != os.path.abspath(PRODUCT_LIB_PATH)
 _lib = None
-ABI_VERSION = 10         # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 11         # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -124,17 +124,20 @@ SIGNATURES = {
     "iff_image_resize_crop": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, c_float_p, c_float_p, _VP, _VP]),
     "iff_image_resize_crop_rgba": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, c_float_p, c_float_p, _VP, _VP]),
     "iff_token_assemble": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _F, c_float_p, c_float_p, _VP, _VP, _VP]),
+    "iff_token_assemble_compact": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _F, c_float_p, c_float_p, _VP, _VP, _VP, _VP]),
     "iff_mask_token_rows": (C.c_int, [_VP, _I64, _VP, _VP, _VP]),
     "iff_ray_cache_bytes": (_SZ, [_VP, _I64]),
     "iff_ray_cache_workspace": (_SZ, [_VP, _I64]),
     "iff_ray_cache_build": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _SZ, _VP, _SZ, _VP]),
     "iff_logits_from_cache_workspace": (_SZ, [_VP, _I64, _I32]),
     "iff_logits_from_cache": (C.c_int, [_VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "iff_logits_from_cache_rows": (C.c_int, [_VP, _VP, _I64, _VP, _I32, _VP, _F, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "iff_attn_colsum": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
     "iff_topk_workspace": (_SZ, [_I64, _I32]),
     "iff_topk": (C.c_int, [_VP, _I64, _I32, _VP, _VP, _VP, _SZ, _VP]),
     "iff_pose_from_topk": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _I64, c_float_p, _VP, _VP, _VP]),
     "iff_attn_colsum_batched": (C.c_int, [_VP, _I32, _I32, _I64, _VP, _VP, _I32, _VP, _VP]),
+    "iff_attn_colsum_rows": (C.c_int, [_VP, _I32, _I32, _I64, _VP, _VP, _VP, _I32, _VP, _VP]),
     "iff_topk_batched": (C.c_int, [_VP, _I32, _I64, _I32, _VP, _VP, _VP]),
     "iff_pose_from_topk_batched": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _I64, _I64, c_float_p, _VP, _VP, _VP]),
     "iff_pose_errors": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _VP]),

@@ -768,6 +768,16 @@ extern "C" int iff_token_assemble(const float* patch_tokens, int32_t Q, int32_t 
                                   (hipStream_t)stream));
     return 0;
 }
+extern "C" int iff_token_assemble_compact(const float* patch_tokens, int32_t Q, int32_t gh, int32_t gw, int32_t C, const float* mask_grid_opt,
+                                          float mask_thres, const float* lin_h_host, const float* lin_w_host, float* tokens_out,
+                                          uint8_t* keep_out, int32_t* rows_out, void* stream) {
+    IFF_REQUIRE(Q >= 0 && gh >= 1 && gh <= 32 && gw >= 1 && gw <= 32 && C >= 1, "iff_token_assemble_compact: bad shape Q=%d grid=%dx%d C=%d", Q, gh, gw, C);
+    if (Q == 0) return 0;
+    IFF_REQUIRE(patch_tokens && lin_h_host && lin_w_host && tokens_out && keep_out && rows_out, "iff_token_assemble_compact: null buffer");
+    IFF_HIP(launch_token_assemble_compact(patch_tokens, Q, gh, gw, C, mask_grid_opt, mask_thres, lin_h_host, lin_w_host, tokens_out, keep_out,
+                                          rows_out, (hipStream_t)stream));
+    return 0;
+}
 extern "C" int iff_mask_token_rows(const uint8_t* keep, int64_t rows, float* row_max, float* row_sumexp, void* stream) {
     IFF_REQUIRE(rows >= 0, "iff_mask_token_rows: bad argument");
     if (rows == 0) return 0;
@@ -806,14 +816,15 @@ extern "C" size_t iff_logits_from_cache_workspace(const iff_idnet* n, int64_t N,
     const size_t n_tb = (size_t)(M + 255) / 256, n_blk = (size_t)(N + 63) / 64;
     return up256a(n_tb * (n->dev.feature_c / 16) * 2 * 8 * 64 * 16) + up256a(n_blk * n_tb * 256 * 8) + up256a(n_tb * 256 * 4) + 256;
 }
-extern "C" int iff_logits_from_cache(const iff_idnet* n, const void* cache, int64_t N, const float* qf, int32_t M, float divisor,
-                                     float* logits, float* row_max, float* row_sumexp, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+static int logits_from_cache(const iff_idnet* n, const void* cache, int64_t N, const float* qf, int32_t M, const int32_t* rows, float divisor,
+                             float* logits, float* row_max, float* row_sumexp, void* workspace, size_t workspace_bytes, void* stream) {
     IFF_REQUIRE(n && N >= 0 && M >= 0, "iff_logits_from_cache: bad argument");
     if (N == 0 || M == 0) return 0;
     IFF_REQUIRE(cache && qf && logits, "iff_logits_from_cache: null buffer");
     IFF_REQUIRE((row_max == nullptr) == (row_sumexp == nullptr), "iff_logits_from_cache: pass both row statistics or neither");
     if (!n->dev.trunk_f16) {
+        // (the other arithmetic modes compute every row; the rows behind a block's count then hold ordinary logits and statistics,
+        // which a caller that stops at the counts never reads)
         IFF_HIP(launch_attn_logits_folded(qf, n->dev.qf_ld, (const float*)cache, M, N, n->dev.feature_c, divisor, logits, row_max,
                                           row_sumexp, (hipStream_t)stream));
         return 0;
@@ -825,12 +836,23 @@ extern "C" int iff_logits_from_cache(const iff_idnet* n, const void* cache, int6
     void* Qf = base;
     float2* part = (float2*)(base + up256a(n_tb * (n->dev.feature_c / 16) * 2 * 8 * 64 * 16));
     float* qscale = (float*)((char*)part + up256a(n_blk64 * n_tb * 256 * 8));
-    IFF_HIP(launch_trunk_h_logits_cached(n->dev, cache, N, qf, M, divisor, logits, Qf, qscale, part, (hipStream_t)stream));
+    IFF_HIP(launch_trunk_h_logits_cached(n->dev, cache, N, qf, M, divisor, logits, Qf, qscale, part, rows, (hipStream_t)stream));
     if (row_max) {
         // (the partials are per 64-ray block whatever tile the launch used)
-        IFF_HIP(launch_merge_stats(part, (int)n_blk64, (int)(n_tb * 256), M, 1, row_max, row_sumexp, (hipStream_t)stream));
+        IFF_HIP(launch_merge_stats(part, (int)n_blk64, (int)(n_tb * 256), M, 1, row_max, row_sumexp, rows, (hipStream_t)stream));
     }
     return 0;
+}
+extern "C" int iff_logits_from_cache(const iff_idnet* n, const void* cache, int64_t N, const float* qf, int32_t M, float divisor,
+                                     float* logits, float* row_max, float* row_sumexp, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    return logits_from_cache(n, cache, N, qf, M, nullptr, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes, stream);
+}
+extern "C" int iff_logits_from_cache_rows(const iff_idnet* n, const void* cache, int64_t N, const float* qf, int32_t M,
+                                          const int32_t* rows_per_block, float divisor, float* logits, float* row_max, float* row_sumexp,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    IFF_REQUIRE(rows_per_block, "iff_logits_from_cache_rows: null row counts (iff_logits_from_cache is the call without them)");
+    return logits_from_cache(n, cache, N, qf, M, rows_per_block, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes, stream);
 }
 
 extern "C" int iff_k_proj(const iff_idnet* n, const float* ray_features, int64_t N, float* k_out, void* stream) {
@@ -872,7 +894,7 @@ extern "C" int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const 
     IFF_REQUIRE(M >= 1 && M <= 8064 && N >= 0, "iff_attn_colsum: bad shape (1 <= M <= 8064: the row statistics live in 64 KiB of LDS)");
     if (N == 0) return 0;
     IFF_REQUIRE(logits_inout && row_max && row_sumexp && score, "iff_attn_colsum: null buffer");
-    IFF_HIP(launch_attn_colsum(logits_inout, 1, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));
+    IFF_HIP(launch_attn_colsum(logits_inout, 1, M, N, row_max, row_sumexp, write_attention, score, nullptr, (hipStream_t)stream));
     return 0;
 }
 
@@ -881,7 +903,15 @@ extern "C" int iff_attn_colsum_batched(float* logits_inout, int32_t Q, int32_t M
     IFF_REQUIRE(Q >= 0 && Q <= 65535 && M >= 1 && M <= 8064 && N >= 0, "iff_attn_colsum_batched: bad shape (1 <= M <= 8064)");
     if (N == 0 || Q == 0) return 0;
     IFF_REQUIRE(logits_inout && row_max && row_sumexp && score, "iff_attn_colsum_batched: null buffer");
-    IFF_HIP(launch_attn_colsum(logits_inout, Q, M, N, row_max, row_sumexp, write_attention, score, (hipStream_t)stream));
+    IFF_HIP(launch_attn_colsum(logits_inout, Q, M, N, row_max, row_sumexp, write_attention, score, nullptr, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int iff_attn_colsum_rows(float* logits_inout, int32_t Q, int32_t M, int64_t N, const float* row_max, const float* row_sumexp,
+                                    const int32_t* rows_per_query, int32_t write_attention, float* score, void* stream) {
+    IFF_REQUIRE(Q >= 0 && Q <= 65535 && M >= 1 && M <= 8064 && N >= 0, "iff_attn_colsum_rows: bad shape (1 <= M <= 8064)");
+    if (N == 0 || Q == 0) return 0;
+    IFF_REQUIRE(logits_inout && row_max && row_sumexp && score && rows_per_query, "iff_attn_colsum_rows: null buffer");
+    IFF_HIP(launch_attn_colsum(logits_inout, Q, M, N, row_max, row_sumexp, write_attention, score, rows_per_query, (hipStream_t)stream));
     return 0;
 }
 

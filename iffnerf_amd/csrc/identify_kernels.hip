@@ -519,12 +519,18 @@ __global__ void k_qf_frag(const float* __restrict__ qf, int ld, int M, __bf16* _
 
 // per-token softmax statistics from the per-workgroup partials of k5_trunk<true>: part [n_blk][Mpad][2] = (max, sum exp)
 // over each workgroup's 64 rays -> row_max [M], row_sumexp [M]; one wave per token, fixed merge order
+// `rows` (optional): kept rows per 256-token block (iff_logits_from_cache_rows): the logits launch skipped the rows behind them and left
+// no partials; their statistics become (+inf, 1), the pair k_mask_token_rows gives a dropped row.
 __global__ void __launch_bounds__(256) k6_merge_stats(const float2* __restrict__ part, int n_blk, int Mpad, int M,
-                                                      float* __restrict__ row_max, float* __restrict__ row_sumexp) {
+                                                      float* __restrict__ row_max, float* __restrict__ row_sumexp, const int* __restrict__ rows) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= M) return;
     part += (size_t)blockIdx.y * n_blk * Mpad; row_max += (size_t)blockIdx.y * M; row_sumexp += (size_t)blockIdx.y * M;
+    if (rows && (t & 255) >= rows[t >> 8]) {
+        if (lane == 0) { row_max[t] = INFINITY; row_sumexp[t] = 1.0f; }
+        return;
+    }
     float m = -INFINITY, sacc = 0.0f;
     for (int b = lane; b < n_blk; b += 64) {
         float2 p = part[(size_t)b * Mpad + t];
@@ -808,8 +814,9 @@ __global__ void __launch_bounds__(FG == 2 ? 256 : 512) k5_trunk(const float* __r
     }
 }
 
-hipError_t launch_merge_stats(const float2* part, int n_blk, int Mpad, int M, int B, float* row_max, float* row_sumexp, hipStream_t s) {
-    hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4), (unsigned)B), dim3(256), 0, s, part, n_blk, Mpad, M, row_max, row_sumexp);
+hipError_t launch_merge_stats(const float2* part, int n_blk, int Mpad, int M, int B, float* row_max, float* row_sumexp, const int* rows,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4), (unsigned)B), dim3(256), 0, s, part, n_blk, Mpad, M, row_max, row_sumexp, rows);
     return hipGetLastError();
 }
 
@@ -1193,7 +1200,7 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
     if (e != hipSuccess) return e;
     if (row_max && row_sumexp) {
         hipLaunchKernelGGL(k6_merge_stats, dim3((unsigned)((M + 3) / 4), (unsigned)B), dim3(256), 0, s, part, (int)n_blk, Mpad, M, row_max,
-                           row_sumexp);
+                           row_sumexp, (const int*)nullptr);
         e = hipGetLastError();
     }
     return e;
@@ -1202,9 +1209,10 @@ hipError_t launch_ray_logits_folded(const IdNetDev& n, const float* o, const flo
 // attention_ij = exp(l_ij - max_i) / sumexp_i ; score_j = sum_i attention_ij.  A 256-thread workgroup owns 64 ray columns;
 // wave g sums the rows of its quarter of the token rows in order, the 4 partial sums are added in fixed order
 // (deterministic).  Each wave-instruction reads one 256-B row segment.
-__global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int M, int64_t N, const float* __restrict__ row_max,
+// `rows` (optional): rows of query q that count (kept rows first: iff_token_assemble_compact); the others are neither read nor written.
+__global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int M_all, int64_t N, const float* __restrict__ row_max,
                                                  const float* __restrict__ row_sumexp, int write_attention,
-                                                 float* __restrict__ score) {
+                                                 float* __restrict__ score, const int* __restrict__ rows) {
     // 256 ray columns per workgroup, 64 per wave, every wave over ALL token rows: the four waves read four adjacent 256-B
     // pieces of the same rows (1 KiB of a row per workgroup at a time -- the logits stream from HBM, and a row is N floats
     // long); a lane keeps four partial sums (rows i mod 4) and adds them pairwise at the end.
@@ -1217,8 +1225,9 @@ __global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int
         // two launches back to back: 111 -> 93 us (score + top-k + pose stage 0.175 -> 0.157 ms).  Which workgroup sums which
         // columns does not touch the sums.
         const int64_t qb = gridDim.y - 1 - blockIdx.y;
-        logits += qb * M * N; row_max += qb * M; row_sumexp += qb * M; score += qb * N;
+        logits += qb * M_all * N; row_max += qb * M_all; row_sumexp += qb * M_all; score += qb * N;
     }
+    const int M = rows ? min(M_all, max(rows[gridDim.y - 1 - blockIdx.y], 0)) : M_all;
     // scores only (no attention map asked for): exp through the hardware exponential and the row's reciprocal sum instead of
     // expf and a division per element -- 2e-7 relative per term, far inside the 5e-5 the logits themselves carry; the kernel
     // was bound by those ~25 extra vector instructions per logit, not by the 262 MB it streams
@@ -1263,10 +1272,10 @@ __global__ void __launch_bounds__(256) k6_colsum(float* __restrict__ logits, int
 }
 
 hipError_t launch_attn_colsum(float* logits, int Q, int M, int64_t N, const float* row_max, const float* row_sumexp,
-                              int write_attention, float* score, hipStream_t s) {
+                              int write_attention, float* score, const int* rows, hipStream_t s) {
     if (N == 0 || Q == 0) return hipSuccess;
     hipLaunchKernelGGL(k6_colsum, dim3((unsigned)((N + 255) / 256), (unsigned)Q), dim3(256), 2 * (size_t)M * sizeof(float), s, logits,
-                       M, N, row_max, row_sumexp, write_attention, score);
+                       M, N, row_max, row_sumexp, write_attention, score, rows);
     return hipGetLastError();
 }
 
@@ -1411,6 +1420,61 @@ hipError_t launch_token_assemble(const float* tok, int Q, int gh, int gw, int C,
     int64_t grid = (n + 255) / 256;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_token_assemble, dim3((unsigned)grid), dim3(256), 0, s, tok, Q, gh, gw, C, mask, thres, lt, out, keep);
+    return hipGetLastError();
+}
+
+// The same rows, KEPT ROWS FIRST: one workgroup per image partitions its G rows stably (kept rows in grid order, then the dropped
+// ones in grid order) and reports how many it kept.  identification_module.py:157-160 deletes the dropped rows before the attention,
+// so its work per image follows the kept count; with the kept rows in front the logits launch and the column pass can stop at
+// rows_out[q] (iff_logits_from_cache_rows, iff_attn_colsum_rows) -- the same saving without a host sync or a changing shape.
+// The values are k_token_assemble's, element for element; keep_out becomes 1 ... 1 0 ... 0.
+__global__ void __launch_bounds__(256) k_token_assemble_compact(const float* __restrict__ tok, int gh, int gw, int C, const float* __restrict__ mask,
+                                                                float thres, LinTab lt, float* __restrict__ out, uint8_t* __restrict__ keep,
+                                                                int* __restrict__ rows_out) {
+    __shared__ int s_dest[1024];                    // destination row of grid cell g
+    __shared__ int s_count[256 + 1];
+    const int G = gh * gw, CO = C + 14, tid = threadIdx.x, q = blockIdx.x;
+    const int per = (G + 255) / 256;                // cells per thread, consecutive: a thread's cells keep their order
+    const int g0 = tid * per, g1 = min(G, g0 + per);
+    int mine = 0;
+    for (int g = g0; g < g1; ++g) mine += (!mask || mask[(int64_t)q * G + g] > thres) ? 1 : 0;
+    s_count[tid + 1] = mine;
+    if (tid == 0) s_count[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int i = 1; i <= 256; ++i) s_count[i] += s_count[i - 1];          // 256 adds: not worth a scan
+    __syncthreads();
+    const int n_keep = s_count[256];
+    int k = s_count[tid], d = n_keep + (g0 - s_count[tid]);                           // next kept / dropped destination of this thread
+    for (int g = g0; g < g1; ++g) {
+        const bool kp = !mask || mask[(int64_t)q * G + g] > thres;
+        s_dest[g] = kp ? k++ : d++;
+    }
+    __syncthreads();
+    if (tid == 0) rows_out[q] = n_keep;
+    for (int g = tid; g < G; g += 256) keep[(int64_t)q * G + s_dest[g]] = s_dest[g] < n_keep ? 1 : 0;
+    const int64_t n = (int64_t)G * CO;
+    for (int64_t t = tid; t < n; t += 256) {
+        const int col = (int)(t % CO), cell = (int)(t / CO), i = cell / gw, j = cell - i * gw;
+        float v;
+        if (col < C) v = tok[((int64_t)q * G + cell) * C + col];
+        else {
+            const int c = col - C;
+            const float pi = lt.h[i], pj = lt.w[j];
+            if (c < 2) v = c == 0 ? pi : pj;
+            else {
+                const int u = (c - 2) % 6;                              // (axis, octave) = (u / 3, u % 3)
+                const float ang = (u < 3 ? pi : pj) * (float)(1 << (u % 3));
+                v = (c - 2) < 6 ? sinf(ang) : cosf(ang);
+            }
+        }
+        out[((int64_t)q * G + s_dest[cell]) * CO + col] = v;
+    }
+}
+hipError_t launch_token_assemble_compact(const float* tok, int Q, int gh, int gw, int C, const float* mask, float thres, const float* lin_h,
+                                         const float* lin_w, float* out, uint8_t* keep, int* rows_out, hipStream_t s) {
+    LinTab lt;
+    for (int i = 0; i < 32; ++i) { lt.h[i] = i < gh ? lin_h[i] : 0.0f; lt.w[i] = i < gw ? lin_w[i] : 0.0f; }
+    hipLaunchKernelGGL(k_token_assemble_compact, dim3((unsigned)Q), dim3(256), 0, s, tok, gh, gw, C, mask, thres, lt, out, keep, rows_out);
     return hipGetLastError();
 }
 

@@ -112,15 +112,18 @@ hipError_t launch_trunk_h_features(const IdNetDev& n, const float* o, const floa
 hipError_t launch_trunk_h_cache(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, void* planes,
                                 hipStream_t s);
 hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, int64_t N, const float* qf, int M, float divisor,
-                                        float* logits, void* Qf, float* qscale, float2* part, hipStream_t s);
-hipError_t launch_merge_stats(const float2* part, int n_blk, int Mpad, int M, int B, float* row_max, float* row_sumexp, hipStream_t s);
+                                        float* logits, void* Qf, float* qscale, float2* part, const int* rows, hipStream_t s);
+hipError_t launch_merge_stats(const float2* part, int n_blk, int Mpad, int M, int B, float* row_max, float* row_sumexp, const int* rows,
+                              hipStream_t s);
 hipError_t launch_trunk_h_logits(const IdNetDev& n, const float* o, const float* d, const float* rgb, int64_t N, const float* qf, int M,
                                  int B, float divisor, float* logits, void* Qf, float* qscale, float2* part, hipStream_t s);
 hipError_t launch_split_rows(const float* w, void* planes, int out_f, int in_f, int in_pad, hipStream_t s);
 hipError_t launch_attn_colsum(float* logits, int Q, int M, int64_t N, const float* row_max, const float* row_sumexp,
-                              int write_attention, float* score, hipStream_t s);
+                              int write_attention, float* score, const int* rows, hipStream_t s);
 hipError_t launch_token_assemble(const float* tok, int Q, int gh, int gw, int C, const float* mask, float thres, const float* lin_h,
                                  const float* lin_w, float* out, uint8_t* keep, hipStream_t s);
+hipError_t launch_token_assemble_compact(const float* tok, int Q, int gh, int gw, int C, const float* mask, float thres, const float* lin_h,
+                                         const float* lin_w, float* out, uint8_t* keep, int* rows_out, hipStream_t s);
 hipError_t launch_mask_token_rows(const uint8_t* keep, int64_t rows, float* row_max, float* row_sumexp, hipStream_t s);
 size_t topk_workspace_bytes(int64_t N, int k);
 hipError_t launch_topk(const float* score, int Q, int64_t N, int k, int64_t* idx, float* val, void* ws, size_t ws_bytes,

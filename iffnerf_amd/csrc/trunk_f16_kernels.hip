@@ -199,6 +199,7 @@ struct TrunkHArgs {
     _Float16* planes;         // MODE 2 (out) / MODE 3 (in): the h3 hi/lo planes [2][N][256], times s3 -- the per-model cache
     const uint4* Qf; const float* qscale; const float* rowc; int rowc_ld; int M; float divisor;
     float* logits; float2* part; int Mpad;
+    const int* rows;          // MODE 3, optional: kept token rows per 256-token block (kept rows first); the rows behind them are skipped
 };
 
 template <int FG> struct WFragH { f16x8 p[FG][2]; };      // [feature group][hi, lo]
@@ -557,6 +558,9 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
         const int tb0 = (int)blockIdx.z * tb_per, tb1 = min(n_tb, tb0 + tb_per);
         const float divisor = a.divisor, inv_div = 1.0f / divisor;
         for (int tb = tb0; tb < tb1; ++tb) {
+            // a token block whose kept rows end before this wave's 32 tokens: nothing to multiply, nothing to store (the statistics
+            // merge gives those rows the pair of a dropped row, the column pass stops at the count).  No barrier inside this loop.
+            if (MODE == 3 && a.rows && 32 * FG * __builtin_amdgcn_readfirstlane(wave) >= a.rows[tb]) continue;
             zero(acc);
             phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_LOGITS>{}, no_t{}, yes_t{}, acc,
                   a.Qf + (size_t)tb * (KH * 2 * 8 * 64), acc, a.Qf);
@@ -819,7 +823,7 @@ static TrunkHArgs base_args(const IdNetDev& n, const float* o, const float* d, c
     a.inv2 = ldexpf(1.0f, -(n.e_w2 + n.e_h1)); a.s2 = ldexpf(1.0f, n.e_h2);
     a.inv3 = ldexpf(1.0f, -(n.e_w3h + n.e_h2)); a.s3 = ldexpf(1.0f, n.e_h3);
     a.h3 = nullptr; a.planes = nullptr; a.Qf = nullptr; a.qscale = nullptr; a.rowc = nullptr; a.rowc_ld = 0; a.M = 0; a.divisor = 1.0f;
-    a.logits = nullptr; a.part = nullptr; a.Mpad = 0;
+    a.logits = nullptr; a.part = nullptr; a.Mpad = 0; a.rows = nullptr;
     return a;
 }
 
@@ -874,7 +878,7 @@ hipError_t launch_trunk_h_cache(const IdNetDev& n, const float* o, const float* 
 }
 
 hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, int64_t N, const float* qf, int M, float divisor,
-                                        float* logits, void* Qf, float* qscale, float2* part, hipStream_t s) {
+                                        float* logits, void* Qf, float* qscale, float2* part, const int* rows, hipStream_t s) {
     const int n_tb = (M + 255) / 256, Mpad = n_tb * 256;
     hipLaunchKernelGGL(k_qf_frag_h, dim3((unsigned)(Mpad / 32), 1u), dim3(256), 0, s, qf, n.qf_ld, M, n_tb, n.e_h3, (_Float16*)Qf, qscale);
     hipError_t e = hipGetLastError();
@@ -883,7 +887,9 @@ hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, i
     a.planes = (_Float16*)const_cast<void*>(planes);
     a.Qf = (const uint4*)Qf; a.qscale = qscale; a.rowc = qf + HC; a.rowc_ld = n.qf_ld; a.M = M; a.divisor = divisor;
     a.logits = logits; a.part = part; a.Mpad = Mpad;
-    const int variant = trunk_h_cached_variant(n.trunk_variant);
+    int variant = trunk_h_cached_variant(n.trunk_variant);
+    if (rows && variant == 3) variant = 2;            // the two-tile form keeps barriers inside its token loop: row counts go to the 128-ray form
+    a.rows = rows;
     const int TR = trunk_h_rays_per_wg(variant);
     const int64_t tiles = (N + TR - 1) / TR;
     return launch_variant<3>(variant, dim3((unsigned)tiles, 1u, token_split(tiles, 1, n_tb, false)), a, s);

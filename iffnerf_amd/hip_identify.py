@@ -242,8 +242,10 @@ class IdNetHandle:
                                         stream_ptr(self.device)), "iff_ray_cache_build")
         return cache
 
-    def logits_from_cache(self, qf, cache: torch.Tensor, n_rays: int, want_stats: bool = True):
-        """Folded token rows qf [M, width] x cached rays -> (logits [M,N], row_max, row_sumexp): no encoder work."""
+    def logits_from_cache(self, qf, cache: torch.Tensor, n_rays: int, want_stats: bool = True, rows: Optional[torch.Tensor] = None):
+        """Folded token rows qf [M, width] x cached rays -> (logits [M,N], row_max, row_sumexp): no encoder work.
+        ``rows`` (int32 [M / 256], device): kept rows per 256-row block, which come first (``iff_token_assemble_compact``): the rows
+        behind them are skipped (``iff_logits_from_cache_rows``) -- their logits are whatever the buffer held."""
         qf = _gpu(qf, "qf")
         M, N = qf.shape[0], int(n_rays)
         L = _lib.lib()
@@ -253,9 +255,16 @@ class IdNetHandle:
         ws_bytes = int(L.iff_logits_from_cache_workspace(self._h, N, M))
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=qf.device)
         with torch.cuda.device(self.device):
-            check(L.iff_logits_from_cache(self._h, cache.data_ptr(), N, dptr(qf), M, float(math.sqrt(self.fea)), dptr(logits),
-                                          dptr(rmax), dptr(rsum), ws.data_ptr(), ws_bytes, stream_ptr(self.device)),
-                  "iff_logits_from_cache")
+            if rows is None:
+                check(L.iff_logits_from_cache(self._h, cache.data_ptr(), N, dptr(qf), M, float(math.sqrt(self.fea)), dptr(logits),
+                                              dptr(rmax), dptr(rsum), ws.data_ptr(), ws_bytes, stream_ptr(self.device)),
+                      "iff_logits_from_cache")
+            else:
+                if M % 256 or rows.dtype != torch.int32 or rows.numel() != M // 256 or rows.device != qf.device or not rows.is_contiguous():
+                    raise RuntimeError(f"rows must be a contiguous int32 tensor of {M} / 256 counts on {qf.device} (M a multiple of 256)")
+                check(L.iff_logits_from_cache_rows(self._h, cache.data_ptr(), N, dptr(qf), M, rows.data_ptr(), float(math.sqrt(self.fea)),
+                                                   dptr(logits), dptr(rmax), dptr(rsum), ws.data_ptr(), ws_bytes, stream_ptr(self.device)),
+                      "iff_logits_from_cache_rows")
         return logits, rmax, rsum
 
     def k_proj(self, ray_features):
@@ -336,16 +345,24 @@ def pose_from_topk(idx, val, rays_o, rays_d, model_up, want_parts: bool = False)
 
 # ---------------------------------------------------------------------------------------------- batches of queries
 def attn_colsum_batched(logits: torch.Tensor, row_max: torch.Tensor, row_sumexp: torch.Tensor, Q: int,
-                        write_attention: bool = True):
-    """logits [Q*M, N] (Q queries of M token rows each), statistics [Q*M] -> score [Q, N]; attention in place if asked."""
+                        write_attention: bool = True, rows: Optional[torch.Tensor] = None):
+    """logits [Q*M, N] (Q queries of M token rows each), statistics [Q*M] -> score [Q, N]; attention in place if asked.
+    ``rows`` (int32 [Q], device): only the first rows[q] rows of query q count (``iff_attn_colsum_rows``)."""
     QM, N = logits.shape
     if Q < 1 or QM % Q:
         raise RuntimeError(f"logits rows ({QM}) must be a multiple of the number of queries ({Q})")
     score = logits.new_empty(Q, N)
     with torch.cuda.device(logits.device):
-        check(_lib.lib().iff_attn_colsum_batched(dptr(logits), Q, QM // Q, N, dptr(row_max), dptr(row_sumexp),
-                                                 int(write_attention), dptr(score), stream_ptr(logits.device)),
-              "iff_attn_colsum_batched")
+        if rows is None:
+            check(_lib.lib().iff_attn_colsum_batched(dptr(logits), Q, QM // Q, N, dptr(row_max), dptr(row_sumexp),
+                                                     int(write_attention), dptr(score), stream_ptr(logits.device)),
+                  "iff_attn_colsum_batched")
+        else:
+            if rows.dtype != torch.int32 or rows.numel() != Q or rows.device != logits.device or not rows.is_contiguous():
+                raise RuntimeError(f"rows must be a contiguous int32 tensor of {Q} counts on {logits.device}")
+            check(_lib.lib().iff_attn_colsum_rows(dptr(logits), Q, QM // Q, N, dptr(row_max), dptr(row_sumexp), rows.data_ptr(),
+                                                  int(write_attention), dptr(score), stream_ptr(logits.device)),
+                  "iff_attn_colsum_rows")
     return score
 
 

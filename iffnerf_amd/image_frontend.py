@@ -25,8 +25,9 @@ from ._lib import check, dptr, fvec, stream_ptr
 from .pose_estimation.identification_module import IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, _center_crop, _resize_short_edge
 
 
-def token_assemble(patch_tokens: torch.Tensor, grid, mask_grid: Optional[torch.Tensor] = None, mask_thres: float = 0.1):
-    """patch_tokens [Q, gh*gw, C] (+ mask_grid [Q, gh*gw]) -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw] uint8)."""
+def token_assemble(patch_tokens: torch.Tensor, grid, mask_grid: Optional[torch.Tensor] = None, mask_thres: float = 0.1, compact: bool = False):
+    """patch_tokens [Q, gh*gw, C] (+ mask_grid [Q, gh*gw]) -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw] uint8).
+    ``compact``: every image's kept rows first, in grid order (``iff_token_assemble_compact``) -> (tokens, keep, rows [Q] int32)."""
     gh, gw = int(grid[0]), int(grid[1])
     if not patch_tokens.is_cuda:
         raise RuntimeError("patch tokens must live on the GPU; libiffnerf_hip has no CPU path")
@@ -42,6 +43,11 @@ def token_assemble(patch_tokens: torch.Tensor, grid, mask_grid: Optional[torch.T
     lin_h = fvec(torch.linspace(-1.0, 1.0, steps=gh, dtype=torch.float32).tolist())
     lin_w = fvec(torch.linspace(-1.0, 1.0, steps=gw, dtype=torch.float32).tolist())
     with torch.cuda.device(t.device):
+        if compact:
+            rows = torch.empty(Q, dtype=torch.int32, device=t.device)
+            check(_lib.lib().iff_token_assemble_compact(dptr(t), Q, gh, gw, Cc, dptr(m), float(mask_thres), lin_h, lin_w, dptr(out),
+                                                        keep.data_ptr(), rows.data_ptr(), stream_ptr(t.device)), "iff_token_assemble_compact")
+            return out, keep, rows
         check(_lib.lib().iff_token_assemble(dptr(t), Q, gh, gw, Cc, dptr(m), float(mask_thres), lin_h, lin_w, dptr(out),
                                             keep.data_ptr(), stream_ptr(t.device)), "iff_token_assemble")
     return out, keep
@@ -138,7 +144,7 @@ class ImageFrontEnd:
         return self._norm[key]
 
     @torch.no_grad()
-    def tokens(self, imgs: torch.Tensor, masks: Optional[torch.Tensor] = None):
+    def tokens(self, imgs: torch.Tensor, masks: Optional[torch.Tensor] = None, compact: bool = False):
         """imgs [Q,H,W,3] in [0,1], masks [Q,H,W] (alpha) -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw]).
         The same arithmetic as identification_module.py:130-160 (``transformations`` / ``mask_transformations`` of the mirror)."""
         if self.native_preprocess:
@@ -161,14 +167,14 @@ class ImageFrontEnd:
             else:
                 m = _center_crop(_resize_short_edge(masks[:, None] * 1.0, self.resize_size, "bilinear"), self.crop_size)
                 mg = _resize_short_edge(m, self.grid[0], "bilinear").reshape(masks.shape[0], -1)
-        return token_assemble(feats, self.grid, mg, 0.1)
+        return token_assemble(feats, self.grid, mg, 0.1, compact=compact)
 
     @torch.no_grad()
-    def tokens_rgba(self, rgba: torch.Tensor):
+    def tokens_rgba(self, rgba: torch.Tensor, compact: bool = False):
         """RGBA query images [Q,H,W,4] as the evaluation loop holds them (pose_estimation/test.py:75-81) -> (tokens, keep): the
         composite on white and the alpha mask are taken inside the two resize launches.  Equals ``tokens(rgb * a + (1 - a), a)``
         bit for bit."""
-        return self.tokens_from_preprocessed(*self.preprocess(rgba))
+        return self.tokens_from_preprocessed(*self.preprocess(rgba), compact=compact)
 
     # The two halves of ``tokens_rgba`` / ``tokens(imgs, None)``, for a caller that keeps the second half in a captured graph: the
     # first half is the only part that reads the full-size images, so run eagerly it takes them WHERE THEY LIE (a slice of the
@@ -187,8 +193,8 @@ class ImageFrontEnd:
         return resize_crop(imgs, self.resize_size, self.crop_size, True, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, out=o_x), None
 
     @torch.no_grad()
-    def tokens_from_preprocessed(self, xin: torch.Tensor, alpha: Optional[torch.Tensor]):
-        """(xin, alpha) of ``preprocess`` -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw])."""
+    def tokens_from_preprocessed(self, xin: torch.Tensor, alpha: Optional[torch.Tensor], compact: bool = False):
+        """(xin, alpha) of ``preprocess`` -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw]) (+ rows [Q] with ``compact``: ``token_assemble``)."""
         if self.backbone_autocast is None:
             feats = self.backbone.forward_features(xin)["x_norm_patchtokens"]
         else:
@@ -197,4 +203,4 @@ class ImageFrontEnd:
         mg = None
         if alpha is not None:
             mg = resize_crop(alpha.permute(0, 2, 3, 1), self.grid[0], None, False).reshape(xin.shape[0], -1)
-        return token_assemble(feats, self.grid, mg, 0.1)
+        return token_assemble(feats, self.grid, mg, 0.1, compact=compact)

@@ -268,21 +268,22 @@ class IdentificationModule(torch.nn.Module):
             self._frontend = ImageFrontEnd(self.image_preprocessing_net, self.backbone_wh, self.resize_size, self.crop_size)
         return self._frontend
 
-    def static_tokens(self, imgs, masks):
+    def static_tokens(self, imgs, masks, compact: bool = False):
         """imgs [Q,H,W,3] (or RGBA [Q,H,W,4] with ``masks`` None: composited on white, alpha as the mask -- pose_estimation/test.py:75-81),
-        masks [Q,H,W] -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw] uint8): reference :130-160 without the row compaction (no
-        boolean index, no host sync; ``scores_static`` applies ``keep`` to the softmax rows)."""
+        masks [Q,H,W] -> (tokens [Q, gh*gw, C+14], keep [Q, gh*gw] uint8): reference :130-160 with static shapes (no boolean index, no
+        host sync).  ``compact``: every image's kept rows first, in the reference's order, + rows [Q] (their count on the device):
+        ``scores_static`` then stops at the count where the reference has deleted the rows (:157-160)."""
         from ..image_frontend import token_assemble
         if imgs.shape[-1] == 4 and masks is None:
             if not self.custom_preprocessing():
-                return self.frontend().tokens_rgba(imgs)
+                return self.frontend().tokens_rgba(imgs, compact=compact)
             imgs, masks = imgs[..., :3] * imgs[..., -1:] + (1 - imgs[..., -1:]), imgs[..., -1]
         if not self.custom_preprocessing():
-            return self.frontend().tokens(imgs, masks)
+            return self.frontend().tokens(imgs, masks, compact=compact)
         norm = self.transformations(imgs.permute(0, 3, 1, 2))
         feats = self.image_preprocessing_net.forward_features(norm)["x_norm_patchtokens"]
         mg = None if masks is None else self.mask_transformations(masks[:, None] * 1.0).reshape(masks.shape[0], -1)
-        return token_assemble(feats, self.backbone_wh, mg, 0.1)
+        return token_assemble(feats, self.backbone_wh, mg, 0.1, compact=compact)
 
     def ray_session(self, rays_ori, rays_dir, rays_rgb) -> RaySession:
         """The session of this ray set: reused while the caller passes the same (unmodified) tensors and the weights stand."""
@@ -292,22 +293,34 @@ class IdentificationModule(torch.nn.Module):
             s = self._ray_session = RaySession(self, rays_ori, rays_dir, rays_rgb)
         return s
 
-    def scores_static(self, tokens, keep, session: RaySession, want_map: bool = True):
+    def scores_static(self, tokens, keep, session: RaySession, want_map: bool = True, rows=None):
         """tokens [Q,G,C+14], keep [Q,G] -> (score [Q,N], one LazyAttentionMap per image or None): identification_module.py:164-167
-        with the encoder taken from the session's cache and the mask select applied to the softmax rows."""
+        with the encoder taken from the session's cache.  The mask select of :157-160: with ``rows`` (kept rows first, their count per
+        image on the device: ``static_tokens(compact=True)``) the logits launch and the column pass stop at the count -- the work per
+        image follows the kept rows, as the reference's does; without it (or for a token grid that is not one 256-row block per image)
+        every row is computed and the dropped ones are given statistics under which they add exactly 0."""
         from .. import hip_identify as H
         from ..image_frontend import mask_token_rows
         net = session.net
         Q, G, C = tokens.shape
         qf = net.q_fold(tokens.reshape(Q * G, C))
-        logits, rmax, rsum = net.logits_from_cache(qf, session.cache, session.n_rays)
-        mask_token_rows(keep, rmax, rsum)
-        score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
+        bounded = rows is not None and G == 256
+        if bounded:
+            logits, rmax, rsum = net.logits_from_cache(qf, session.cache, session.n_rays, rows=rows)
+            score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False, rows=rows)
+        else:
+            logits, rmax, rsum = net.logits_from_cache(qf, session.cache, session.n_rays)
+            mask_token_rows(keep, rmax, rsum)
+            score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
         if not want_map:
             return score, None
 
         def thunk(q):
             def make():
+                if bounded:
+                    lg, mx, sm = net.logits_from_cache(qf[q * G:(q + 1) * G], session.cache, session.n_rays, rows=rows[q:q + 1])
+                    H.attn_colsum_batched(lg, mx, sm, 1, write_attention=True, rows=rows[q:q + 1])
+                    return lg[:int(rows[q])]                      # the kept rows, in the reference's order (the one host read of the map)
                 lg, mx, sm = net.logits_from_cache(qf[q * G:(q + 1) * G], session.cache, session.n_rays)
                 mask_token_rows(keep[q], mx, sm)
                 H.attn_colsum(lg, mx, sm, write_attention=True)
@@ -323,7 +336,7 @@ class IdentificationModule(torch.nn.Module):
             indices, values = H.topk(scores, rays_to_output)
             return indices, values, scores, attention_map
         session = self.ray_session(rays_ori, rays_dir, rays_rgb)
-        tokens, keep = self.static_tokens(img[None], mask[None])
-        score, maps = self.scores_static(tokens, keep, session)
+        tokens, keep, rows = self.static_tokens(img[None], mask[None], compact=True)
+        score, maps = self.scores_static(tokens, keep, session, rows=rows)
         indices, values = H.topk(score[0], rays_to_output)
         return indices, values, score[0], maps[0]

@@ -54,9 +54,9 @@ def _record(sequence_id, img_idx, summary_row, c2w_rows, gt_rows):
             "pred_c2w": c2w_rows, "gt_c2w": gt_rows}
 
 
-def _eval_from_tokens(id_module, session, tokens, keep, gt_poses, model_up, k):
+def _eval_from_tokens(id_module, session, tokens, keep, rows, gt_poses, model_up, k):
     from .. import hip_identify as H
-    score, _ = id_module.scores_static(tokens, keep, session, want_map=False)
+    score, _ = id_module.scores_static(tokens, keep, session, want_map=False, rows=rows)
     idx, val = H.topk_batched(score, k)
     c2w, parts = H.pose_from_topk_batched(idx, val, session.ori, session.dirs, model_up, want_parts=True)
     return c2w, H.pose_errors(c2w, gt_poses, parts)
@@ -65,8 +65,8 @@ def _eval_from_tokens(id_module, session, tokens, keep, gt_poses, model_up, k):
 def eval_batch(id_module, session, images, gt_poses, model_up, k=TOPK):
     """images [B,H,W,4] (RGBA) or [B,H,W,3], gt_poses [B,4,4] -> (c2w [B,4,4], summary [B,4]) on the device, nothing read back.
     The body of reference :71-232 for B images: the launches of ``IdentificationModule.test_image`` + pose solve + error metrics."""
-    tokens, keep = id_module.static_tokens(images, None)
-    return _eval_from_tokens(id_module, session, tokens, keep, gt_poses, model_up, k)
+    tokens, keep, rows = id_module.static_tokens(images, None, compact=True)
+    return _eval_from_tokens(id_module, session, tokens, keep, rows, gt_poses, model_up, k)
 
 
 class CapturedEvalBatch:
@@ -102,8 +102,8 @@ class CapturedEvalBatch:
         self.pending = None
 
     def _tail(self, id_module, session, model_up, k):
-        tokens, keep = self.fe.tokens_from_preprocessed(self.xin, self.alpha)
-        return _eval_from_tokens(id_module, session, tokens, keep, self.gt, model_up, k)
+        tokens, keep, rows = self.fe.tokens_from_preprocessed(self.xin, self.alpha, compact=True)
+        return _eval_from_tokens(id_module, session, tokens, keep, rows, self.gt, model_up, k)
 
     def submit(self, images, gt, tag):
         with torch.cuda.stream(self.stream):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IFF_ABI_VERSION 10
+#define IFF_ABI_VERSION 11
 
 #define IFF_ERR_INVALID_ARGUMENT 1001
 #define IFF_ERR_UNSUPPORTED      1002
@@ -429,6 +429,14 @@ int iff_image_resize_crop_rgba(const float* src, int32_t Q, int32_t H, int32_t W
 int iff_token_assemble(const float* patch_tokens, int32_t Q, int32_t gh, int32_t gw, int32_t C, const float* mask_grid_opt,
                        float mask_thres, const float* lin_h_host, const float* lin_w_host, float* tokens_out, uint8_t* keep_out,
                        void* stream);
+/* iff_token_assemble with the KEPT ROWS FIRST: every image's rows are partitioned stably (kept rows in grid order, then the dropped
+ * ones) and rows_out[q] = how many it kept; keep_out becomes 1 ... 1 0 ... 0.  identification_module.py:157-160 deletes the dropped rows
+ * before the attention (:164-167), so the reference's work per image follows the kept count; with the kept rows in front
+ * iff_logits_from_cache_rows and iff_attn_colsum_rows stop at rows_out[q] -- the same saving with static shapes and no host read --
+ * and the first rows_out[q] rows of an image's logits ARE the reference's attention-map rows, in its order. */
+int iff_token_assemble_compact(const float* patch_tokens, int32_t Q, int32_t gh, int32_t gw, int32_t C, const float* mask_grid_opt,
+                               float mask_thres, const float* lin_h_host, const float* lin_w_host, float* tokens_out, uint8_t* keep_out,
+                               int32_t* rows_out, void* stream);
 /* keep [rows] (iff_token_assemble), statistics [rows]: rows with keep == 0 get (row_max, row_sumexp) = (+inf, 1)
  * (the mask select of pose_estimation/identification_module.py:157-160 applied to the softmax rows of :165-167) */
 int iff_mask_token_rows(const uint8_t* keep, int64_t rows, float* row_max, float* row_sumexp, void* stream);
@@ -449,6 +457,14 @@ size_t iff_logits_from_cache_workspace(const iff_idnet* net, int64_t N, int32_t 
 int iff_logits_from_cache(const iff_idnet* net, const void* cache, int64_t N, const float* qf, int32_t M, float divisor,
                           float* logits, float* row_max, float* row_sumexp, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* iff_logits_from_cache for token rows laid out by iff_token_assemble_compact: rows_per_block[b] (device, M / 256 entries, M a multiple
+ * of 256: one block per image of a 16 x 16 grid) = the kept rows of block b, which come first -- the rows the mask select of
+ * pose_estimation/identification_module.py:157-160 leaves for the attention of :164-167.  Under IFF_GEMM_F16X2 the rows behind
+ * them are neither multiplied nor written (their logits are left as they were) and their statistics become (+inf, 1); the other
+ * arithmetic modes compute every row.  Kept rows: the bits of iff_logits_from_cache.  Workspace: iff_logits_from_cache_workspace. */
+int iff_logits_from_cache_rows(const iff_idnet* net, const void* cache, int64_t N, const float* qf, int32_t M,
+                               const int32_t* rows_per_block, float divisor, float* logits, float* row_max, float* row_sumexp,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* scaled_attention_product (multihead_attention.py:4-12, mask=None), split so that ray shards on several
  * GPUs can exchange row statistics between the two halves:
@@ -464,6 +480,10 @@ int iff_attn_colsum(float* logits_inout, int32_t M, int64_t N, const float* row_
  * (the per-image loop of pose_estimation/test.py:67-91 around identification_module.py:167) */
 int iff_attn_colsum_batched(float* logits_inout, int32_t Q, int32_t M, int64_t N, const float* row_max,
                             const float* row_sumexp, int32_t write_attention, float* score, void* stream);
+/* iff_attn_colsum_batched over the first rows_per_query[q] (device) rows of every query only -- attention_map.sum(0) over the rows
+ * identification_module.py:157-160 keeps; the other rows are neither read nor written */
+int iff_attn_colsum_rows(float* logits_inout, int32_t Q, int32_t M, int64_t N, const float* row_max, const float* row_sumexp,
+                         const int32_t* rows_per_query, int32_t write_attention, float* score, void* stream);
 
 /* ---- the merge steps of the ray-sharded path (one process per GPU, rays sharded by surface point; the exchanges themselves are
  * RCCL all_gathers issued by the caller).  The reference is single-process; over G column shards these reproduce its ONE softmax

@@ -96,14 +96,18 @@ def test_batched_eval_loop_equals_image_by_image(dev, monkeypatch, capsys):
     sess = mod.ray_session(ro, rd, rc)
     imgs = ds.all_rgbs.to(dev)
     from iffnerf_amd import hip_identify as H
-    tokens, keep = mod.static_tokens(imgs, None)
-    score, _ = mod.scores_static(tokens, keep, sess, want_map=False)
+    tokens, keep, rows = mod.static_tokens(imgs, None, compact=True)           # kept rows first: what the loop and test_image run
+    score, _ = mod.scores_static(tokens, keep, sess, want_map=False, rows=rows)
     idx_b, val_b = H.topk_batched(score, 100)
     for q in range(6):
         obs = imgs[q]
         i1, v1, s1, _ = mod.test_image(obs[..., :3] * obs[..., -1:] + (1 - obs[..., -1:]), obs[..., -1], ro, rd, rc)
         assert torch.equal(i1, idx_b[q]) and torch.equal(v1, val_b[q]) and torch.equal(s1, score[q]), q
-    assert 30 < int(keep[0].sum()) < 256
+    assert 30 < int(keep[0].sum()) == int(rows[0]) < 256
+    # the route without the compaction (every row computed, dropped rows masked on the statistics) sums the same terms in another order
+    tokens_p, keep_p = mod.static_tokens(imgs, None)
+    score_p, _ = mod.scores_static(tokens_p, keep_p, sess, want_map=False)
+    torch.testing.assert_close(score, score_p, atol=1e-9, rtol=2e-6)
 
 
 def test_attention_map_is_lazy_and_right(dev, monkeypatch):

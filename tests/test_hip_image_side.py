@@ -82,6 +82,63 @@ def test_mask_select_on_the_softmax_rows_equals_dropping_the_rows(dev):
         util.assert_topk_matches(idx.cpu(), score_ref, 100)
 
 
+def test_kept_rows_first_and_the_launches_stop_at_their_count(dev):
+    """iff_token_assemble_compact + iff_logits_from_cache_rows + iff_attn_colsum_rows: the static-shape route with the reference's
+    work per image.  The assembly is a STABLE partition of iff_token_assemble's rows (kept rows in grid order: the reference's
+    boolean index, identification_module.py:157-160); the kept rows' logits and statistics are the bits of the unbounded launch, the
+    dropped rows are not touched; the scores are those of the compacted token tensor, the top-100 and the attention-map rows too.
+    Edge cases: an image that keeps nothing, one that keeps everything, one with fewer kept rows than a wave's 32."""
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.image_frontend import mask_token_rows, token_assemble
+    from iffnerf_amd.pipeline import PosePipeline
+    w = synthetic.make_id_weights(seed=99)
+    pipe = PosePipeline.from_checkpoints(util.ckpt("small"), w, dev, model_up=(0.1, 0.2, 0.9))
+    ori, dirs, rgb = pipe.emit(75, seed=3)
+    rays = pipe.make_resident(ori, dirs, rgb)
+    N = ori.shape[0]
+    gen = torch.Generator().manual_seed(8)
+    Q = 6
+    patch = torch.randn(Q, 256, 384, generator=gen)
+    keep = torch.stack([_keep_pattern(q % 3) for q in range(Q)]).reshape(Q, 256)
+    keep[3] = False                                              # keeps nothing
+    keep[4] = True                                               # keeps everything
+    keep[5] = False; keep[5, [7, 100, 101, 255]] = True          # four rows: less than one wave's 32 tokens
+    mg = keep.float().to(dev)
+    plain, flags = token_assemble(patch.to(dev), (16, 16), mg, 0.1)
+    tok, flags_c, rows = token_assemble(patch.to(dev), (16, 16), mg, 0.1, compact=True)
+    assert rows.dtype == torch.int32 and rows.tolist() == keep.sum(1).tolist() == flags.sum(1).tolist()
+    for q in range(Q):
+        n = int(rows[q])
+        assert torch.equal(tok[q, :n], plain[q][flags[q].bool()]) and torch.equal(tok[q, n:], plain[q][~flags[q].bool()])
+        assert flags_c[q].tolist() == [1] * n + [0] * (256 - n)
+    # logits: kept rows = the unbounded launch's bits on the same (compacted) rows; dropped rows untouched; statistics (+inf, 1)
+    qf = pipe.idnet.q_fold(tok.reshape(Q * 256, 398))
+    full, fmax, fsum = pipe.idnet.logits_from_cache(qf, rays.cache, N)
+    got, gmax, gsum = pipe.idnet.logits_from_cache(qf, rays.cache, N, rows=rows)
+    for q in range(Q):
+        n, lo = int(rows[q]), 256 * q
+        assert torch.equal(got[lo:lo + n], full[lo:lo + n]) and torch.equal(gmax[lo:lo + n], fmax[lo:lo + n]) and torch.equal(gsum[lo:lo + n], fsum[lo:lo + n])
+        assert bool(torch.isinf(gmax[lo + n:lo + 256]).all()) and bool((gsum[lo + n:lo + 256] == 1).all())
+    # scores: the column pass over the kept rows only == every row with the dropped ones masked (another order of the same terms)
+    score = H.attn_colsum_batched(got, gmax, gsum, Q, write_attention=False, rows=rows)
+    mask_token_rows(flags_c, fmax, fsum)
+    want = H.attn_colsum_batched(full, fmax, fsum, Q, write_attention=False)
+    torch.testing.assert_close(score, want, atol=1e-9, rtol=2e-6)
+    assert bool((score[3] == 0).all())                           # nothing kept: nothing summed
+    for q in (0, 1, 2, 4, 5):
+        assert abs(float(score[q].sum()) - int(rows[q])) < 1e-2
+        util.assert_topk_matches(H.topk(score[q], 100)[0].cpu(), want[q].cpu(), 100)
+    # poisoned buffers: the bounded column pass must not read a dropped row (NaN there would reach every score)
+    poisoned = got.clone()
+    for q in range(Q):
+        poisoned[256 * q + int(rows[q]):256 * (q + 1)] = float("nan")
+    assert torch.equal(H.attn_colsum_batched(poisoned, gmax, gsum, Q, write_attention=False, rows=rows), score)
+    with pytest.raises(RuntimeError):
+        pipe.idnet.logits_from_cache(qf, rays.cache, N, rows=rows.long())
+    with pytest.raises(RuntimeError):
+        H.attn_colsum_batched(got, gmax, gsum, Q, write_attention=False, rows=rows[:3])
+
+
 def test_image_in_pose_out_capture(dev, monkeypatch):
     """ImageFrontEnd reproduces the mirrored module's image_processing (same torch ops + the assembly kernel), and the
     captured image -> pose graph equals the per-image drop-in calls (IdentificationModule.test_image + pose solve)."""

@@ -159,7 +159,10 @@ def test_rccl_rehearsal_keeps_the_single_graph_rate():
             json.dump(rates, fh, indent=1)
     except OSError:
         pass
-    assert rates["ratio"] >= 0.93, rates          # measured 0.97-1.01; the bar leaves room for a box that drifts between the runs
+    # measured 0.97-1.01 on a quiet box; two IDENTICAL runs of one form have been seen 7 % apart within the minute this test takes
+    # (15 076 and 14 067 poses/s, ratio 0.91 that time), so the bar is where a real cost of the host-side exchange would show
+    # (a serialised step is 0.5), not where the box's drift does
+    assert rates["ratio"] >= 0.85, rates
 
 
 def test_large_ray_sets_keep_the_invariants(dev):
