@@ -305,6 +305,45 @@ def test_resident_rays_encoder_cache(st, dev, idw):
     assert n_swapped <= 1
 
 
+def test_kept_token_rows_at_full_size(st, dev, idw):
+    """The mask select of identification_module.py:157-160 as the evaluation loop runs it (kept rows first + a count on the device:
+    iff_token_assemble_compact, iff_logits_from_cache_rows, iff_attn_colsum_rows) on the bench's ray sets, 3 images per call -- an
+    object-shaped mask, one that keeps 9 rows, one that keeps all 256 -- against the ORACLE's test_image on the compacted tokens
+    (which is what the reference hands to its attention): scores, top-100 list (near-tie rule), pose."""
+    from iffnerf_amd import hip_identify as H
+    from iffnerf_amd.image_frontend import token_assemble
+    from oracle import identify as oid, pose as opose
+    pipe = st.pipe
+    o, d, c = st.ori.cpu(), st.dirs.cpu(), st.rgb.cpu()
+    rays = pipe.make_resident(st.ori, st.dirs, st.rgb)
+    gen = torch.Generator().manual_seed(31)
+    patch = torch.stack([synthetic.make_tokens(256, 384, seed=500 + q)[:, :384] for q in range(3)])
+    yy, xx = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij")
+    keep = torch.stack([((yy - 7.5) ** 2 + (xx - 7.5) ** 2) <= 6.7 ** 2, (yy >= 13) & (xx < 3), torch.ones(16, 16, dtype=torch.bool)]).reshape(3, 256)
+    tok, flags, rows = token_assemble(patch.to(dev), (16, 16), keep.float().to(dev), 0.1, compact=True)
+    assert rows.tolist() == keep.sum(1).tolist() and rows.tolist()[1:] == [9, 256] and 120 < int(rows[0]) < 160
+    qf = pipe.idnet.q_fold(tok.reshape(3 * 256, -1))
+    logits, rmax, rsum = pipe.idnet.logits_from_cache(qf, rays.cache, st.ori.shape[0], rows=rows)
+    score = H.attn_colsum_batched(logits, rmax, rsum, 3, write_attention=False, rows=rows)
+    idx, val = H.topk_batched(score, 100)
+    c2w = H.pose_from_topk_batched(idx, val, st.ori, st.dirs, st.up)
+    swapped = 0
+    for q in range(3):
+        n = int(rows[q])
+        compact = tok[q, :n].cpu()
+        assert torch.equal(compact[:, :384], patch[q][keep[q]])                      # the reference's boolean index, in its order
+        i_ref, v_ref, s_ref, _ = oid.test_image(idw, compact, o, d, c, 100)
+        e = float(((score[q].cpu() - s_ref).abs() / s_ref.abs().clamp_min(1e-30))[s_ref > 1e-6 * s_ref.max()].max())
+        record(st.name, f"kept_rows_{n}_score_max_rel_err", e)
+        assert e <= 2e-4
+        swapped += util.assert_topk_matches(idx[q].cpu(), s_ref, 100, rel_tie=TIE_REL)
+        want = opose.pose_from_topk(i_ref, v_ref, o, d, torch.tensor(st.up))
+        if idx[q].cpu().tolist() == i_ref.tolist():
+            assert float((c2w[q, :3, 3].cpu() - want[:3, 3]).abs().max()) <= TOL_POSE_UNITS
+            assert _rotation_angle(c2w[q, :3, :3].cpu(), want[:3, :3]) <= TOL_POSE_RAD
+    record(st.name, "kept_rows_lists_with_a_near_tie_swap_of_3", swapped)
+
+
 def test_batch_of_64_queries_sharded_over_emulated_ranks(dev, idw):
     """BASELINE configs[3]: 64 query images against one emitted ray set whose surface points are sharded over the ranks
     (PosePipeline.query_sharded's three segments; the two all_gathers are emulated by stacking the per-rank messages, which is
