@@ -59,6 +59,14 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.iff_pack_candidates(None, None, None, None, 0, 3, 101, 100, 0, None, None) != 0          # kl > k
     assert L.iff_pack_candidates(None, None, None, None, 0, 0, 0, 100, 0, None, None) == 0            # no queries
     assert L.iff_merge_candidates(None, 100, 4, 0, 4, 100, None, None, None, None, None) != 0 and b"exceed" in L.iff_last_error()
+    # the kept-rows calls: shapes and null buffers are refused before a launch; the row counts are not optional
+    assert L.iff_token_assemble_compact(None, 2, 16, 16, 384, None, 0.1, None, None, None, None, None, None) != 0 and b"null" in L.iff_last_error()
+    assert L.iff_token_assemble_compact(None, 2, 33, 16, 384, None, 0.1, None, None, None, None, None, None) != 0 and b"bad shape" in L.iff_last_error()
+    assert L.iff_token_assemble_compact(None, 0, 16, 16, 384, None, 0.1, None, None, None, None, None, None) == 0
+    assert L.iff_logits_from_cache_rows(None, None, 10, None, 256, None, 1.0, None, None, None, None, 0, None) != 0 and b"row counts" in L.iff_last_error()
+    assert L.iff_attn_colsum_rows(None, 2, 256, 10, None, None, None, 0, None, None) != 0 and b"null" in L.iff_last_error()
+    assert L.iff_attn_colsum_rows(None, 2, 9000, 10, None, None, None, 0, None, None) != 0 and b"bad shape" in L.iff_last_error()
+    assert L.iff_attn_colsum_rows(None, 0, 256, 10, None, None, None, 0, None, None) == 0
     assert L.iff_merge_candidates(None, 8, 4, 2, 3, 100, None, None, None, None, None) != 0            # window past the message
     assert L.iff_merge_candidates(None, 8, 4, 0, 0, 100, None, None, None, None, None) == 0
     assert L.iff_mask_occupied(None, None, 3, None, None) != 0
