@@ -138,15 +138,20 @@ class PosePipeline:
 
     def identify_images_resident(self, frontend, imgs, masks, rays: "ResidentRays", k: int = 100):
         """Image in -> pose out against resident rays: imgs [Q,H,W,3], masks [Q,H,W] -> (c2w [Q,4,4], idx, val).  Static shapes
-        throughout (the mask select is applied to the softmax rows, image_frontend.py), so the whole call captures as ONE
-        hipGraph (CapturedImageQuery).  Equals ``IdentificationModule.test_image`` + the pose solve per image."""
+        throughout (the mask select of identification_module.py:157-160 as kept rows first + a count per image on the device,
+        image_frontend.py), so the whole call captures as ONE hipGraph (CapturedImageQuery).  The launches of
+        ``IdentificationModule.test_image`` + the pose solve per image."""
         from .image_frontend import mask_token_rows
-        tokens, keep = frontend.tokens(imgs, masks)
+        tokens, keep, rows = frontend.tokens(imgs, masks, compact=True)
         Q, M, C = tokens.shape
         qf = self.idnet.q_fold(tokens.reshape(Q * M, C))
-        logits, rmax, rsum = self.idnet.logits_from_cache(qf, rays.cache, rays.ori.shape[0])
-        mask_token_rows(keep, rmax, rsum)
-        score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
+        if M == 256:
+            logits, rmax, rsum = self.idnet.logits_from_cache(qf, rays.cache, rays.ori.shape[0], rows=rows)
+            score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False, rows=rows)
+        else:
+            logits, rmax, rsum = self.idnet.logits_from_cache(qf, rays.cache, rays.ori.shape[0])
+            mask_token_rows(keep, rmax, rsum)
+            score = H.attn_colsum_batched(logits, rmax, rsum, Q, write_attention=False)
         idx, val = H.topk_batched(score, k)
         return H.pose_from_topk_batched(idx, val, rays.ori, rays.dirs, self.model_up), idx, val
 
