@@ -23,6 +23,8 @@ if os.environ.get("SORT"):          # experiment: fans in a spatially coherent o
     for b in range(k):
         for ax in range(3):
             key |= ((q[:, ax] >> b) & 1) << (3 * b + ax)
+    if os.environ.get("SORT_PER_QUERY"):          # ... inside each query only (what a product could do: a query's rays stay together)
+        key = key + (torch.arange(samples.shape[0], device=samples.device) // P << 40)
     samples = samples[torch.argsort(key)]
 normals = pipe.field.point_normals(samples)
 ori, dirs, rays = isocell_emit(pipe.cells, samples, normals, want_rays6=True)
