@@ -542,10 +542,13 @@ def instrument(result, args, pipe, tokens, gen_points, B, shared, world_size, ra
         torch.cuda.synchronize(device)
         for name, a, b in zip(stage_ms, e[:-1], e[1:]):
             stage_ms[name] += a.elapsed_time(b) / n_rep
-        # the same march again through the instrumented entry point: per-launch durations from events on the launch
-        # stream, and the kernels' own (valid, shaded) sample counters for the algorithmic byte count
+        # the same march again through the instrumented entry point: per-launch durations from events on the launch stream, on
+        # the launch AS THE TIMED REGION ISSUES IT (no counters: rounds 3-4 timed the launch that also writes the per-ray sample
+        # counters, 8 % longer than the product's -- the gap to rocprofv3's duration the round-4 verdict asked about); then once
+        # more, untimed, for the kernels' own (valid, shaded) sample counters of the algorithmic byte count
         ms = []
-        counts = pipe.field.march(rays, 0, 20, want_alpha=False, want_counts=True, stage_ms=ms)[4].double().sum(0)
+        pipe.field.march(rays, 0, 20, want_alpha=False, stage_ms=ms)
+        counts = pipe.field.march(rays, 0, 20, want_alpha=False, want_counts=True)[4].double().sum(0)
         for i in range(3):
             march_launch_ms[i] += ms[i] / n_rep
         if shared:
