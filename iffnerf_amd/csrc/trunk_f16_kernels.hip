@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
 
     f32x16 acc[FG][RG], acc3[FG][RG];
     zero(acc); zero(acc3);
+    int wsel = wave;          // whose 32 FG weight rows (encoder: features; logits: tokens) this wave streams: the wave's own, except below
     constexpr int KX = (141 + 15) / 16, KH = HC / 16;
 
     // One k loop, software-pipelined in registers: the weight fragments of k-step ks + DEPTH - 1 are requested before
@@ -477,15 +478,15 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
 #pragma unroll
         for (int i = 0; i < DEPTH - 1; ++i) {
             if (i < NK) {
-                trunk_load_w_h(wa[i], WA, i, wave, lane);
-                if (DUAL) trunk_load_w_h(wb[i], WB, i, wave, lane);
+                trunk_load_w_h(wa[i], WA, i, wsel, lane);
+                if (DUAL) trunk_load_w_h(wb[i], WB, i, wsel, lane);
             }
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             if (ks + DEPTH - 1 < NK) {
-                trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wave, lane);
-                if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wave, lane);
+                trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wsel, lane);
+                if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wsel, lane);
             }
             if (AB == 2 && ks + 1 < NK) load_act(act[(ks + 1) & 1], ks + 1);
             __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them)
@@ -560,7 +561,14 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
         for (int tb = tb0; tb < tb1; ++tb) {
             // a token block whose kept rows end before this wave's 32 tokens: nothing to multiply, nothing to store (the statistics
             // merge gives those rows the pair of a dropped row, the column pass stops at the count).  No barrier inside this loop.
-            if (MODE == 3 && a.rows && 32 * FG * __builtin_amdgcn_readfirstlane(wave) >= a.rows[tb]) continue;
+            // With row counts the waves take the block's 32 FG-token groups in an order that ROTATES with the block: the kept groups
+            // are the first ones, and a workgroup's waves sit on the four SIMDs cyclically -- unrotated, 5 kept groups of 8 would
+            // leave SIMD 0 with two waves' products in every block and the others with one (no barrier separates the blocks, so
+            // rotated the SIMDs even out over the blocks a workgroup serves).  Which wave computes a group does not touch its bits.
+            if (MODE == 3 && a.rows) {
+                wsel = __builtin_amdgcn_readfirstlane((wave + tb) & (NWAVE - 1));
+                if (32 * FG * wsel >= a.rows[tb]) continue;
+            }
             zero(acc);
             phase(integral_constant<int, KH>{}, integral_constant<int, DEPTH_LOGITS>{}, no_t{}, yes_t{}, acc,
                   a.Qf + (size_t)tb * (KH * 2 * 8 * 64), acc, a.Qf);
@@ -568,7 +576,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
             // tile: rows = rays 32 rg + (reg & 3) + 8 (reg >> 2) + 4 lh, columns = tokens 256 tb + 32 FG wave + 32 tg + lr
 #pragma unroll
             for (int tg = 0; tg < FG; ++tg) {
-                const int tok = tb * 256 + 32 * FG * wave + 32 * tg + lr;
+                const int tok = tb * 256 + 32 * FG * wsel + 32 * tg + lr;
                 const bool tok_ok = tok < a.M;
                 const float rc = tok_ok ? a.rowc[(size_t)tok * a.rowc_ld] : 0.0f;
                 const float qs = a.qscale[tok];
