@@ -459,9 +459,11 @@ int iff_logits_from_cache(const iff_idnet* net, const void* cache, int64_t N, co
                           void* stream);
 /* iff_logits_from_cache for token rows laid out by iff_token_assemble_compact: rows_per_block[b] (device, M / 256 entries, M a multiple
  * of 256: one block per image of a 16 x 16 grid) = the kept rows of block b, which come first -- the rows the mask select of
- * pose_estimation/identification_module.py:157-160 leaves for the attention of :164-167.  Under IFF_GEMM_F16X2 the rows behind
- * them are neither multiplied nor written (their logits are left as they were) and their statistics become (+inf, 1); the other
- * arithmetic modes compute every row.  Kept rows: the bits of iff_logits_from_cache.  Workspace: iff_logits_from_cache_workspace. */
+ * pose_estimation/identification_module.py:157-160 leaves for the attention of :164-167.  Under IFF_GEMM_F16X2 the groups of 32 rows
+ * that lie wholly behind the count are neither multiplied nor written (their logits are left as they were); the statistics of EVERY
+ * row behind the count become (+inf, 1) (rows of the last, partly kept group hold ordinary logits); the other arithmetic modes
+ * compute every row.  A caller reads the first rows_per_block[b] rows of a block only (iff_attn_colsum_rows does).  Kept rows: the bits
+ * of iff_logits_from_cache.  Workspace: iff_logits_from_cache_workspace. */
 int iff_logits_from_cache_rows(const iff_idnet* net, const void* cache, int64_t N, const float* qf, int32_t M,
                                const int32_t* rows_per_block, float divisor, float* logits, float* row_max, float* row_sumexp,
                                void* workspace, size_t workspace_bytes, void* stream);
