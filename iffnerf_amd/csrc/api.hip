@@ -852,6 +852,8 @@ extern "C" int iff_logits_from_cache_rows(const iff_idnet* n, const void* cache,
                                           const int32_t* rows_per_block, float divisor, float* logits, float* row_max, float* row_sumexp,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     IFF_REQUIRE(rows_per_block, "iff_logits_from_cache_rows: null row counts (iff_logits_from_cache is the call without them)");
+    IFF_REQUIRE(M > 0 && M % 256 == 0, "iff_logits_from_cache_rows: M = %d is not a whole number of 256-row token blocks (one block per "
+                "image, rows_per_block holds M / 256 counts)", M);
     return logits_from_cache(n, cache, N, qf, M, rows_per_block, divisor, logits, row_max, row_sumexp, workspace, workspace_bytes, stream);
 }
 

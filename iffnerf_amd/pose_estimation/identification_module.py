@@ -49,13 +49,16 @@ class RaySession:
     """What stage C keeps per (module weights, ray set): the rays as the kernels read them and the ray encoder's cached output
     (``iff_ray_cache_build``; SURVEY.md 8f-2 -- the reference re-runs the encoder per image, identification_module.py:164, on rays
     that do not change between the images of pose_estimation/test.py:67-91).  Validity is by IDENTITY: the very tensor objects
-    ``explore_model`` returned (held weakly) at the same in-place version, and the same weight versions; anything else builds a
-    new session.  ``graphs`` holds the evaluation loop's captured batches (pose_estimation/test.py of this package)."""
+    ``explore_model`` returned (held weakly) at the same in-place version, storage address and shape, and the same weight versions;
+    anything else builds a new session.  What the key cannot see is a write through a raw pointer (a kernel launched through
+    ctypes, a hipGraph replay into the same buffers): whoever refills ray tensors in place that way calls
+    ``IdentificationModule.invalidate_ray_session()`` (the captured pipelines of this package keep their own ray buffers and
+    encoder caches and never go through a session).  ``graphs`` holds the evaluation loop's captured batches (pose_estimation/test.py of this package)."""
 
     def __init__(self, module: "IdentificationModule", rays_ori, rays_dir, rays_rgb):
         from ..hip_identify import _gpu
         self._refs = tuple(weakref.ref(t) for t in (rays_ori, rays_dir, rays_rgb))
-        self._versions = tuple(t._version for t in (rays_ori, rays_dir, rays_rgb))
+        self._versions = tuple((t._version, t.data_ptr(), tuple(t.shape)) for t in (rays_ori, rays_dir, rays_rgb))
         self.weights_key = module._weights_key()
         self.net = module._idnet()
         self.ori, self.dirs = _gpu(rays_ori, "rays_ori", 3), _gpu(rays_dir, "rays_dir", 3)
@@ -65,7 +68,8 @@ class RaySession:
         self.logits_budget = 0           # bytes of logits per captured batch, fixed when the first graphs are made
 
     def serves(self, module, rays_ori, rays_dir, rays_rgb) -> bool:
-        same = all(r() is t and t._version == v for r, t, v in zip(self._refs, (rays_ori, rays_dir, rays_rgb), self._versions))
+        same = all(r() is t and (t._version, t.data_ptr(), tuple(t.shape)) == v
+                   for r, t, v in zip(self._refs, (rays_ori, rays_dir, rays_rgb), self._versions))
         return same and module._net is self.net and module._weights_key() == self.weights_key
 
 
@@ -76,9 +80,18 @@ class LazyAttentionMap:
     the logits and the row statistics).  Any tensor use -- an attribute, an index, a torch function -- materialises it through
     ``iff_logits_from_cache`` + ``iff_attn_colsum(write_attention=1)`` and the mask select of reference :157-160."""
 
-    def __init__(self, thunk):
+    def __init__(self, thunk, shape_thunk=None):
         object.__setattr__(self, "_thunk", thunk)
         object.__setattr__(self, "_tensor", None)
+        object.__setattr__(self, "_shape_thunk", shape_thunk)
+
+    @property
+    def shape(self) -> torch.Size:
+        """(kept token rows, rays) -- what pose_estimation/test.py:121 reads for the loss -- from the kept-row count alone (one
+        4-byte read), without computing the map."""
+        if self._tensor is None and self._shape_thunk is not None:
+            return torch.Size(self._shape_thunk())
+        return self.materialize().shape
 
     def materialize(self) -> torch.Tensor:
         if self._tensor is None:
@@ -177,6 +190,12 @@ class IdentificationModule(torch.nn.Module):
         self._net = None
         self._net_key = None
         self._ray_session = None          # its encoder cache (and any captured batch) belongs to the handle just closed
+
+    def invalidate_ray_session(self):
+        """Drop the cached ray encoder output (and the captured batches made against it).  For callers that rewrite the ray tensors
+        IN PLACE through something torch's version counter does not see: a raw-pointer kernel, a hipGraph replay into static
+        buffers, a ``.data`` swap.  Writes through torch ops are noticed without it."""
+        self._ray_session = None
 
     def _weights_key(self):
         """Identity + in-place version of every tensor the kernel handle was built from.  ``optimizer.step()`` updates the
@@ -326,7 +345,9 @@ class IdentificationModule(torch.nn.Module):
                 H.attn_colsum(lg, mx, sm, write_attention=True)
                 return lg[keep[q].bool()]
             return make
-        return score, [LazyAttentionMap(thunk(q)) for q in range(Q)]
+        def shape_of(q):
+            return lambda: (int(rows[q]) if bounded else int(keep[q].count_nonzero()), session.n_rays)
+        return score, [LazyAttentionMap(thunk(q), shape_of(q)) for q in range(Q)]
 
     @torch.no_grad()
     def test_image(self, img, mask, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100):

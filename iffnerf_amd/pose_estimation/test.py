@@ -16,7 +16,9 @@ bit for bit, what the image-by-image route below returns (tests/test_hip_eval_lo
 arithmetic does not depend on the batch.  Image by image is the route of everything a batch cannot serve: an arbitrary backbone
 module (``IdentificationModule.serves_batches``), replaced preprocessing, the iNeRF refinement of reference :196-211
 (``inerf_refinement=True``: 800 Adam steps per image through the HIP slab march and its HIP backward, ``iffnerf_amd/inerf``).
-``loss_fn`` / ``save`` belong to the training and plotting code and are out of scope for the MI355X path.
+``loss_fn`` (the validation calls of pose_estimation/train.py:145-153,188-196 pass the training loss) also runs image by image:
+the loss is the CALLER's module, called per image exactly as reference :113-127 calls it, on scores that come from the HIP path.
+``save=True`` writes to a path inside the author's home directory (reference :185-188) and is refused.
 """
 from __future__ import annotations
 
@@ -39,19 +41,40 @@ TOPK = 100             # rays_to_output of reference :90
 
 
 def estimate_pose(id_module, obs_img, mask_img, rays_ori, rays_dirs, rays_rgb, model_up, rays_to_output=TOPK):
-    """One query image -> (c2w [4,4] on the GPU, solver internals, top-k indices, top-k values, scores)."""
+    """One query image -> (c2w [4,4] on the GPU, solver internals, top-k indices, top-k values, scores, attention map (lazy))."""
     from .. import hip_identify as H
-    idx, weights, scores, _ = id_module.test_image(obs_img, mask_img, rays_ori, rays_dirs, rays_rgb,
+    idx, weights, scores, attention_map = id_module.test_image(obs_img, mask_img, rays_ori, rays_dirs, rays_rgb,
                                                    rays_to_output=rays_to_output)
     c2w, parts = H.pose_from_topk(idx, weights, rays_ori, rays_dirs, model_up, want_parts=True)
-    return c2w, parts, idx, weights, scores
+    return c2w, parts, idx, weights, scores, attention_map
 
 
-def _record(sequence_id, img_idx, summary_row, c2w_rows, gt_rows):
+def _record(sequence_id, img_idx, summary_row, c2w_rows, gt_rows, scores_loss=-1.0, recall=-1.0):
     """One entry of the reference's result list (:234-246).  ``summary_row`` = (loss, translation error, angular error, kept)."""
     return {"sequence_id": sequence_id, "category_name": "id_net", "frame_id": img_idx,
-            "loss": summary_row[0], "scores_loss": -1.0, "recall": -1.0, "total_optimization_time_in_ms": 0.0,
+            "loss": summary_row[0], "scores_loss": scores_loss, "recall": recall, "total_optimization_time_in_ms": 0.0,
             "pred_c2w": c2w_rows, "gt_c2w": gt_rows}
+
+
+def _as_4x4(poses):
+    """Ground-truth poses [..,3,4] (the reference only ever reads ``pose[:3, :]``, :213-232) or [..,4,4] -> [..,4,4]."""
+    if poses.shape[-2:] == (4, 4):
+        return poses
+    if poses.shape[-2:] != (3, 4):
+        raise RuntimeError(f"test_pose_estimation: dataset.poses must be [..,3,4] or [..,4,4], got {tuple(poses.shape)}")
+    last = torch.zeros(poses.shape[:-2] + (1, 4), dtype=poses.dtype, device=poses.device)
+    last[..., 0, 3] = 1.0
+    return torch.cat((poses, last), dim=-2)
+
+
+def _score_loss(loss_fn, id_module, scores, idx, weights, attention_map, pose, intrinsic, rays_ori, rays_dirs, model_up):
+    """Reference :110-127: the caller's loss on this image's scores + the reference's "recall" (the positions of the 100 largest
+    top-k weights looked up among the ray indices, exactly as :125-127 writes it).  Two host reads, as in the reference."""
+    avg_score, _ = loss_fn(scores, pose, intrinsic, rays_ori, rays_dirs, attention_map.shape[-2], id_module.backbone_wh,
+                           model_up=model_up)
+    target_idx = torch.topk(weights, k=min(TOPK, weights.shape[0])).indices
+    recall = torch.count_nonzero(torch.isin(target_idx, idx)).item() / target_idx.shape[0]
+    return avg_score.item(), recall
 
 
 def _eval_from_tokens(id_module, session, tokens, keep, rows, gt_poses, model_up, k):
@@ -153,12 +176,15 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
         slots = session.graphs[key]
         cur = torch.cuda.current_stream(device)
         for s in slots:
+            if s.pending is not None:                    # an earlier call died between submit and collect: its batch is not ours
+                s.stream.synchronize()
+                s.pending = None
             s.stream.wait_stream(cur)
         for b in range(n_full):
             slot = slots[b % len(slots)]
             if slot.pending is not None:
                 harvest(*slot.collect())
-            slot.submit(dataset.all_rgbs[b * B:(b + 1) * B], dataset.poses[b * B:(b + 1) * B], b * B)
+            slot.submit(dataset.all_rgbs[b * B:(b + 1) * B], _as_4x4(dataset.poses[b * B:(b + 1) * B]), b * B)
         for slot in slots:
             if slot.pending is not None:
                 harvest(*slot.collect())
@@ -166,7 +192,7 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
     if n_full * B < n:                                  # the tail batch: the same launches, eagerly
         lo = n_full * B
         imgs = dataset.all_rgbs[lo:].to(device=device, dtype=torch.float32, non_blocking=True)
-        gt = dataset.poses[lo:].to(device=device, dtype=torch.float32, non_blocking=True)
+        gt = _as_4x4(dataset.poses[lo:]).to(device=device, dtype=torch.float32, non_blocking=True)
         c2w, summary = eval_batch(id_module, session, imgs, gt, up)
         harvest(lo, c2w.cpu(), summary.cpu())
     return out
@@ -180,9 +206,9 @@ def _batchable(dataset, id_module, rays_ori, inerf_refinement) -> bool:
 
 def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id="", loss_fn=None,
                          save=False, inerf_refinement=False, nerf_model=None, save_all=False, augmentation_parameters={}):
-    if loss_fn is not None or save:
-        raise RuntimeError("test_pose_estimation: loss_fn / save belong to the training and plotting code paths, which "
-                           "are out of scope for the MI355X hot path")
+    if save:
+        raise RuntimeError("test_pose_estimation(save=True) writes its dump to a path inside the reference author's home directory "
+                           "(pose_estimation/test.py:185-188); not provided")
     if inerf_refinement and nerf_model is None:
         raise RuntimeError("test_pose_estimation(inerf_refinement=True) needs nerf_model (reference test.py:196-203)")
     from .. import hip_identify as H
@@ -191,22 +217,35 @@ def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, mode
     n_images = dataset.all_rgbs.shape[0]
     results = []
     start = time.time()
-    if _batchable(dataset, id_module, rays_ori, inerf_refinement):
+    scores_losses, recalls = [], []
+    if loss_fn is None and _batchable(dataset, id_module, rays_ori, inerf_refinement):
         with torch.no_grad():
             rows = _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id)
         gt_rows = dataset.poses.detach().cpu().tolist()               # one read for the whole dataset, not one per image
         for img_idx, (summary, c2w) in enumerate(rows):
             results.append((summary, _record(sequence_id, img_idx, summary, c2w, gt_rows[img_idx])))
     else:
+        if loss_fn is not None:
+            up_unit = torch.as_tensor(model_up, dtype=torch.float32, device=device)
+            up_unit = up_unit / torch.linalg.norm(up_unit, dim=-1, keepdim=True)          # reference :29: the loss gets the unit vector
+            intrinsic = dataset.K.to(device, non_blocking=True)[0]
         for img_idx in range(n_images):
-            pose = dataset.poses[img_idx].to(device, non_blocking=True)
+            pose_as_given = dataset.poses[img_idx].to(device, non_blocking=True)
+            pose = _as_4x4(pose_as_given)
             obs = dataset.all_rgbs[img_idx].to(device, non_blocking=True)
             if obs.shape[-1] == 4:
                 mask_img = obs[..., -1]
                 obs = obs[..., :3] * obs[..., -1:] + (1 - obs[..., -1:])
             else:
                 mask_img = torch.ones_like(obs[..., -1], dtype=torch.bool)
-            c2w, parts, idx, weights, _ = estimate_pose(id_module, obs, mask_img, rays_ori, rays_dirs, rays_rgb, model_up)
+            c2w, parts, idx, weights, scores, attention_map = estimate_pose(id_module, obs, mask_img, rays_ori, rays_dirs, rays_rgb, model_up)
+            scores_loss, recall = -1.0, -1.0
+            if loss_fn is not None:
+                with torch.no_grad():
+                    scores_loss, recall = _score_loss(loss_fn, id_module, scores, idx, weights, attention_map, pose, intrinsic,
+                                                      rays_ori, rays_dirs, up_unit)
+            scores_losses.append(scores_loss)
+            recalls.append(recall)
             if inerf_refinement:                                                               # reference :196-211
                 from ..inerf.estimate_pose_inerf import pose_estimation
                 rgba = torch.cat((obs, mask_img[..., None].to(obs.dtype)), dim=-1).cpu().numpy()
@@ -216,12 +255,17 @@ def test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, mode
                 c2w = c2w.to(device)
             # error metrics (:213-232) and the "loss" entry (:241) in one launch, ONE read per image
             both = torch.cat((H.pose_errors(c2w, pose, parts).reshape(-1), c2w.detach().to(torch.float32).reshape(-1))).cpu().tolist()
-            results.append((both[:4], _record(sequence_id, img_idx, both[:4], [both[4 + 4 * r:8 + 4 * r] for r in range(4)], pose.cpu().tolist())))
+            results.append((both[:4], _record(sequence_id, img_idx, both[:4], [both[4 + 4 * r:8 + 4 * r] for r in range(4)], pose_as_given.cpu().tolist(),
+                                              scores_loss, recall)))
     per_image = (time.time() - start) / max(n_images, 1)
+    avg_score, avg_recall = (mean(scores_losses), mean(recalls)) if scores_losses else (-1.0, -1.0)
+    if loss_fn is not None:
+        print("Average loss score: ", avg_score)
+        print("Average Recall: ", avg_recall)
     print("Time per element: ", per_image)
     translation_errors = [s[1] for s, _ in results]
     angular_errors = [s[2] for s, _ in results]
     avg_t, avg_a = mean(translation_errors), mean(angular_errors)
     print("Translation Error: ", avg_t)
     print("Angular Error: ", avg_a)
-    return [r for _, r in results], avg_t, avg_a, -1.0, -1.0
+    return [r for _, r in results], avg_t, avg_a, avg_score, avg_recall

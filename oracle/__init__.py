@@ -18,4 +18,4 @@ leg of ``bench.py`` -- as the checker / the timed CPU baseline, never as a produ
 product (``iffnerf_amd``) never imports it and raises if its HIP library is missing.
 """
 
-from . import field, emit, identify, pose  # noqa: F401
+from . import field, emit, identify, pose, loss  # noqa: F401

@@ -21,6 +21,8 @@ Vectors (names follow SURVEY.md section 8c):
   g12_march_grad    d loss / d rays through forward(rays) (slab sampler) and through the point-centred sampler, the
                     autograd path of inerf/estimate_pose_inerf.py:164-176 (`python make_golden.py g12` writes only this one)
   g13_inerf_host    CameraTransfer, get_ray_directions_Ks / get_rays, SoftDiceLossV2 of the iNeRF loop (`... g13`)
+  g15_score_loss    DistanceBasedScoreLoss.forward on fixed scores / poses / rays, and test_pose_estimation(..., loss_fn=that loss) --
+                    the validation call of pose_estimation/train.py:145-153 -- on the G8 set (`... g15`)
   g14_api_surface   (JSON) the boundary itself as the imported reference presents it: inspect.signature of every callable the
                     mirror keeps, state_dict keys + shapes of IdentificationModule("dino") over a DINOv2-keyed backbone and of
                     TensorVMSplit, the checkpoint's kwargs keys (`... g14`)
@@ -287,7 +289,66 @@ def g14(ref):
     print(f"g14_api_surface: {len(sigs)} signatures, {len(id_sd)} id-module keys, {len(missing)} modules not importable")
 
 
+def g15(ref):
+    """The score loss of pose_estimation/loss.py:97-147 and the loss route of pose_estimation/test.py:110-127, on the G6 rays and
+    the G8 image set (same fake backbone and identity transforms as G8)."""
+    import importlib
+    loss_mod = importlib.import_module("pose_estimation.loss")
+    g6 = np.load(os.path.join(HERE, "g6_identify.npz"))
+    g8 = np.load(os.path.join(HERE, "g8_end_to_end.npz"))
+    o6, d6, c6 = (torch.from_numpy(g6[k]) for k in ("ori", "dirs", "rgb"))
+    loss = loss_mod.DistanceBasedScoreLoss()
+    gen = torch.Generator().manual_seed(1515)
+    pred = torch.rand(o6.shape[0], generator=gen) * 0.3
+    pose = torch.eye(4)
+    pose[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=gen)).Q
+    pose[:3, 3] = torch.tensor([1.7, -0.9, 1.2])
+    K = torch.tensor([[20.0, 0.0, 8.0], [0.0, 20.0, 8.0], [0.0, 0.0, 1.0]])
+    up = torch.from_numpy(g8["model_up"])
+    with torch.no_grad():
+        avg, target = loss(pred, pose, K, o6, d6, 137, (16, 16), model_up=up / torch.linalg.norm(up))
+
+    IM = ref.identification_module
+    tok8 = torch.from_numpy(g8["tokens"])
+
+    class FakeBackbone(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def forward_features(self, x):
+            self.calls += 1
+            return {"x_norm_patchtokens": (tok8 * (1.0 + 0.05 * self.calls))[None]}
+
+    IM.create_backbone = lambda type="dino", pretrained=False, **k: (FakeBackbone(), (16, 16), 384)
+    idm = IM.IdentificationModule("dino")
+    sd = idm.state_dict()
+    sd.update(synthetic.make_id_weights(seed=99))
+    idm.load_state_dict(sd)
+    idm.eval()
+
+    class Dataset:
+        pass
+
+    ds = Dataset()
+    ds.all_rgbs = torch.from_numpy(g8["imgs"]).clone()
+    ds.K = K[None].clone()
+    ds.all_rays = torch.zeros(2, 4, 6)
+    ds.poses = torch.from_numpy(g8["poses"]).clone()
+    with contextlib.redirect_stdout(io.StringIO()):
+        res, te, ae, avg_loss, avg_recall = ref.pe_test.test_pose_estimation(ds, idm, o6, d6, c6, up.clone(), loss_fn=loss)
+    save("g15_score_loss", pred_score=pred, pose=pose, K=K, n_features=np.int64(137), avg_score=avg, target_score=target,
+         scores_loss=np.asarray([r["scores_loss"] for r in res], dtype=np.float64),
+         recall=np.asarray([r["recall"] for r in res], dtype=np.float64),
+         pred_c2w=np.asarray([r["pred_c2w"] for r in res], dtype=np.float32),
+         avg_loss_score=np.float64(avg_loss), avg_recall=np.float64(avg_recall),
+         avg_translation_error=np.float32(te), avg_angular_error=np.float32(ae))
+
+
 def main():
+    if sys.argv[1:] == ["g15"]:
+        g15(ri.install())
+        return
     if sys.argv[1:] == ["g14"]:
         g14(ri.install())
         return
@@ -491,6 +552,7 @@ def main():
     g12(ref)
     g13()
     g14(ref)
+    g15(ref)
     print("done")
 
 

@@ -136,6 +136,30 @@ def test_g8_end_to_end(golden):
         _eq(c2w, g["pred_c2w"][i], 1e-5)
 
 
+def test_g15_score_loss(golden):
+    """The loss of the validation calls (pose_estimation/train.py:145-153) and the loss route of test.py:110-127 chained on the
+    oracle's stage C: per-image loss and "recall" as the reference returned them."""
+    from oracle import loss as oloss
+    g = golden["g15_score_loss"]
+    o, d, c = (golden.t("g6_identify", k) for k in ("ori", "dirs", "rgb"))
+    up = golden.t("g8_end_to_end", "model_up")
+    fn = oloss.DistanceBasedScoreLoss()
+    avg, target = fn(golden.t("g15_score_loss", "pred_score"), golden.t("g15_score_loss", "pose"), golden.t("g15_score_loss", "K"),
+                     o, d, int(g["n_features"]), (16, 16), model_up=up / torch.linalg.norm(up))
+    _eq(avg, g["avg_score"]); _eq(target, g["target_score"])
+    w = synthetic.make_id_weights(seed=int(golden["g6_identify"]["id_seed"]))
+    tok = golden.t("g8_end_to_end", "tokens")
+    for i in range(2):
+        keep = golden.t("g8_end_to_end", "imgs")[i, ..., 3] > 0.1
+        t = identify.tokens_with_pe(tok * (1.0 + 0.05 * (i + 1)), keep)
+        idx, val, score, amap = identify.test_image(w, t, o, d, c, 100)
+        sl, _ = fn(score, golden.t("g8_end_to_end", "poses")[i], golden.t("g15_score_loss", "K"), o, d, amap.shape[-2], (16, 16))
+        assert float(sl) == float(g["scores_loss"][i])
+        target_idx = torch.topk(val, k=100).indices                       # the reference's "recall" (test.py:125-127)
+        assert torch.count_nonzero(torch.isin(target_idx, idx)).item() / 100 == float(g["recall"][i])
+    _eq(torch.from_numpy(g["pred_c2w"]), golden["g8_end_to_end"]["pred_c2w"])       # the loss does not touch the pose
+
+
 def test_g9_sampler(golden):
     g = golden["g9_sampler"]
     f = field.field_from_ckpt(util.ckpt("small"))
