@@ -122,9 +122,10 @@ def test_attention_map_is_lazy_and_right(dev, monkeypatch):
     idx, val, scores, amap = mod.test_image(img, mask, ro, rd, rc, rays_to_output=100)
     assert isinstance(amap, LazyAttentionMap) and not amap.is_materialized
     assert idx.shape == (100,) and idx.dtype == torch.int64 and scores.shape == (ro.shape[0],) and torch.equal(scores[idx], val)
-    M = amap.shape[0]                                    # first read: computed now
-    assert amap.is_materialized and amap.shape == (M, ro.shape[0]) and 30 < M < 256
-    torch.testing.assert_close(amap.sum(-1), torch.ones(M, device=dev), atol=1e-4, rtol=0)
+    M = amap.shape[0]                                    # the shape (all pose_estimation/test.py:121 reads of the map) costs a 4-byte read
+    assert not amap.is_materialized and amap.shape == (M, ro.shape[0]) and 30 < M < 256
+    torch.testing.assert_close(amap.sum(-1), torch.ones(M, device=dev), atol=1e-4, rtol=0)      # first use as a tensor: computed now
+    assert amap.is_materialized and tuple(amap.materialize().shape) == (M, ro.shape[0])
     torch.testing.assert_close(torch.sum(amap, dim=0), scores, atol=1e-6, rtol=1e-4)            # a torch function on the lazy object
     assert torch.is_tensor(amap * 2.0) and torch.is_tensor(amap[0]) and len(amap) == M
     # the compacting route (run_attention: boolean row select before the logits, as the reference) gives the same map
