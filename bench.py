@@ -273,10 +273,36 @@ def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=Fal
         torch.cuda.synchronize(device)
         t_second = time.perf_counter() - t0
     assert len(res[0]) == n_images and all(len(r["pred_c2w"]) == 4 for r in res[0])
-    kept = idm.static_tokens(ds.all_rgbs[:8].to(device), None, compact=True)[2].float().mean().item()
+    rows = idm.static_tokens(ds.all_rgbs[:8].to(device), None, compact=True)[2].float()
+    kept = rows.mean().item()
     return {"poses_per_s": round(n_images / t_second, 2), "images": n_images, "rays": int(rays[0].shape[0]), "tokens_kept_per_image": round(kept, 1),
             "explore_model_ms": round(t_explore * 1e3, 3), "first_call_ms": round(t_first * 1e3, 2),
-            "dataset": "host memory (PCIe inside the timed call)" if host_dataset else "resident in HBM"}
+            "dataset": "host memory (PCIe inside the timed call)" if host_dataset else "resident in HBM",
+            "roofline": dropin_roofline(int(rays[0].shape[0]), kept, (torch.ceil(rows / 32) * 32).mean().item(), t_second / n_images,
+                                        idm._idnet().mfma_products())}
+
+
+def dropin_roofline(n_rays, kept_rows, issued_rows, s_per_image, products):
+    """The roof of the evaluation loop (never part of `value`): per image the route writes the logits of the kept token rows
+    ([kept, N] fp32: iff_logits_from_cache_rows) and reads them back once for the column sums (iff_attn_colsum_rows) -- the round
+    trip pose_estimation/identification_module.py:165-167 makes through its [M, N] attention map -- so no such loop runs faster than
+    those bytes at the HBM rate.  `frac` = that floor over the WHOLE loop's time per image (backbone, fold, logits, column pass,
+    top-k, pose, read-back: everything test_pose_estimation does).  `mfma`: the logits product alone against the matrix-core peak
+    over the same time -- algorithmic (2 x 384 + 4 flops per (kept token, ray) pair) and as issued (rows in groups of 32,
+    256-deep, `products` fp16 products per fp32-accurate product)."""
+    nbytes = 2.0 * kept_rows * n_rays * 4.0
+    gbs = nbytes / s_per_image / 1e9
+    algo = kept_rows * n_rays * (2.0 * 384.0 + 4.0) / s_per_image / 1e12
+    issued = issued_rows * n_rays * products * 2.0 * 256.0 / s_per_image / 1e12
+    return {"route": "test_pose_estimation, per image: logits of the kept token rows written once + read once",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "logits_bytes_per_image": round(nbytes), "ms_per_image": round(s_per_image * 1e3, 4),
+            "floor_ms_per_image": round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
+            "mfma": {"kernel": "iff_logits_from_cache_rows", "algorithmic_tflops": round(algo, 1), "issued_tflops": round(issued, 1),
+                     "frac": round(algo / MFMA_BF16_PEAK_TFLOPS, 4), "frac_issued": round(issued / MFMA_BF16_PEAK_TFLOPS, 4)},
+            "traffic": None,
+            "note": "time = the whole loop's seconds per image, so `frac` is the share of the loop's time the logits' HBM round trip alone would need at "
+                    "8 TB/s; `traffic` (PMC) is not collected for this route"}
 
 
 def main():

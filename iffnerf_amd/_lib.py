@@ -21,7 +21,7 @@ PRODUCT_LIB_PATH = os.path.join(_HERE, "libiffnerf_hip.so")
 LIB_PATH = os.environ.get("IFF_LIB_PATH") or PRODUCT_LIB_PATH
 DEV_LIBRARY = os.path.abspath(LIB_PATH) != os.path.abspath(PRODUCT_LIB_PATH)
 _lib = None
-ABI_VERSION = 11         # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
+ABI_VERSION = 12         # include/iffnerf_hip.h IFF_ABI_VERSION this binding was written against
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -53,7 +53,7 @@ class IdNetDesc(C.Structure):
 class VitDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "mlp", "patch", "grid_h", "grid_w")] + [("ln_eps", C.c_float)] + [
         (n, C.c_void_p) for n in ("patch_w", "patch_b", "cls", "pos", "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
-                                  "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "norm_w", "norm_b")] + [("precision", C.c_int32)]
+                                  "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "norm_w", "norm_b")] + [("precision", C.c_int32), ("gemm_form", C.c_int32)]
 
 
 VIT_FP32, VIT_BF16 = 0, 1          # include/iffnerf_hip.h IFF_VIT_FP32 / IFF_VIT_BF16

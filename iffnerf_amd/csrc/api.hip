@@ -1239,6 +1239,7 @@ extern "C" int iff_vit_create(const iff_vit_desc* d, void* stream, iff_vit** out
     iff_vit* v = new iff_vit();                     // every descriptor check is above this line: nothing below returns without freeing v
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
+    IFF_REQUIRE(d->gemm_form >= 0 && d->gemm_form <= 4, "iff_vit_create: gemm_form %d is not one of 0 .. 4", d->gemm_form);
     const bool split = d->precision == IFF_VIT_FP32;
     const size_t eb = split ? 4 : 2;               // bytes per weight: bf16, or fp16 hi + lo planes
     const size_t o_pw = take(D * kp * eb), o_qkv = take(L * 3 * D * D * eb), o_proj = take(L * D * D * eb), o_fc1 = take(L * F * D * eb),
@@ -1260,6 +1261,7 @@ extern "C" int iff_vit_create(const iff_vit_desc* d, void* stream, iff_vit** out
     VitDev& w = v->dev;
     memset(&w, 0, sizeof(w));
     w.prec = split ? 1 : 0;
+    w.gemm_form = d->gemm_form;
     w.s_patch = 1.0f;
     for (int l = 0; l < VIT_MAX_DEPTH; ++l) w.s_qkv[l] = w.s_proj[l] = w.s_fc1[l] = w.s_fc2[l] = 1.0f;
     if (!split) {

@@ -160,6 +160,7 @@ struct VitDev {
     int dim, depth, heads, mlp, patch, gh, gw, T, kp;
     float eps;
     int prec;                             // 0: bf16 operands; 1: split fp16 operands (hi + lo), three products per block
+    int gemm_form;                        // iff_vit_desc.gemm_form: which GEMM kernels serve a large batch (0: the product's choice)
     float s_patch, s_qkv[VIT_MAX_DEPTH], s_proj[VIT_MAX_DEPTH], s_fc1[VIT_MAX_DEPTH], s_fc2[VIT_MAX_DEPTH];      // accumulator scales (prec 1)
 };
 hipError_t launch_resize_crop(const float* src, int Q, int H, int W, int C, int mode, int rh, int rw, int top, int left, int ch, int cw, int cubic,

@@ -413,6 +413,205 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ GEMM, operand tiles by LDS-DMA
+// The same product with the operand tiles filled by global_load_lds_dwordx4 (no staging registers, no ds_write pass: those stores
+// were a fifth of the register-staged kernel and its tiles one deep) into TWO LDS buffers: the tile of k-step t + 1 travels while
+// step t is multiplied, one barrier per step.  An LDS row is 128 B = eight 16-byte chunks of one operand row: PREC 0 64 k of the
+// bf16 plane; PREC 1 32 k of the hi plane then the same 32 k of the lo plane (so both precisions stage 128 B per row and step, and
+// a PREC 1 step is 32 deep with three products).  A DMA instruction writes 1 KiB lane-linearly -- eight whole rows -- so rows
+// cannot be padded; chunk c of row r sits in slot c ^ ((r >> 1) & 7) instead (the swizzle is applied to the per-lane SOURCE
+// address), which spreads the 16 lanes of every ds_read_b128 group over the 16 slots of a 256-byte bank row: conflict-free.
+// Tile: BN = 32 AR WN features x BM = 32 BR WM tokens over WN x WM waves, a wave 32 AR x 32 BR.  The k order of every
+// accumulator (16-deep blocks in increasing k; per block lo hi, hi lo, hi hi) is the register-staged kernel's: the same bits.
+template <int EPI, int PREC, int WN, int WM, int AR, int BR>
+__global__ void __launch_bounds__(64 * WN * WM, (WN * WM <= 4 ? 2 : 1))
+k_vit_gemm_dma(const typename VT<PREC>::e* __restrict__ X, int64_t x_lo, const typename VT<PREC>::e* __restrict__ Wt, int64_t w_lo, int64_t M,
+               int N, int K, GemmEpi e) {
+    typedef typename VT<PREC>::e ET;
+    typedef typename VT<PREC>::v8 V8;
+    constexpr int NW = WN * WM, BN = 32 * AR * WN, BM = 32 * BR * WM, ROWS = BN + BM;
+    constexpr int KT = PREC ? 32 : 64;                          // k per step
+    constexpr int KS = PREC ? 2 : 4;                            // 16-deep blocks per step
+    constexpr int TILE = ROWS * 128;                            // bytes per buffer
+    constexpr int PPW = ROWS / 8 / NW;                          // 1-KiB pieces per wave and step
+    static_assert(ROWS % (8 * NW) == 0, "whole pieces per wave");
+    __shared__ __attribute__((aligned(1024))) char s_all[2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = (wave % WN) * (32 * AR), wm = (wave / WN) * (32 * BR);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    f32x16 acc[AR][BR];
+#pragma unroll
+    for (int a = 0; a < AR; ++a)
+#pragma unroll
+        for (int b = 0; b < BR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    // this lane's source of every piece the wave fills (at k = 0): piece p = rows 8 p .. 8 p + 7, lane -> row 8 p + (lane >> 3), slot lane & 7
+    const ET* src[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int r = 8 * (wave + NW * i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int kc = PREC ? (c & 3) * 8 : c * 8;
+        const bool lo = PREC && c >= 4;
+        if (r < BN) src[i] = Wt + (lo ? w_lo : 0) + (int64_t)(n0 + r) * K + kc;
+        else        src[i] = X + (lo ? x_lo : 0) + min(m0 + (r - BN), M - 1) * K + kc;
+    }
+    auto issue = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            // (the source as `const void*`: with a pointer of template-dependent type here hipcc's host pass silently drops the kernel's launch stub)
+            __builtin_amdgcn_global_load_lds((const void*)(src[i] + (int64_t)t * KT),
+                                             (__attribute__((address_space(3))) void*)(s_all + buf * TILE + (wave + NW * i) * 1024), 16, 0, 0);
+    };
+    const int sw = (lr >> 1) & 7;
+    const int steps = K / KT;
+    issue(0, 0);
+    for (int t = 0; t < steps; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step t have landed ...
+        __syncthreads();                                       // ... everybody's have, and everybody is done reading the other buffer
+        if (t + 1 < steps) issue(t + 1, (t + 1) & 1);
+        const char* bw = s_all + (t & 1) * TILE + (wn + lr) * 128;
+        const char* bx = s_all + (t & 1) * TILE + (BN + wm + lr) * 128;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            constexpr int NP = PREC ? 2 : 1;
+            V8 fa[NP][AR], fb[NP][BR];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                const int slot = ((4 * pl + 2 * ks + lh) ^ sw) << 4;
+#pragma unroll
+                for (int a = 0; a < AR; ++a) fa[pl][a] = *reinterpret_cast<const V8*>(bw + a * (32 * 128) + slot);
+#pragma unroll
+                for (int b = 0; b < BR; ++b) fb[pl][b] = *reinterpret_cast<const V8*>(bx + b * (32 * 128) + slot);
+            }
+#pragma unroll
+            for (int a = 0; a < AR; ++a)
+#pragma unroll
+                for (int b = 0; b < BR; ++b) {
+                    if (PREC) {
+                        acc[a][b] = VT<PREC>::mfma(fa[NP - 1][a], fb[0][b], acc[a][b]);      // W lo x X hi
+                        acc[a][b] = VT<PREC>::mfma(fa[0][a], fb[NP - 1][b], acc[a][b]);      // W hi x X lo
+                    }
+                    acc[a][b] = VT<PREC>::mfma(fa[0][a], fb[0][b], acc[a][b]);
+                }
+        }
+    }
+    // epilogues: the register-staged kernel's, per 64-feature half of the wave's tile (a wave's 64 features are one head) and per
+    // 32-token block.  D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh
+    if constexpr (PREC == 1 && (EPI == EPI_QKV || EPI == EPI_GELU)) {
+        const bool by_rows = !(EPI == EPI_QKV && n0 / (N / 3) == 2);
+        if (by_rows) {
+            constexpr int TLD = 68;
+            static_assert(NW * 32 * TLD * 4 <= 2 * TILE, "the waves' output tiles fit the operand pool");
+            float* const tile = reinterpret_cast<float*>(s_all) + wave * 32 * TLD;
+#pragma unroll
+            for (int h = 0; h < AR / 2; ++h)
+#pragma unroll
+                for (int b = 0; b < BR; ++b) {
+                    __syncthreads();                       // the last fragments / the previous block's rows have been read
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int a = 2 * h + a2;
+                            const int nl = 32 * a2 + 8 * g4 + 4 * lh;
+                            const float4 bi = *reinterpret_cast<const float4*>(e.bias + n0 + wn + 64 * h + nl);
+                            float v[4] = {acc[a][b][4 * g4] * e.wscale + bi.x, acc[a][b][4 * g4 + 1] * e.wscale + bi.y,
+                                          acc[a][b][4 * g4 + 2] * e.wscale + bi.z, acc[a][b][4 * g4 + 3] * e.wscale + bi.w};
+                            if (EPI == EPI_QKV) {
+                                const float sc = n0 < N / 3 ? e.qscale : 1.0f;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] *= sc;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752440f));
+                            }
+                            *reinterpret_cast<float4*>(tile + lr * TLD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    __syncthreads();
+                    const int n8 = (lane & 7) * 8;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = 8 * it + (lane >> 3);
+                        const int64_t m = m0 + wm + 32 * b + row;
+                        if (m >= M) continue;
+                        const float4 v0 = *reinterpret_cast<const float4*>(tile + row * TLD + n8);
+                        const float4 v1 = *reinterpret_cast<const float4*>(tile + row * TLD + n8 + 4);
+                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        f16x8 hh8, ll8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { _Float16 hh, ll; split_h(v[j], hh, ll); hh8[j] = hh; ll8[j] = ll; }
+                        _Float16* dst;
+                        int64_t at, lo_off;
+                        if (EPI == EPI_QKV) {
+                            const int D = N / 3, which = n0 / D, head = (n0 - which * D + wn + 64 * h) >> 6;
+                            const int img = (int)(m / e.T), tk = (int)(m - (int64_t)img * e.T);
+                            dst = reinterpret_cast<_Float16*>(which == 0 ? e.q : e.k);
+                            at = (((int64_t)(img * e.heads + head) * e.T + tk) << 6) + n8;
+                            lo_off = e.qk_lo;
+                        } else {
+                            dst = reinterpret_cast<_Float16*>(e.out);
+                            at = m * N + n0 + wn + 64 * h + n8;
+                            lo_off = M * (int64_t)N;
+                        }
+                        *reinterpret_cast<f16x8*>(dst + at) = hh8;
+                        *reinterpret_cast<f16x8*>(dst + at + lo_off) = ll8;
+                    }
+                }
+            return;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+        const int64_t m = m0 + wm + 32 * b + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int a = 0; a < AR; ++a)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + wn + 32 * a + 8 * g4 + 4 * lh;
+                const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
+                float v[4] = {acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+                if (PREC) { v[0] *= e.wscale; v[1] *= e.wscale; v[2] *= e.wscale; v[3] *= e.wscale; }
+                v[0] += bi.x; v[1] += bi.y; v[2] += bi.z; v[3] += bi.w;
+                if (EPI == EPI_QKV) {
+                    const int D = N / 3, which = n0 / D, c = n - which * D, head = c >> 6, d = c & 63;
+                    const int img = (int)m / e.T;
+                    const int tk = (int)m - img * e.T;
+                    if (which == 2) {
+                        const int64_t at = ((int64_t)(img * e.heads + head) * 64 + d) * AT_TP + tk;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) put1<PREC>(e.v, at + (int64_t)i * AT_TP, e.v_lo, v[i]);
+                    } else {
+                        const int64_t at = (((int64_t)(img * e.heads + head) * e.T + tk) << 6) + d;
+                        const float sc = which == 0 ? e.qscale : 1.0f;
+                        const float o[4] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+                        put4<PREC>(which == 0 ? e.q : e.k, at, e.qk_lo, o);
+                    }
+                } else if (EPI == EPI_GELU) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752440f));
+                    put4<PREC>(e.out, m * N + n, M * (int64_t)N, o);
+                } else if (EPI == EPI_RESID) {
+                    const float4 ls = *reinterpret_cast<const float4*>(e.ls + n);
+                    float4* xp = reinterpret_cast<float4*>(e.x + m * N + n);
+                    float4 xv = *xp;
+                    xv.x = fmaf(ls.x, v[0], xv.x); xv.y = fmaf(ls.y, v[1], xv.y); xv.z = fmaf(ls.z, v[2], xv.z); xv.w = fmaf(ls.w, v[3], xv.w);
+                    *xp = xv;
+                } else {
+                    const int64_t img = m / e.G;
+                    const int p = (int)(m - img * e.G);
+                    const float4 ps = *reinterpret_cast<const float4*>(e.pos + (int64_t)(1 + p) * N + n);
+                    *reinterpret_cast<float4*>(e.x + (img * e.T + 1 + p) * N + n) = make_float4(v[0] + ps.x, v[1] + ps.y, v[2] + ps.z, v[3] + ps.w);
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ attention
 // One workgroup = (image, head, block of 128 queries); wave w serves queries 32 w .. 32 w + 31 of the block.  (Two workgroups per
 // (image, head) with a second pass for the 257th token in one wave -- 384 workgroups, one round of the chip's slots instead of 576 --
@@ -863,8 +1062,18 @@ inline unsigned grid1(int64_t n, int block = 256, int cap = 256 * 16) {
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+template <int EPI, int PREC, int WN, int WM, int AR, int BR>
+void gemm_dma(const typename VT<PREC>::e* X, int64_t x_lo, const typename VT<PREC>::e* W, int64_t w_lo, int64_t M, int N, int K, const GemmEpi& e,
+              hipStream_t s) {
+    constexpr int BN = 32 * AR * WN, BM = 32 * BR * WM;
+    hipLaunchKernelGGL((k_vit_gemm_dma<EPI, PREC, WN, WM, AR, BR>), dim3((unsigned)(N / BN), (unsigned)((M + BM - 1) / BM)), dim3(64 * WN * WM), 0, s, X,
+                       x_lo, W, w_lo, M, N, K, e);
+}
+
+// `form` (iff_vit_desc.gemm_form): 0 the product's choice; 1 the register-staged kernels only; 2-4 name one DMA tile shape for
+// every product of a large batch (A/B runs and the bit-equality test: every form returns the same bits)
 template <int EPI, int PREC>
-hipError_t gemm(const void* Xv, int64_t x_lo, const void* Wv, int64_t w_lo, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
+hipError_t gemm(int form, const void* Xv, int64_t x_lo, const void* Wv, int64_t w_lo, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
     typedef typename VT<PREC>::e ET;
     const ET* X = (const ET*)Xv;
     const ET* W = (const ET*)Wv;
@@ -875,8 +1084,14 @@ hipError_t gemm(const void* Xv, int64_t x_lo, const void* Wv, int64_t w_lo, int6
     const bool wide = M >= 6144;       // (64-token tiles for the N = 384 products only: -1.7 % images/s)
     if (!wide)
         hipLaunchKernelGGL((k_vit_gemm<EPI, 64, PREC>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, x_lo, W, w_lo, M, N, K, e);
-    else
+    else if (form == 1)
         hipLaunchKernelGGL((k_vit_gemm<EPI, 128, PREC>), dim3((unsigned)(N / GBN), (unsigned)((M + 127) / 128)), dim3(256), 0, s, X, x_lo, W, w_lo, M, N, K, e);
+    else if (form == 4 && EPI == EPI_GELU && N % 256 == 0)
+        gemm_dma<EPI, PREC, 2, 4, 4, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else if (form == 3 || form == 4)
+        gemm_dma<EPI, PREC, 2, 4, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else
+        gemm_dma<EPI, PREC, 2, 2, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
     return hipGetLastError();
 }
 
@@ -960,7 +1175,7 @@ static hipError_t vit_forward(const VitDev& v, const float* images, int Q, int H
     hipLaunchKernelGGL(k_vit_cls, dim3(grid1((int64_t)Q * D)), dim3(256), 0, s, v.cls, v.pos, Q, v.T, D, x);
     GemmEpi ep = {};
     ep.bias = v.patch_b; ep.x = x; ep.pos = v.pos; ep.G = v.T - 1; ep.T = v.T; ep.wscale = v.s_patch;
-    if ((e = gemm<EPI_EMBED, PREC>(col, col_lo, v.patch_w, w_patch_lo, G, D, v.kp, ep, s)) != hipSuccess) return e;
+    if ((e = gemm<EPI_EMBED, PREC>(v.gemm_form, col, col_lo, v.patch_w, w_patch_lo, G, D, v.kp, ep, s)) != hipSuccess) return e;
     const unsigned ln_grid = (unsigned)((M + 3) / 4);
     constexpr int LN_OUT = PREC ? 2 : 1;
     for (int l = 0; l < L; ++l) {
@@ -969,7 +1184,7 @@ static hipError_t vit_forward(const VitDev& v, const float* images, int Q, int H
         GemmEpi e0 = {};
         e0.bias = v.qkv_b + (size_t)l * 3 * D; e0.q = q; e0.k = k; e0.v = vv; e0.T = v.T; e0.heads = v.heads; e0.qscale = 0.125f;
         e0.qk_lo = qk_lo; e0.v_lo = v_lo; e0.wscale = v.s_qkv[l];
-        if ((e = gemm<EPI_QKV, PREC>(xn, xn_lo, (const ET*)v.qkv_w + (size_t)l * 3 * D * D, w_qkv_lo, M, 3 * D, D, e0, s)) != hipSuccess) return e;
+        if ((e = gemm<EPI_QKV, PREC>(v.gemm_form, xn, xn_lo, (const ET*)v.qkv_w + (size_t)l * 3 * D * D, w_qkv_lo, M, 3 * D, D, e0, s)) != hipSuccess) return e;
         if (PREC)
             hipLaunchKernelGGL(k_vit_attention_x2, dim3((unsigned)((v.T + 127) / 128), (unsigned)(Q * v.heads)), dim3(256), 0, s, (const _Float16*)q,
                                (const _Float16*)k, qk_lo, (const _Float16*)vv, v_lo, v.T, v.heads, (_Float16*)xn, xn_lo);
@@ -978,15 +1193,15 @@ static hipError_t vit_forward(const VitDev& v, const float* images, int Q, int H
                                (const __bf16*)k, (const __bf16*)vv, v.T, v.heads, (__bf16*)xn);
         GemmEpi e1 = {};
         e1.bias = v.proj_b + (size_t)l * D; e1.x = x; e1.ls = v.ls1 + (size_t)l * D; e1.wscale = v.s_proj[l];
-        if ((e = gemm<EPI_RESID, PREC>(xn, xn_lo, (const ET*)v.proj_w + (size_t)l * D * D, w_proj_lo, M, D, D, e1, s)) != hipSuccess) return e;
+        if ((e = gemm<EPI_RESID, PREC>(v.gemm_form, xn, xn_lo, (const ET*)v.proj_w + (size_t)l * D * D, w_proj_lo, M, D, D, e1, s)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_vit_layernorm<LN_OUT>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.ln2_w + (size_t)l * D, v.ln2_b + (size_t)l * D,
                            v.eps, (void*)xn, nullptr, nullptr);
         GemmEpi e2 = {};
         e2.bias = v.fc1_b + (size_t)l * v.mlp; e2.out = hid; e2.wscale = v.s_fc1[l];
-        if ((e = gemm<EPI_GELU, PREC>(xn, xn_lo, (const ET*)v.fc1_w + (size_t)l * v.mlp * D, w_fc_lo, M, v.mlp, D, e2, s)) != hipSuccess) return e;
+        if ((e = gemm<EPI_GELU, PREC>(v.gemm_form, xn, xn_lo, (const ET*)v.fc1_w + (size_t)l * v.mlp * D, w_fc_lo, M, v.mlp, D, e2, s)) != hipSuccess) return e;
         GemmEpi e3 = {};
         e3.bias = v.fc2_b + (size_t)l * D; e3.x = x; e3.ls = v.ls2 + (size_t)l * D; e3.wscale = v.s_fc2[l];
-        if ((e = gemm<EPI_RESID, PREC>(hid, hid_lo, (const ET*)v.fc2_w + (size_t)l * D * v.mlp, w_fc_lo, M, D, v.mlp, e3, s)) != hipSuccess) return e;
+        if ((e = gemm<EPI_RESID, PREC>(v.gemm_form, hid, hid_lo, (const ET*)v.fc2_w + (size_t)l * D * v.mlp, w_fc_lo, M, D, v.mlp, e3, s)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_vit_layernorm<0>), dim3(ln_grid), dim3(256), 0, s, x, M, v.T, v.norm_w, v.norm_b, v.eps, nullptr, patch_tokens, cls_opt);
     return hipGetLastError();

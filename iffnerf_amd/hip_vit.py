@@ -52,8 +52,9 @@ class ViTHandle:
     """One ViT-S/14's weights on one GPU (``iff_vit``)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device, grid=(16, 16), patch: int = 14, heads: int = 6, ln_eps: float = 1e-6,
-                 precision: str = "fp32"):
-        """``precision``: "fp32" (the default) -- the accuracy class of the reference's fp32 DINOv2: every matrix operand split exactly
+                 precision: str = "fp32", gemm_form: int = 0):
+        """``gemm_form`` (``iff_vit_desc.gemm_form``): 0 the library's choice of GEMM kernels; 1-4 name one (A/B runs, the bit-equality test).
+        ``precision``: "fp32" (the default) -- the accuracy class of the reference's fp32 DINOv2: every matrix operand split exactly
         into two fp16 pieces, three MFMA products per block, fp32 accumulation (include/iffnerf_hip.h IFF_VIT_FP32); "bf16" -- bf16
         operands, ~2x faster, token features move by ~1e-2 relative (a throughput option)."""
         self._h = None
@@ -95,6 +96,7 @@ class ViTHandle:
         d.dim, d.depth, d.heads, d.mlp, d.patch, d.grid_h, d.grid_w = dim, depth, int(heads), int(t["fc1_w"].shape[1]), int(patch), gh, gw
         d.ln_eps = float(ln_eps)
         d.precision = PRECISIONS[precision]
+        d.gemm_form = int(gemm_form)
         self.precision = precision
         keep = []
         for name, v in t.items():

@@ -88,3 +88,9 @@ def test_roofline_object_states_both_hbm_readings():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ("dropin_poses_per_s", "cold_image_to_pose_per_s", "value_without_settle", "dev_library"):
         assert '"%s"' % key in src, key
+    # the route users run carries its own roof: the logits round trip of the kept rows at the HBM rate over the loop's time per image
+    r = bench.dropin_roofline(540000, 256.0, 256.0, 0.49e-3, 3)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["logits_bytes_per_image"] == 2 * 256 * 540000 * 4
+    assert abs(r["frac"] - 1105920000 / 0.49e-3 / 8e12) < 1e-3 and abs(r["floor_ms_per_image"] - 0.1382) < 1e-3
+    assert abs(r["mfma"]["frac_issued"] - 256 * 540000 * 3 * 512 / 0.49e-3 / 2.5e15) < 1e-3 and r["mfma"]["kernel"] == "iff_logits_from_cache_rows"
+    assert '"roofline": dropin_roofline(' in src

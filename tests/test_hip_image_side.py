@@ -285,6 +285,38 @@ def test_native_vit_matches_the_fp32_torch_module(dev):
         vit.forward(torch.zeros(1, 3, 200, 224, device=dev))
 
 
+def test_vit_gemm_forms_return_the_same_bits(dev):
+    """A batch of 24 images or more takes the wide GEMM kernels (csrc/vit_kernels.hip gemm()): register-staged 128 x 128 tiles
+    (form 1) or tiles filled by LDS-DMA in three shapes (forms 2-4; 0 = the library's choice).  Every form adds a row's products
+    in the same order, so all of them -- and the 64-token kernels that serve the same images in smaller batches -- return the
+    SAME tokens bit for bit, in both precisions; and they are the fp32 torch module's tokens to 1e-4."""
+    from iffnerf_amd.hip_vit import ViTHandle
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    net, grid, C = create_standin_backbone(seed=4)
+    net = net.to(dev)
+    Q = 25                                                   # 6 425 tokens: the last 128- and 256-token tiles are partly empty
+    x = torch.randn(Q, 3, 224, 224, generator=torch.Generator().manual_seed(31)).to(dev)
+    with torch.no_grad():
+        ref = net.forward_features(x)["x_norm_patchtokens"]
+    scale = float(ref.abs().max())
+    for prec in ("fp32", "bf16"):
+        outs = {}
+        for form in (0, 1, 2, 3, 4):
+            vit = ViTHandle(net.state_dict(), dev, precision=prec, gemm_form=form)
+            tok, cls = vit.forward(x, want_cls=True)
+            outs[form] = (tok, cls)
+            assert torch.isfinite(tok).all()
+        for form in (0, 2, 3, 4):
+            assert torch.equal(outs[form][0], outs[1][0]) and torch.equal(outs[form][1], outs[1][1]), (prec, form)
+        small = ViTHandle(net.state_dict(), dev, precision=prec)
+        parts = torch.cat([small.forward(x[i:i + 5]) for i in range(0, Q, 5)])             # the same images, five per call: 64-token tiles
+        assert torch.equal(parts, outs[0][0]), prec
+        err = float((outs[0][0] - ref).abs().max())
+        assert err <= (1e-4 if prec == "fp32" else 4e-2) * scale, (prec, err, scale)
+    with pytest.raises(RuntimeError, match="gemm_form"):
+        ViTHandle(net.state_dict(), dev, gemm_form=9)
+
+
 def test_native_vit_small_activations(dev):
     """The fp32 class splits an operand into two fp16 pieces; for |v| < 2^-3 the low piece is an fp16 SUBNORMAL (csrc/vit_kernels.hip
     split_h).  Move every matrix product's activations there -- LayerNorm gains and biases times 2^-7, the weights that consume them
