@@ -1239,7 +1239,7 @@ extern "C" int iff_vit_create(const iff_vit_desc* d, void* stream, iff_vit** out
     iff_vit* v = new iff_vit();                     // every descriptor check is above this line: nothing below returns without freeing v
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
-    IFF_REQUIRE(d->gemm_form >= 0 && d->gemm_form <= 4, "iff_vit_create: gemm_form %d is not one of 0 .. 4", d->gemm_form);
+    IFF_REQUIRE(d->gemm_form >= 0 && d->gemm_form <= 10, "iff_vit_create: gemm_form %d is not one of 0 .. 10", d->gemm_form);
     const bool split = d->precision == IFF_VIT_FP32;
     const size_t eb = split ? 4 : 2;               // bytes per weight: bf16, or fp16 hi + lo planes
     const size_t o_pw = take(D * kp * eb), o_qkv = take(L * 3 * D * D * eb), o_proj = take(L * D * D * eb), o_fc1 = take(L * F * D * eb),

@@ -423,8 +423,32 @@ __global__ void __launch_bounds__(256, 2) k_vit_gemm(const typename VT<PREC>::e*
 // address), which spreads the 16 lanes of every ds_read_b128 group over the 16 slots of a 256-byte bank row: conflict-free.
 // Tile: BN = 32 AR WN features x BM = 32 BR WM tokens over WN x WM waves, a wave 32 AR x 32 BR.  The k order of every
 // accumulator (16-deep blocks in increasing k; per block lo hi, hi lo, hi hi) is the register-staged kernel's: the same bits.
-template <int EPI, int PREC, int WN, int WM, int AR, int BR>
-__global__ void __launch_bounds__(64 * WN * WM, (WN * WM <= 4 ? 2 : 1))
+#ifndef VIT_XCD_REMAP
+#define VIT_XCD_REMAP 1
+#endif
+#ifndef VIT_ABLATE
+#define VIT_ABLATE 0          // timing-only development builds, a bit mask: 1 no epilogue, 2 no LDS reads / MFMAs, 4 no operand DMA (never shipped)
+#endif
+// Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, workgroup dispatch), each with its own L2: in launch order the
+// gx column tiles of one token tile land on gx different XCDs and every one of them fetches the token tile's operand rows again from the
+// Infinity Cache.  The workgroups that share an XCD (ids equal mod 8) take a CONTIGUOUS range of tiles instead (bijective for any
+// grid: the first total % 8 XCDs serve one tile more), token tile by token tile, so a token tile's rows are fetched into one L2 once.
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+#if VIT_XCD_REMAP
+    const int total = gx * gy, orig = blockIdx.y * gx + blockIdx.x;
+    const int xcd = orig & 7, q = total >> 3, r = total & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    ty = id / gx; tx = id - ty * gx;
+#else
+    tx = blockIdx.x; ty = blockIdx.y;
+#endif
+}
+
+// NBUF 2: the tile of step t + 1 travels while step t is multiplied (one barrier per step).  NBUF 1: one buffer, filled and then
+// multiplied (two barriers per step) -- half the LDS, so twice the workgroups per CU, and the overlap comes from THEM: the product is
+// bound by the L2 -> LDS fill and by its epilogue's stores, and workgroups in different phases keep both paths busy.
+template <int EPI, int PREC, int WN, int WM, int AR, int BR, int NBUF>
+__global__ void __launch_bounds__(64 * WN * WM, (NBUF == 1 ? (WN * WM <= 4 ? 4 : 2) : (NBUF == 2 && WN * WM <= 4 ? 2 : 1)))
 k_vit_gemm_dma(const typename VT<PREC>::e* __restrict__ X, int64_t x_lo, const typename VT<PREC>::e* __restrict__ Wt, int64_t w_lo, int64_t M,
                int N, int K, GemmEpi e) {
     typedef typename VT<PREC>::e ET;
@@ -435,12 +459,14 @@ k_vit_gemm_dma(const typename VT<PREC>::e* __restrict__ X, int64_t x_lo, const t
     constexpr int TILE = ROWS * 128;                            // bytes per buffer
     constexpr int PPW = ROWS / 8 / NW;                          // 1-KiB pieces per wave and step
     static_assert(ROWS % (8 * NW) == 0, "whole pieces per wave");
-    __shared__ __attribute__((aligned(1024))) char s_all[2 * TILE];
+    __shared__ __attribute__((aligned(1024))) char s_all[NBUF * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = (wave % WN) * (32 * AR), wm = (wave / WN) * (32 * BR);
     const int lr = lane & 31, lh = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    int tile_x, tile_y;
+    xcd_tile((int)gridDim.x, (int)gridDim.y, tile_x, tile_y);
+    const int64_t m0 = (int64_t)tile_y * BM;
+    const int n0 = tile_x * BN;
     f32x16 acc[AR][BR];
 #pragma unroll
     for (int a = 0; a < AR; ++a)
@@ -468,13 +494,40 @@ k_vit_gemm_dma(const typename VT<PREC>::e* __restrict__ X, int64_t x_lo, const t
     };
     const int sw = (lr >> 1) & 7;
     const int steps = K / KT;
-    issue(0, 0);
+    // NBUF >= 2: a ring of NBUF buffers with NBUF - 1 steps travelling.  Before step t is multiplied its own pieces must have landed:
+    // all but the (up to NBUF - 2) younger steps' -- a COUNTED wait, the raw barrier (a __syncthreads would drain the DMA queue: it
+    // fences vmcnt(0)), then step t + NBUF - 1 is requested into the buffer step t - 1 has just been read from.
+    constexpr int AHEAD = NBUF - 1;
+    if (NBUF >= 2) {
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+            if (i < steps) issue(i, i);
+    }
+    int cur = 0, nxt = AHEAD % (NBUF > 1 ? NBUF : 1);
     for (int t = 0; t < steps; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step t have landed ...
-        __syncthreads();                                       // ... everybody's have, and everybody is done reading the other buffer
-        if (t + 1 < steps) issue(t + 1, (t + 1) & 1);
-        const char* bw = s_all + (t & 1) * TILE + (wn + lr) * 128;
-        const char* bx = s_all + (t & 1) * TILE + (BN + wm + lr) * 128;
+        if (NBUF == 1) {
+            if (t) __syncthreads();                            // everybody is done reading the buffer
+            issue(t, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            const int younger = min(AHEAD - 1, steps - 1 - t);         // steps behind t that stay in flight
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // everybody's pieces of step t have landed; everybody is done reading step t - 1
+            asm volatile("" ::: "memory");                     // (the compiler may not lift this step's LDS reads over the barrier)
+#if !(VIT_ABLATE & 4)
+            if (t + AHEAD < steps) issue(t + AHEAD, nxt);
+#endif
+        }
+#if VIT_ABLATE & 2
+        if (NBUF > 1) { cur = cur + 1 == NBUF ? 0 : cur + 1; nxt = nxt + 1 == NBUF ? 0 : nxt + 1; }
+        continue;
+#endif
+        const char* bw = s_all + cur * TILE + (wn + lr) * 128;
+        const char* bx = s_all + cur * TILE + (BN + wm + lr) * 128;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             constexpr int NP = PREC ? 2 : 1;
@@ -498,69 +551,78 @@ k_vit_gemm_dma(const typename VT<PREC>::e* __restrict__ X, int64_t x_lo, const t
                     acc[a][b] = VT<PREC>::mfma(fa[0][a], fb[0][b], acc[a][b]);
                 }
         }
+        if (NBUF > 1) { cur = cur + 1 == NBUF ? 0 : cur + 1; nxt = nxt + 1 == NBUF ? 0 : nxt + 1; }
     }
+#if VIT_ABLATE & 1
+    if (acc[0][0][0] != 123456.789f) return;
+#endif
     // epilogues: the register-staged kernel's, per 64-feature half of the wave's tile (a wave's 64 features are one head) and per
     // 32-token block.  D[i = n][j = m]: the lane holds column m = lr and rows n = (reg & 3) + 8 (reg >> 2) + 4 lh
     if constexpr (PREC == 1 && (EPI == EPI_QKV || EPI == EPI_GELU)) {
         const bool by_rows = !(EPI == EPI_QKV && n0 / (N / 3) == 2);
         if (by_rows) {
             constexpr int TLD = 68;
-            static_assert(NW * 32 * TLD * 4 <= 2 * TILE, "the waves' output tiles fit the operand pool");
-            float* const tile = reinterpret_cast<float*>(s_all) + wave * 32 * TLD;
+            constexpr int TT = NW * 32 * TLD * 4 <= NBUF * TILE ? 32 : 16;      // tokens a wave turns over per pass: what the operand pool holds
+            static_assert(NW * TT * TLD * 4 <= NBUF * TILE, "the waves' output tiles fit the operand pool");
+            float* const tile = reinterpret_cast<float*>(s_all) + wave * TT * TLD;
 #pragma unroll
             for (int h = 0; h < AR / 2; ++h)
 #pragma unroll
-                for (int b = 0; b < BR; ++b) {
-                    __syncthreads();                       // the last fragments / the previous block's rows have been read
+                for (int b = 0; b < BR; ++b)
 #pragma unroll
-                    for (int a2 = 0; a2 < 2; ++a2)
+                    for (int ps = 0; ps < 32 / TT; ++ps) {
+                        __syncthreads();                       // the last fragments / the previous pass's rows have been read
+                        if (TT == 32 || (lr >> 4) == ps) {
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int a = 2 * h + a2;
-                            const int nl = 32 * a2 + 8 * g4 + 4 * lh;
-                            const float4 bi = *reinterpret_cast<const float4*>(e.bias + n0 + wn + 64 * h + nl);
-                            float v[4] = {acc[a][b][4 * g4] * e.wscale + bi.x, acc[a][b][4 * g4 + 1] * e.wscale + bi.y,
-                                          acc[a][b][4 * g4 + 2] * e.wscale + bi.z, acc[a][b][4 * g4 + 3] * e.wscale + bi.w};
+                            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                                for (int g4 = 0; g4 < 4; ++g4) {
+                                    const int a = 2 * h + a2;
+                                    const int nl = 32 * a2 + 8 * g4 + 4 * lh;
+                                    const float4 bi = *reinterpret_cast<const float4*>(e.bias + n0 + wn + 64 * h + nl);
+                                    float v[4] = {acc[a][b][4 * g4] * e.wscale + bi.x, acc[a][b][4 * g4 + 1] * e.wscale + bi.y,
+                                                  acc[a][b][4 * g4 + 2] * e.wscale + bi.z, acc[a][b][4 * g4 + 3] * e.wscale + bi.w};
+                                    if (EPI == EPI_QKV) {
+                                        const float sc = n0 < N / 3 ? e.qscale : 1.0f;
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) v[i] *= sc;
+                                    } else {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752440f));
+                                    }
+                                    *reinterpret_cast<float4*>(tile + (lr & (TT - 1)) * TLD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+                                }
+                        }
+                        __syncthreads();
+                        const int n8 = (lane & 7) * 8;
+#pragma unroll
+                        for (int it = 0; it < TT / 8; ++it) {
+                            const int row = 8 * it + (lane >> 3);
+                            const int64_t m = m0 + wm + 32 * b + TT * ps + row;
+                            if (m >= M) continue;
+                            const float4 v0 = *reinterpret_cast<const float4*>(tile + row * TLD + n8);
+                            const float4 v1 = *reinterpret_cast<const float4*>(tile + row * TLD + n8 + 4);
+                            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                            f16x8 hh8, ll8;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { _Float16 hh, ll; split_h(v[j], hh, ll); hh8[j] = hh; ll8[j] = ll; }
+                            _Float16* dst;
+                            int64_t at, lo_off;
                             if (EPI == EPI_QKV) {
-                                const float sc = n0 < N / 3 ? e.qscale : 1.0f;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] *= sc;
+                                const int D = N / 3, which = n0 / D, head = (n0 - which * D + wn + 64 * h) >> 6;
+                                const int img = (int)(m / e.T), tk = (int)(m - (int64_t)img * e.T);
+                                dst = reinterpret_cast<_Float16*>(which == 0 ? e.q : e.k);
+                                at = (((int64_t)(img * e.heads + head) * e.T + tk) << 6) + n8;
+                                lo_off = e.qk_lo;
                             } else {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752440f));
+                                dst = reinterpret_cast<_Float16*>(e.out);
+                                at = m * N + n0 + wn + 64 * h + n8;
+                                lo_off = M * (int64_t)N;
                             }
-                            *reinterpret_cast<float4*>(tile + lr * TLD + nl) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<f16x8*>(dst + at) = hh8;
+                            *reinterpret_cast<f16x8*>(dst + at + lo_off) = ll8;
                         }
-                    __syncthreads();
-                    const int n8 = (lane & 7) * 8;
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int row = 8 * it + (lane >> 3);
-                        const int64_t m = m0 + wm + 32 * b + row;
-                        if (m >= M) continue;
-                        const float4 v0 = *reinterpret_cast<const float4*>(tile + row * TLD + n8);
-                        const float4 v1 = *reinterpret_cast<const float4*>(tile + row * TLD + n8 + 4);
-                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        f16x8 hh8, ll8;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { _Float16 hh, ll; split_h(v[j], hh, ll); hh8[j] = hh; ll8[j] = ll; }
-                        _Float16* dst;
-                        int64_t at, lo_off;
-                        if (EPI == EPI_QKV) {
-                            const int D = N / 3, which = n0 / D, head = (n0 - which * D + wn + 64 * h) >> 6;
-                            const int img = (int)(m / e.T), tk = (int)(m - (int64_t)img * e.T);
-                            dst = reinterpret_cast<_Float16*>(which == 0 ? e.q : e.k);
-                            at = (((int64_t)(img * e.heads + head) * e.T + tk) << 6) + n8;
-                            lo_off = e.qk_lo;
-                        } else {
-                            dst = reinterpret_cast<_Float16*>(e.out);
-                            at = m * N + n0 + wn + 64 * h + n8;
-                            lo_off = M * (int64_t)N;
-                        }
-                        *reinterpret_cast<f16x8*>(dst + at) = hh8;
-                        *reinterpret_cast<f16x8*>(dst + at + lo_off) = ll8;
                     }
-                }
             return;
         }
     }
@@ -851,10 +913,15 @@ __global__ void __launch_bounds__(256, 2) k_vit_attention_x2(const _Float16* __r
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.0f;
+    // exp(s - mx) = exp2(s log2 e - mx log2 e): one fma (a single rounding of the argument) + the hardware exp2 (1 ulp).  The argument's
+    // rounding is 2^-24 |s log2 e|: for every term that carries weight (s - mx > -20) the probability moves by < 2e-6 relative, far
+    // inside the fp32 class; libm's expf -- an extended-precision argument reduction, ~11 instructions per value -- was a quarter of
+    // this kernel's vector instructions (144 exponentials per lane)
+    const float mxl = mx * 1.4426950408889634f;
 #pragma unroll
     for (int b = 0; b < AT_TP / 32; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { S[b][r] = expf(S[b][r] - mx); sum += S[b][r]; }
+        for (int r = 0; r < 16; ++r) { S[b][r] = __builtin_amdgcn_exp2f(fmaf(S[b][r], 1.4426950408889634f, -mxl)); sum += S[b][r]; }
     sum += __shfl_xor(sum, 32, 64);
     f32x16 O[2];
 #pragma unroll
@@ -1062,16 +1129,23 @@ inline unsigned grid1(int64_t n, int block = 256, int cap = 256 * 16) {
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-template <int EPI, int PREC, int WN, int WM, int AR, int BR>
+template <int EPI, int PREC, int WN, int WM, int AR, int BR, int NBUF>
 void gemm_dma(const typename VT<PREC>::e* X, int64_t x_lo, const typename VT<PREC>::e* W, int64_t w_lo, int64_t M, int N, int K, const GemmEpi& e,
               hipStream_t s) {
     constexpr int BN = 32 * AR * WN, BM = 32 * BR * WM;
-    hipLaunchKernelGGL((k_vit_gemm_dma<EPI, PREC, WN, WM, AR, BR>), dim3((unsigned)(N / BN), (unsigned)((M + BM - 1) / BM)), dim3(64 * WN * WM), 0, s, X,
+    hipLaunchKernelGGL((k_vit_gemm_dma<EPI, PREC, WN, WM, AR, BR, NBUF>), dim3((unsigned)(N / BN), (unsigned)((M + BM - 1) / BM)), dim3(64 * WN * WM), 0, s, X,
                        x_lo, W, w_lo, M, N, K, e);
 }
 
-// `form` (iff_vit_desc.gemm_form): 0 the product's choice; 1 the register-staged kernels only; 2-4 name one DMA tile shape for
-// every product of a large batch (A/B runs and the bit-equality test: every form returns the same bits)
+// `form` (iff_vit_desc.gemm_form) names the kernels that multiply a batch of 24 images or more; every form returns the same bits
+// (tests/test_hip_image_side.py::test_vit_gemm_forms_return_the_same_bits):
+//   0 / 10  the product's choice: 128 x 128 tiles by LDS-DMA into two buffers, 256 x 256 for the MLP's first product
+//   1       the register-staged 128 x 128 tiles (round 5's product)
+//   2       128 x 128 by DMA for every product          3  128 features x 256 tokens over eight waves
+//   4       form 3 + 256 x 256 for the MLP's first product
+//   5 / 6   forms 2 / 3 with ONE buffer and twice the workgroups per CU       7 / 8 / 9   rings of 4 / 3 / 3 buffers (128^2, 128^2, 128 x 256)
+// Measured, 32 images, image -> pose with 4 graphs in flight / one forward alone (profiles/r06_vit_gemm_forms.txt): 1: 12 490 images/s /
+// 2.60 ms; 2: 12 630 / 2.55; 4: 12 810 / 2.88; 10: 12 830 / 2.56 -- none of the shapes moves the forward by more than 4 %, see NOTES.md.
 template <int EPI, int PREC>
 hipError_t gemm(int form, const void* Xv, int64_t x_lo, const void* Wv, int64_t w_lo, int64_t M, int N, int K, const GemmEpi& e, hipStream_t s) {
     typedef typename VT<PREC>::e ET;
@@ -1082,16 +1156,29 @@ hipError_t gemm(int form, const void* Xv, int64_t x_lo, const void* Wv, int64_t 
     // from 24 images on 128-token tiles: each launch alone is 5-15 % slower, but the workgroups read 1/3 fewer operand bytes per flop
     // and with several batches in flight (the bench's four graphs) the total is 5 % faster (17 700 -> 18 700 images/s at 32 images)
     const bool wide = M >= 6144;       // (64-token tiles for the N = 384 products only: -1.7 % images/s)
+    if (form == 0) form = 10;
     if (!wide)
         hipLaunchKernelGGL((k_vit_gemm<EPI, 64, PREC>), dim3((unsigned)(N / GBN), (unsigned)((M + 63) / 64)), dim3(256), 0, s, X, x_lo, W, w_lo, M, N, K, e);
     else if (form == 1)
         hipLaunchKernelGGL((k_vit_gemm<EPI, 128, PREC>), dim3((unsigned)(N / GBN), (unsigned)((M + 127) / 128)), dim3(256), 0, s, X, x_lo, W, w_lo, M, N, K, e);
     else if (form == 4 && EPI == EPI_GELU && N % 256 == 0)
-        gemm_dma<EPI, PREC, 2, 4, 4, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
+        gemm_dma<EPI, PREC, 2, 4, 4, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
     else if (form == 3 || form == 4)
-        gemm_dma<EPI, PREC, 2, 4, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
+        gemm_dma<EPI, PREC, 2, 4, 2, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else if (form == 5)
+        gemm_dma<EPI, PREC, 2, 2, 2, 2, 1>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else if (form == 6)
+        gemm_dma<EPI, PREC, 2, 4, 2, 2, 1>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else if (form == 7)
+        gemm_dma<EPI, PREC, 2, 2, 2, 2, 4>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else if (form == 8)
+        gemm_dma<EPI, PREC, 2, 2, 2, 2, 3>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else if (form == 9)
+        gemm_dma<EPI, PREC, 2, 4, 2, 2, 3>(X, x_lo, W, w_lo, M, N, K, e, s);
+    else if (form == 10 && EPI == EPI_GELU && N % 256 == 0)
+        gemm_dma<EPI, PREC, 2, 4, 4, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
     else
-        gemm_dma<EPI, PREC, 2, 2, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
+        gemm_dma<EPI, PREC, 2, 2, 2, 2, 2>(X, x_lo, W, w_lo, M, N, K, e, s);
     return hipGetLastError();
 }
 

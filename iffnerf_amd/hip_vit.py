@@ -48,6 +48,9 @@ def _pick(sd: Dict[str, torch.Tensor], *names):
     raise RuntimeError(f"backbone state_dict has none of {names}")
 
 
+DEFAULT_GEMM_FORM = 0     # iff_vit_desc.gemm_form of the handles a served backbone builds (0: the library's choice; development scripts set others for A/B runs)
+
+
 class ViTHandle:
     """One ViT-S/14's weights on one GPU (``iff_vit``)."""
 
@@ -173,7 +176,7 @@ class _NativeForwardFeatures:
             self.close()
             self._key = key
         if grid not in self._handles:
-            self._handles[grid] = ViTHandle(self.module.state_dict(), device, grid, self.patch, precision=self.precision)
+            self._handles[grid] = ViTHandle(self.module.state_dict(), device, grid, self.patch, precision=self.precision, gemm_form=DEFAULT_GEMM_FORM)
         return self._handles[grid]
 
     MAX_TOKENS = 288          # csrc/api.hip iff_vit_create: 1 + gh * gw tokens per image at most

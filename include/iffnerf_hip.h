@@ -375,11 +375,10 @@ typedef struct iff_vit_desc {
     const float* ls2;                                 /* blocks.*.ls2.gamma */
     const float* norm_w;   const float* norm_b;       /* norm.{weight,bias} [dim] */
     int32_t precision;                                /* IFF_VIT_FP32 / IFF_VIT_BF16 below */
-    int32_t gemm_form;                                /* which kernels multiply a batch of >= 24 images (smaller batches: the 64-token
-                                                       * register-staged tiles).  0: the library's choice; 1: register-staged 128 x 128 tiles;
-                                                       * 2 / 3 / 4: tiles filled by LDS-DMA, 128 x 128 over four waves / 128 x 256 tokens over
-                                                       * eight / the latter with 256 x 256 for the MLP's first product.  Every form returns
-                                                       * the same bits (same k order per accumulator): the others exist for A/B runs and tests */
+    int32_t gemm_form;                                /* which kernels multiply a batch of >= 24 images (smaller batches: 64-token register-staged
+                                                       * tiles).  0: the library's choice (today 10); 1: register-staged 128 x 128 tiles; 2-10: operand
+                                                       * tiles by LDS-DMA in several shapes and buffer counts (csrc/vit_kernels.hip gemm()).  Every form
+                                                       * returns the same bits (one k order per accumulator): the others exist for A/B runs and tests */
 } iff_vit_desc;
 /* Arithmetic of the backbone's matrix products.  The reference runs DINOv2 in fp32 (pose_estimation/identification_module.py:137-142,
  * backbone.py:12-14); IFF_VIT_FP32 is that accuracy class on the fp16 matrix cores: every operand split exactly into two fp16

@@ -8,9 +8,10 @@ dev = torch.device("cuda:0")
 net, grid, _ = create_standin_backbone(seed=0)
 sd = net.to(dev).state_dict()
 forms = [int(f) for f in os.environ.get("FORMS", "0").split(",")]
-for prec, form in [(p, f) for p in ("fp32", "bf16") for f in forms]:
+precs = os.environ.get("PRECS", "fp32,bf16").split(",")
+for prec, form in [(p, f) for p in precs for f in forms]:
     vit = ViTHandle(sd, dev, precision=prec, gemm_form=form)
-    for Q in ((16, 32) if form == forms[0] else (32,)):
+    for Q in ((16, 32) if form == forms[0] and not os.environ.get("ONLY32") else (32,)):
         x = torch.randn(Q, 3, 224, 224, device=dev)
         for _ in range(3): vit.forward(x)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
