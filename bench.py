@@ -407,6 +407,9 @@ def main():
     # K = 20 after W = 5 reads 14 650-14 970 poses/s, after W = 100 15 310-15 370, K = 200 after W = 20 15 370-15 450.  The timed
     # region is unchanged: exactly K steps between two barriers; `config.settle_steps` says how many untimed steps came before W.
     settle = max(0, args.settle - args.warmup)
+    # the `value_without_settle` pass below runs W + K steps of its own before the settling: they count as settling, so that `value` is
+    # timed after the same number of untimed steps (--settle in all) as in the rounds before that pass existed
+    settle_after_cold = max(0, settle - (args.warmup + args.steps)) if settle > 0 else 0
     # (the driver's literal protocol first -- W warm-up steps, K timed steps, nothing else before them -- reported as
     # `value_without_settle` so the round-over-round series stays like-for-like)
     dt_cold = None
@@ -417,7 +420,7 @@ def main():
         run_steps(args.warmup, args.steps)
         barrier()
         dt_cold = time.perf_counter() - t0
-    run_steps(0, settle)
+    run_steps(0, settle_after_cold)
     barrier()
     run_steps(settle, args.warmup)
     barrier()
@@ -481,7 +484,7 @@ def main():
         }
         if dt_cold is not None:
             result["value_without_settle"] = round(queries_per_step * args.steps / dt_cold, 3)
-            result["value_note"] = ("`value`: K steps timed after %d untimed settling steps + the W warm-up steps (steady clocks); "
+            result["value_note"] = ("`value`: K steps timed after %d untimed settling steps (the W + K steps of the `value_without_settle` pass among them) + the W warm-up steps (steady clocks); "
                                     "`value_without_settle`: the same K steps timed right after W warm-up steps only, the protocol of rounds 1-3" % settle)
         if sharded:      # what the process group itself reports (the collectives really ran over this many ranks of this backend)
             result["config"]["rccl_world_size"] = dist.get_world_size()

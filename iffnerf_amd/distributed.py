@@ -53,10 +53,15 @@ def _all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+TRACE = None     # tests set a list here: every all_gather_into then appends (bytes per rank, shape) in HOST ISSUE ORDER (the skewed schedule's check)
+
+
 def all_gather_into(out: torch.Tensor, src: torch.Tensor, group=None) -> None:
     """``out`` [world, *src.shape] <- every rank's ``src``, in rank order.  With the ``nccl`` (= RCCL) backend this is one
     ``all_gather_into_tensor`` on device memory.  With ``gloo`` and device tensors (rehearsing several ranks on ONE GPU,
     where RCCL refuses two ranks per device) the message is staged through host memory; without a process group it is a copy."""
+    if TRACE is not None:
+        TRACE.append((src.numel() * src.element_size(), tuple(src.shape)))
     if not (dist.is_available() and dist.is_initialized()):
         out.copy_(src[None])
         return

@@ -139,30 +139,32 @@ def test_rccl_rehearsal_keeps_the_single_graph_rate():
     import json
     import socket
     rates = {}
-    # (alternating, two runs of each form, best of two against best of two: a box drifts by a few per cent within a minute)
-    for name, extra in (("single_graph", []), ("sharded_ws1", ["--force-sharded"]), ("single_graph_again", []), ("sharded_ws1_again", ["--force-sharded"])):
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "120", "--warmup", "15", "--batch", "16", "--no-cpu-baseline",
-                            "--no-instrument", *extra], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-        line = json.loads(r.stdout.strip().splitlines()[-1])
-        rates[name] = line["value"]
-        if extra:
-            assert line["config"]["rccl_world_size"] == 1 and line["config"]["collective_backend"] == "nccl"
-            rates["collective_us"] = line["config"]["collective_us"]
-    base = max(rates["single_graph"], rates["single_graph_again"])
-    rates["ratio"] = max(rates["sharded_ws1"], rates["sharded_ws1_again"]) / base
+    # (alternating, three runs of each form, best of three against best of three: a box drifts by a few per cent within a minute)
+    for rep in range(3):
+        for name, extra in ((f"single_graph_{rep}", []), (f"sharded_ws1_{rep}", ["--force-sharded"])):
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "120", "--warmup", "15", "--batch", "16", "--no-cpu-baseline",
+                                "--no-instrument", *extra], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            rates[name] = line["value"]
+            if extra:
+                assert line["config"]["rccl_world_size"] == 1 and line["config"]["collective_backend"] == "nccl"
+                rates["collective_us"] = line["config"]["collective_us"]
+    base = max(rates[f"single_graph_{rep}"] for rep in range(3))
+    rates["ratio"] = max(rates[f"sharded_ws1_{rep}"] for rep in range(3)) / base
+    rates["ratio_of_medians"] = sorted(rates[f"sharded_ws1_{rep}"] for rep in range(3))[1] / sorted(rates[f"single_graph_{rep}"] for rep in range(3))[1]
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "rccl_rehearsal.json"), "w") as fh:
             json.dump(rates, fh, indent=1)
     except OSError:
         pass
-    # measured 0.97-1.01 on a quiet box; two IDENTICAL runs of one form have been seen 7 % apart within the minute this test takes
-    # (15 076 and 14 067 poses/s, ratio 0.91 that time), so the bar is where a real cost of the host-side exchange would show
-    # (a serialised step is 0.5), not where the box's drift does
-    assert rates["ratio"] >= 0.85, rates
+    # measured 0.97-1.01 on a quiet box.  Best of three interleaved runs against best of three takes the box's drift out (two identical
+    # runs have been seen 7 % apart within a minute): a host-side exchange that costs throughput shows in the BEST sharded run too
+    # (a serialised step is 0.5), so the bar sits at 0.93
+    assert rates["ratio"] >= 0.93, rates
 
 
 def test_large_ray_sets_keep_the_invariants(dev):
@@ -225,20 +227,20 @@ def test_batched_cold_queries_sharded_over_emulated_ranks_equal_one_gpu(pipe, de
     assert torch.equal(a[2], b[1]) and torch.equal(a[0], b[0])
 
 
-_GLOO_2RANKS = r"""
+_GLOO_RANKS = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-rank = int(sys.argv[3])
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE="2")
-from iffnerf_amd import synthetic
+rank, WS = int(sys.argv[3]), int(sys.argv[5])
+B, M, P, k = int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]), 100
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE=str(WS))
+from iffnerf_amd import synthetic, distributed as D
 from iffnerf_amd.pipeline import PosePipeline
 from tests import util
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-dist.init_process_group("gloo")          # two ranks on ONE GPU: RCCL refuses that, gloo stages the messages through the host
+dist.init_process_group("gloo")          # several ranks on ONE GPU: RCCL refuses that, gloo stages the messages through the host
 pipe = PosePipeline.from_checkpoints(util.ckpt("small"), synthetic.make_id_weights(seed=99), dev, model_up=(0.1, 0.2, 0.9))
-B, M, P, k = 2, 64, 75, 100
-tok_all = torch.stack([synthetic.make_tokens(M, 384, seed=40 + q) for q in range(2 * B)]).to(dev)
+tok_all = torch.stack([synthetic.make_tokens(M, 384, seed=40 + q) for q in range(WS * B)]).to(dev)
 mine = tok_all[rank * B:(rank + 1) * B].contiguous()
 out = {}
 out["eager"] = [t.cpu() for t in pipe.query_batch_sharded(mine, P, seed=1234, k=k)]
@@ -255,12 +257,15 @@ torch.cuda.synchronize()
 def part(i, head):
     with torch.cuda.stream(streams[i % 2]):
         slots[i % 2].replay_head() if head else slots[i % 2].replay_tail()
+D.TRACE = []
 part(0, True)
 for i in range(4):
     if i + 1 < 4:
         part(i + 1, True)
     part(i, False)
 torch.cuda.synchronize(); cq.check(); cq2.check()
+out["issue_order"], D.TRACE = D.TRACE, None
+out["msg_bytes"] = cq.msg.numel() * cq.msg.element_size()
 out["skew_slot0"] = [cq.poses.cpu().clone(), cq.val.cpu().clone(), cq.idx.cpu().clone()]        # its 4th replay (counter 4)
 out["skew_slot1"] = [cq2.poses.cpu().clone(), cq2.val.cpu().clone(), cq2.idx.cpu().clone()]     # its 2nd replay (counter 2)
 # the shared-ray-set form (BASELINE configs[3]) through the same transport
@@ -275,40 +280,52 @@ if rank == 0:
     ctr += 2
     want["skew_slot0"] = pipe.query_batch(tok_all, P, seed=1234, k=k, seed_offset=ctr)
     out["want"] = {key: [t.cpu() for t in v] for key, v in want.items()}
-    out["want_shared"] = [torch.stack([pipe.query(tok_all[q], P, seed=55, k=k)[j] for q in range(2 * B)]).cpu() for j in range(3)]
+    out["want_shared"] = [torch.stack([pipe.query(tok_all[q], P, seed=55, k=k)[j] for q in range(WS * B)]).cpu() for j in range(3)]
 torch.save(out, sys.argv[4])
 dist.barrier()
 dist.destroy_process_group()
-print("GLOO_2RANKS_OK")
+print("GLOO_RANKS_OK")
 """
 
 
-@pytest.mark.timeout(900)
-def test_two_real_ranks_on_one_gpu_over_gloo(tmp_path):
-    """Two PROCESSES (ranks 0 and 1 of a gloo group, both on the one GPU of the box) run the sharded paths end to end -- eager,
-    and as captured segments with the collectives between them: every rank's poses / top-100 are those of the one-GPU
-    batch path.  Only the transport differs from the 8-GPU run (gloo through host memory instead of RCCL over xGMI)."""
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("ws,B,M,P", [(2, 2, 64, 75), (4, 16, 256, 593)])
+def test_real_ranks_on_one_gpu_over_gloo(tmp_path, ws, B, M, P):
+    """`ws` PROCESSES (ranks of a gloo group, all on the one GPU of the box) run the sharded paths end to end -- eager, and as
+    captured segments with the collectives between them: every rank's poses / top-100 are those of the one-GPU batch path.  Only
+    the transport differs from the 8-GPU run (gloo through host memory instead of RCCL over xGMI).  (4, 16, 256, 593) is the bench's
+    own shape per rank -- 16 cold queries of 256 tokens, 16 011 rays each, and 64 images against one ray set (BASELINE configs[3]) --
+    on four ranks: the box admits six processes of ours on its GPU, this one included, so eight real ranks are not possible here.
+    The skewed schedule (the head of step i + 1 before the tail of step i, bench.py) is checked where it is decided, in the HOST's
+    issue order: the first all_gather of step i + 1 (points + folded queries: 4.6 MB per rank at the bench's shape) goes out before
+    the two small ones of step i."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = [subprocess.Popen([sys.executable, "-c", _GLOO_2RANKS, ROOT, str(port), str(r), str(tmp_path / f"r{r}.pt")],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=800) for p in procs]
+    procs = [subprocess.Popen([sys.executable, "-c", _GLOO_RANKS, ROOT, str(port), str(r), str(tmp_path / f"r{r}.pt"), str(ws), str(B), str(M), str(P)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(ws)]
+    outs = [p.communicate(timeout=1000) for p in procs]
     for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0 and "GLOO_2RANKS_OK" in so, so[-2000:] + se[-4000:]
-    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(2)]
-    B = 2
+        assert p.returncode == 0 and "GLOO_RANKS_OK" in so, so[-2000:] + se[-4000:]
+    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(ws)]
     for key in ("eager", "replay1", "replay2", "skew_slot0", "skew_slot1"):
         c2w, idx, val = r[0]["want"][key]
-        for rank in range(2):
+        for rank in range(ws):
             poses, v, i = r[rank][key]
             assert torch.equal(i, idx[rank * B:(rank + 1) * B]), (key, rank)
             torch.testing.assert_close(v, val[rank * B:(rank + 1) * B], atol=0, rtol=1e-5)
             torch.testing.assert_close(poses, c2w[rank * B:(rank + 1) * B], atol=1e-5, rtol=0)
     w_c2w, w_idx, w_val = r[0]["want_shared"]
-    for rank in range(2):
+    for rank in range(ws):
         poses, v, i = r[rank]["shared"]
         assert torch.equal(i, w_idx) and torch.equal(poses, r[0]["shared"][0])
         torch.testing.assert_close(poses, w_c2w, atol=1e-5, rtol=0)
+    # the host's issue order of the four skewed steps: msg(0) | msg(1) stats(0) cand(0) | msg(2) stats(1) cand(1) | msg(3) stats(2) cand(2) | stats(3) cand(3)
+    for rank in range(ws):
+        sizes, big = [b for b, _ in r[rank]["issue_order"]], r[rank]["msg_bytes"]
+        assert len(sizes) == 12 and sizes.count(big) == 4 and all(b < big // 8 for b in sizes if b != big), sizes
+        assert [i for i, b in enumerate(sizes) if b == big] == [0, 1, 4, 7], sizes
+    if (B, M, P) == (16, 256, 593):
+        assert 4.4e6 < r[0]["msg_bytes"] < 4.8e6
 
 
 def test_merge_kernels_equal_their_torch_statements(dev):
