@@ -213,13 +213,14 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         }
     }
     __syncthreads();
-    int lo[3];
+    int lo[3], ext[3];                                  // the box: its low corner and its side per axis, in texels
     bool fits = n_live > 0, inner = true;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         lo[ax] = __builtin_amdgcn_readfirstlane(s_box[ax]);
         const int hi = __builtin_amdgcn_readfirstlane(s_box[3 + ax]);
-        fits = fits && (hi - lo[ax] + 1 <= FP);
+        ext[ax] = hi - lo[ax] + 1;
+        fits = fits && (ext[ax] <= FP);
         inner = inner && (lo[ax] + FP <= f.grid[ax]);
     }
     // ---------------------------------------------------------------------------------------------------- the DMA of a pass
@@ -246,10 +247,18 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
         const int Ga = f.grid[pa], Gb = f.grid[pb], Gv = f.grid[pv];
         const char* pbase = reinterpret_cast<const char*>(ptab + ((size_t)lo[pb] * Ga + lo[pa]) * C + ch0);
         const char* lbase = reinterpret_cast<const char*>(ltab + (size_t)lo[pv] * C + ch0);
+        // only the fan's ACTUAL box travels: every tap of every sample lies inside it (phase 0), the rest of the FP x FP template is never
+        // read.  The pass image keeps its layout (the lanes of the texels outside the box are switched off in the DMA instructions: no
+        // bytes fetched for them); on the 640^3 unisphere workload a fan's box is 17 x 18.5 x 20 texels on average against the template's
+        // 22^3: 0.71 of the staged bytes (scripts/fan_box_stats.py)
+        const int na = ext[pa], nb = ext[pb], nv = ext[pv];
+        constexpr int NR_ = G::NR;
 #pragma unroll
-        for (int r = 0; r < G::NR; ++r) {
+        for (int r = 0; r < NR_; ++r) {
             const uint32_t e = chunk_of(r);
-            if (e & (1u << 15)) {
+            const int rx_ = (e >> 4) & 31u, ry_ = (e >> 9) & 31u;
+            const bool wanted = (e & (1u << 14)) ? ry_ < nv : (rx_ < na && ry_ < nb);
+            if ((e & (1u << 15)) && wanted) {
                 const int qq = e & 15u, rx = (e >> 4) & 31u, ry = (e >> 9) & 31u;
                 const char* src;
                 if (inner) {
@@ -286,7 +295,9 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
                 const int row = is_line ? (inner ? lv + texel : min(lv + texel, Gv - 1)) : (inner ? lb + ry : min(lb + ry, Gb - 1));
                 const int col = inner ? la + rx : min(la + rx, Ga - 1);
                 const float* src = is_line ? ltab + ((size_t)row * 16 + 4 * qq) : ptab + (((size_t)row * Ga + col) * 16 + 4 * qq);
-                dma16(src, buf + (NT * r + 64 * wave) * 4);
+                const int ea = i == 2 ? ext[1] : ext[0], eb = i == 0 ? ext[1] : ext[2], ev = i == 0 ? ext[2] : (i == 1 ? ext[1] : ext[0]);
+                if (is_line ? texel < ev : (rx < ea && ry < eb))          // the actual box only (dma_slice)
+                    dma16(src, buf + (NT * r + 64 * wave) * 4);
             }
         }
     };
@@ -523,15 +534,17 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
                     T.t[4] = *reinterpret_cast<const f32q*>(L); T.t[5] = *reinterpret_cast<const f32q*>(L + rv.d[ax_v] * SLC);
                     T.pw[0] = rv.wt[ax_b][0] * rv.wt[ax_a][0]; T.pw[1] = rv.wt[ax_b][0] * rv.wt[ax_a][1];
                     T.pw[2] = rv.wt[ax_b][1] * rv.wt[ax_a][0]; T.pw[3] = rv.wt[ax_b][1] * rv.wt[ax_a][1];
-                    T.lw[0] = rv.wt[ax_v][0]; T.lw[1] = rv.wt[ax_v][1];
+                    // the compositing weight rides on the line taps' weights, as in the four-wave kernel (fan_march_kernels.hip, phase C):
+                    // plane * (w line), one fma per channel
+                    T.lw[0] = w * rv.wt[ax_v][0]; T.lw[1] = w * rv.wt[ax_v][1];
                     T.w = w;
                 };
                 auto combine = [&](const Trip& T) {
-                    const f32q pr = lerp_plane_q(T.t[0], T.t[1], T.t[2], T.t[3], T.pw) * lerp_line_q(T.t[4], T.t[5], T.lw);
-                    accp[12 * j + 4 * i + 0] = fmaf(T.w, pr.x, accp[12 * j + 4 * i + 0]);
-                    accp[12 * j + 4 * i + 1] = fmaf(T.w, pr.y, accp[12 * j + 4 * i + 1]);
-                    accp[12 * j + 4 * i + 2] = fmaf(T.w, pr.z, accp[12 * j + 4 * i + 2]);
-                    accp[12 * j + 4 * i + 3] = fmaf(T.w, pr.w, accp[12 * j + 4 * i + 3]);
+                    const f32q pl = lerp_plane_q(T.t[0], T.t[1], T.t[2], T.t[3], T.pw), ln = lerp_line_q(T.t[4], T.t[5], T.lw);
+                    accp[12 * j + 4 * i + 0] = fmaf(pl.x, ln.x, accp[12 * j + 4 * i + 0]);
+                    accp[12 * j + 4 * i + 1] = fmaf(pl.y, ln.y, accp[12 * j + 4 * i + 1]);
+                    accp[12 * j + 4 * i + 2] = fmaf(pl.z, ln.z, accp[12 * j + 4 * i + 2]);
+                    accp[12 * j + 4 * i + 3] = fmaf(pl.w, ln.w, accp[12 * j + 4 * i + 3]);
                 };
                 Trip A, B;
                 u32q rec = {0u, 0u, 0u, 0u};
@@ -583,18 +596,18 @@ __global__ void __launch_bounds__(NT, 4) k4g_fan_march(FieldDev f, MarchArgs a) 
                 const int dv = rv.d[ax_v] * SLC;
                 const float pw[4] = {rv.wt[ax_b][0] * rv.wt[ax_a][0], rv.wt[ax_b][0] * rv.wt[ax_a][1],
                                      rv.wt[ax_b][1] * rv.wt[ax_a][0], rv.wt[ax_b][1] * rv.wt[ax_a][1]};
-                const float lw[2] = {rv.wt[ax_v][0], rv.wt[ax_v][1]};
+                const float lw[2] = {w * rv.wt[ax_v][0], w * rv.wt[ax_v][1]};        // (the compositing weight on the line taps: see above)
 #pragma unroll
                 for (int jj = 0; jj < QPP; ++jj) {         // quarter c + 4 j of the 192-B texel, j = QPP js + jj
                     const int j = QPP * js + jj;
                     const f32q tnw = *reinterpret_cast<const f32q*>(P + 16 * jj), tne = *reinterpret_cast<const f32q*>(P + 16 * jj + da);
                     const f32q tsw = *reinterpret_cast<const f32q*>(P + 16 * jj + db), tse = *reinterpret_cast<const f32q*>(P + 16 * jj + db + da);
                     const f32q ll = *reinterpret_cast<const f32q*>(L + 16 * jj), lh = *reinterpret_cast<const f32q*>(L + 16 * jj + dv);
-                    const f32q pr = lerp_plane_q(tnw, tne, tsw, tse, pw) * lerp_line_q(ll, lh, lw);
-                    accp[12 * j + 4 * i + 0] = fmaf(w, pr.x, accp[12 * j + 4 * i + 0]);
-                    accp[12 * j + 4 * i + 1] = fmaf(w, pr.y, accp[12 * j + 4 * i + 1]);
-                    accp[12 * j + 4 * i + 2] = fmaf(w, pr.z, accp[12 * j + 4 * i + 2]);
-                    accp[12 * j + 4 * i + 3] = fmaf(w, pr.w, accp[12 * j + 4 * i + 3]);
+                    const f32q pl = lerp_plane_q(tnw, tne, tsw, tse, pw), ln = lerp_line_q(ll, lh, lw);
+                    accp[12 * j + 4 * i + 0] = fmaf(pl.x, ln.x, accp[12 * j + 4 * i + 0]);
+                    accp[12 * j + 4 * i + 1] = fmaf(pl.y, ln.y, accp[12 * j + 4 * i + 1]);
+                    accp[12 * j + 4 * i + 2] = fmaf(pl.z, ln.z, accp[12 * j + 4 * i + 2]);
+                    accp[12 * j + 4 * i + 3] = fmaf(pl.w, ln.w, accp[12 * j + 4 * i + 3]);
                 }
             }
             }
