@@ -394,6 +394,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
     }
     STAMP(5);
     FAN_EXIT(5);
+    const int gr = gg;          // (the ray a group serves in phases C / D: a tile-level order by shaded count was tried, NOTES.md)
     if (!live) shmask = 0u;
     const bool any = shmask != 0u;
     const unsigned mymask = shmask & (h ? 0xAAAAAu : 0x55555u);       // this sub-group's shaded samples
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) s_A[(48 * i + 16 * j + 4 * c + e4) * DLD + g] = accp[12 * j + 4 * i + e4];
+                for (int e4 = 0; e4 < 4; ++e4) s_A[(48 * i + 16 * j + 4 * c + e4) * DLD + gr] = accp[12 * j + 4 * i + e4];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -554,7 +555,7 @@ __global__ void __launch_bounds__(NT, FAN_WAVES) k4f_fan_march(FieldDev f, March
         const float* pp = s_pool + ry * 32 + o;
         s_feat[ry * 28 + o] = (pp[0] + pp[32 * 32]) + (pp[2 * 32 * 32] + pp[3 * 32 * 32]);
     }
-    if (h == 0 && c == 0 && grp_on) s_feat[g * 28 + 27] = any ? 1.0f : 0.0f;
+    if (h == 0 && c == 0 && grp_on) s_feat[gr * 28 + 27] = any ? 1.0f : 0.0f;
     if (MODE == 3 && tid < 5 * 28) s_feat[FR * 28 + tid] = 0.0f;             // rows 27..31 of the matrix operand
     STAMP(13);
     FAN_EXIT(13);
