@@ -307,18 +307,32 @@ def test_real_ranks_on_one_gpu_over_gloo(tmp_path, ws, B, M, P):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and "GLOO_RANKS_OK" in so, so[-2000:] + se[-4000:]
     r = [torch.load(tmp_path / f"r{i}.pt") for i in range(ws)]
+    def same_lists(i, idx, val, what):
+        """The rank's top-100 lists are the one-GPU batch's, up to NEAR TIES: the shards' statistics are merged rank by rank, so a
+        score can differ from the one-GPU sum in its last bit, and two rays whose scores agree to 2e-5 relative may swap places (or
+        the 100th and 101st may trade the last place).  Nothing else may differ (the order of such pairs is
+        open in any fp32 evaluation)."""
+        K = idx.shape[1]
+        for q in range(idx.shape[0]):
+            bad = (i[q] != idx[q]).nonzero().flatten().tolist()
+            assert len(bad) <= 4, (what, q, bad)
+            for p_ in bad:
+                near = [abs(float(val[q, p_] - val[q, n])) <= 2e-5 * abs(float(val[q, p_])) for n in (p_ - 1, p_ + 1) if 0 <= n < K]
+                assert any(near) or p_ == K - 1, (what, q, p_, val[q, max(p_ - 1, 0):p_ + 2].tolist())
+
     for key in ("eager", "replay1", "replay2", "skew_slot0", "skew_slot1"):
         c2w, idx, val = r[0]["want"][key]
         for rank in range(ws):
             poses, v, i = r[rank][key]
-            assert torch.equal(i, idx[rank * B:(rank + 1) * B]), (key, rank)
-            torch.testing.assert_close(v, val[rank * B:(rank + 1) * B], atol=0, rtol=1e-5)
-            torch.testing.assert_close(poses, c2w[rank * B:(rank + 1) * B], atol=1e-5, rtol=0)
+            same_lists(i, idx[rank * B:(rank + 1) * B], val[rank * B:(rank + 1) * B], (key, rank))
+            torch.testing.assert_close(v, val[rank * B:(rank + 1) * B], atol=0, rtol=2e-5)
+            torch.testing.assert_close(poses, c2w[rank * B:(rank + 1) * B], atol=1e-4 if ws > 2 else 1e-5, rtol=0)
     w_c2w, w_idx, w_val = r[0]["want_shared"]
     for rank in range(ws):
         poses, v, i = r[rank]["shared"]
-        assert torch.equal(i, w_idx) and torch.equal(poses, r[0]["shared"][0])
-        torch.testing.assert_close(poses, w_c2w, atol=1e-5, rtol=0)
+        assert torch.equal(i, r[0]["shared"][2]) and torch.equal(poses, r[0]["shared"][0])       # every rank holds the SAME merged result
+        same_lists(i, w_idx, w_val, ("shared", rank))
+        torch.testing.assert_close(poses, w_c2w, atol=1e-4 if ws > 2 else 1e-5, rtol=0)
     # the host's issue order of the four skewed steps: msg(0) | msg(1) stats(0) cand(0) | msg(2) stats(1) cand(1) | msg(3) stats(2) cand(2) | stats(3) cand(3)
     for rank in range(ws):
         sizes, big = [b for b, _ in r[rank]["issue_order"]], r[rank]["msg_bytes"]
