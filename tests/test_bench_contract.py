@@ -56,7 +56,7 @@ def test_defaults_and_workloads():
 
 
 def test_traffic_figure_is_keyed_on_the_kernel_sources():
-    """profiles/r05_hbm_traffic_<config>.json carries the fingerprint of the sources it was measured on and the workload; bench.py
+    """profiles/r06_hbm_traffic_<config>.json carries the fingerprint of the sources it was measured on and the workload; bench.py
     and the summariser compute the fingerprint the same way (bench.py reports `roofline.traffic` / `frac_hbm_counters` only while both
     agree -- it takes the newest rNN file of its --config)."""
     import bench
@@ -66,12 +66,12 @@ def test_traffic_figure_is_keyed_on_the_kernel_sources():
     assert fp == summarize_pmc.source_fingerprint() and len(fp) == 16
     for cfg, march in (("lego16k", "k4f_fan_march<3>"), ("truck32k", "k4f_fan_march<3>"), ("bicycle64k", "k4g_fan_march<22, 3, 3>"),
                        ("lego_b64", "k4f_fan_march<3>"), ("lego540k", "k4f_fan_march<3>")):
-        j = json.load(open(os.path.join(ROOT, "profiles", f"r05_hbm_traffic_{cfg}.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", f"r06_hbm_traffic_{cfg}.json")))
         assert j["config"] == cfg and len(j["source_sha16"]) == 16
         for k in ("k5_trunk_h<1, 1, 2>", march):
             assert j["kernels"][k]["hbm_bytes_per_launch"] > 0 and j["kernels"][k]["valu_wave_insts"] > 0, (cfg, k)
         # the committed counters belong to the kernel sources in the tree: the driver's bench line can carry them
-        assert j["source_sha16"] == fp, f"profiles/r05_hbm_traffic_{cfg}.json was collected on other kernel sources: re-run scripts/gpu_profile.sh"
+        assert j["source_sha16"] == fp, f"profiles/r06_hbm_traffic_{cfg}.json was collected on other kernel sources: re-run scripts/gpu_profile.sh"
 
 
 def test_roofline_object_states_both_hbm_readings():
