@@ -64,6 +64,11 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.iff_token_assemble_compact(None, 2, 33, 16, 384, None, 0.1, None, None, None, None, None, None) != 0 and b"bad shape" in L.iff_last_error()
     assert L.iff_token_assemble_compact(None, 0, 16, 16, 384, None, 0.1, None, None, None, None, None, None) == 0
     assert L.iff_logits_from_cache_rows(None, None, 10, None, 256, None, 1.0, None, None, None, None, 0, None) != 0 and b"row counts" in L.iff_last_error()
+    # ... and neither is "one 256-row block per image" (only the Python wrapper used to check it)
+    counts = (ctypes.c_int32 * 2)(100, 100)
+    for m in (100, 300, 0):
+        assert L.iff_logits_from_cache_rows(None, None, 10, None, m, ctypes.cast(counts, ctypes.c_void_p), 1.0, None, None, None, None, 0, None) != 0
+        assert b"256-row token blocks" in L.iff_last_error(), L.iff_last_error()
     assert L.iff_attn_colsum_rows(None, 2, 256, 10, None, None, None, 0, None, None) != 0 and b"null" in L.iff_last_error()
     assert L.iff_attn_colsum_rows(None, 2, 9000, 10, None, None, None, 0, None, None) != 0 and b"bad shape" in L.iff_last_error()
     assert L.iff_attn_colsum_rows(None, 0, 256, 10, None, None, None, 0, None, None) == 0

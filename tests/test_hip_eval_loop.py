@@ -159,6 +159,56 @@ def test_ray_session_follows_rays_and_weights(dev, monkeypatch):
     assert twin._net is None and twin._ray_session is None
     c = twin.test_image(obs[..., :3], obs[..., 3], ro, rd, rc)[2]
     assert torch.equal(b, c)
+    # writes torch's version counter does not see.  A `.data` swap moves the storage: noticed through the key's address
+    s4 = mod.ray_session(ro, rd, rc)
+    rc.data = rc.data.clone()
+    assert mod.ray_session(ro, rd, rc) is not s4
+    # ... a write into the SAME storage behind torch's back (a ctypes kernel, a hipGraph replay into static buffers) is not: the caller says so
+    new = rc.flip(0).contiguous()
+    want = mod.test_image(obs[..., :3], obs[..., 3], ro, rd, new)[2].clone()         # the scores of the colours about to be written
+    s5 = mod.ray_session(ro, rd, rc)
+    v = rc._version
+    rc.untyped_storage().copy_(new.untyped_storage())                                # storage-level copy: `rc`'s version counter does not move
+    torch.cuda.synchronize()
+    if rc._version == v:                                                             # (where a torch does bump it, the key catches the write by itself)
+        assert mod.ray_session(ro, rd, rc) is s5                                     # stale by construction ...
+        mod.invalidate_ray_session()                                                 # ... until the writer says what it did
+    got = mod.test_image(obs[..., :3], obs[..., 3], ro, rd, rc)[2]
+    assert mod._ray_session is not s5 and torch.equal(got, want)
+
+
+def test_eval_loop_recovers_from_a_call_that_died_between_submit_and_collect(dev, monkeypatch):
+    """A captured batch that was submitted and never collected (an exception mid-loop: ADVICE round 5) must not leak into the next call:
+    its slot is drained on entry, and the next call's records are its own."""
+    import iffnerf_amd.pose_estimation.test as pt
+    mod = _module(dev, monkeypatch)
+    ro, rd, rc = _rays(dev)
+    up = torch.tensor([0.1, 0.2, 0.9], device=dev)
+    monkeypatch.setattr(pt, "EVAL_BATCH", 4)
+    ds = _dataset(9, 120, 160, 4, seed=77)
+    good = pt.test_pose_estimation(ds, mod, ro, rd, rc, up)[0]
+    real = pt.CapturedEvalBatch.collect
+    calls = {"n": 0}
+
+    def dying(self):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise RuntimeError("host-side failure between submit and collect")
+        return real(self)
+
+    with monkeypatch.context() as m:
+        m.setattr(pt.CapturedEvalBatch, "collect", dying)
+        with pytest.raises(RuntimeError, match="between submit and collect"):
+            pt.test_pose_estimation(ds, mod, ro, rd, rc, up)
+    slots = next(iter(mod._ray_session.graphs.values()))
+    assert any(s.pending is not None for s in slots)                    # the dead call left a batch behind ...
+    smaller = _dataset(5, 120, 160, 4, seed=78)                         # ... whose indices would not even fit the next dataset
+    again = pt.test_pose_estimation(smaller, mod, ro, rd, rc, up)[0]
+    assert len(again) == 5 and all(s.pending is None for s in slots)
+    with monkeypatch.context() as m:
+        m.setattr(pt, "_batchable", lambda *a, **k: False)
+        assert again == pt.test_pose_estimation(smaller, mod, ro, rd, rc, up)[0]
+    assert pt.test_pose_estimation(ds, mod, ro, rd, rc, up)[0] == good
 
 
 def test_rgba_resize_equals_composite_then_resize(dev):
