@@ -513,7 +513,7 @@ def main():
             dr["note"] = ("iffnerf_amd.install(); explore_model(model, gen_points) once, then test_pose_estimation(dataset, id_module, rays_ori, "
                           "rays_dirs, rays_rgb, model_up) as train_eval_pose_est.py:131-149 calls it, on synthetic 800x800 RGBA queries: images per "
                           "second of the SECOND call (the first also builds the encoder cache and captures the batch graphs: first_call_ms).  "
-                          "Batches of 32 images (540 000 rays: 17) as captured hipGraphs on two alternating streams, one device->host read per "
+                          "Batches of 32 images (540 000 rays: 17) as captured hipGraphs on four alternating streams (a tail batch padded with copies of its last image), one device->host read per "
                           "batch; results bit-identical to the image-by-image route (tests/test_hip_eval_loop.py).  Backbone: DINOv2 ViT-S/14's "
                           "architecture with seeded stand-in weights through iff_vit_forward in the fp32 class.  *_object_mask: the same calls on images "
                           "whose alpha is a disc over a third of the image instead of noise that keeps all 256 tokens: about half the tokens are "

@@ -10,8 +10,8 @@ serves the images in BATCHES through one set of launches per batch -- composite 
 (``iff_image_resize_crop_rgba``), DINOv2's forward (``iff_vit_forward``), token assembly, folded query projection, logits against
 the ray encoder's cached output (``iff_ray_cache_build`` once per (weights, ray set), ``iff_logits_from_cache`` per batch), softmax
 / column sums / top-100, the closed-form pose (``iff_pose_from_topk_batched``) and the error metrics (``iff_pose_errors``) -- with
-full batches replayed as captured hipGraphs on two alternating streams (the resize launches stay outside the graph and read the
-batch where the dataset holds it) and ONE device->host read per batch.  Every number equals,
+batches replayed as captured hipGraphs on four alternating streams (the resize launches stay outside the graph and read the
+batch where the dataset holds it; a dataset's tail is padded with copies of its last image) and ONE device->host read per batch.  Every number equals,
 bit for bit, what the image-by-image route below returns (tests/test_hip_eval_loop.py): both run the same kernels, whose per-row
 arithmetic does not depend on the batch.  Image by image is the route of everything a batch cannot serve: an arbitrary backbone
 module (``IdentificationModule.serves_batches``), replaced preprocessing, the iNeRF refinement of reference :196-211
@@ -32,10 +32,12 @@ from .errors import compute_angular_error, compute_translation_error  # noqa: F4
 INERF_ITERS = 800      # reference test.py:204
 INERF_BATCH = 1024     # pose_estimation's default batch_size (inerf/estimate_pose_inerf.py:31), which test.py:196-209 leaves alone
 EVAL_BATCH = 32        # images per batch of the batched route (one captured hipGraph per full batch)
-EVAL_SLOTS = 2         # captured batches in flight, each on its own stream (the chip is full at two: bench.py, image -> pose)
+EVAL_SLOTS = 4         # captured batches in flight, each on its own stream.  Same-box medians of five calls, images/s at 2 -> 4 slots
+#                        (scripts/time_dropin_slots.py): 128 images 10 060-10 180 -> 10 900-10 990; 200 images (six batches + a padded tail
+#                        of eight) 7 230-8 950 -> 10 140-10 170; 540 000 rays, 68 / 136 images 2 026 / 1 888 -> 2 154 / 2 198
 LOGITS_BUDGET_BYTES = 9 << 30     # a batch's [B * 256, N] fp32 logits stay below this (540 000 rays: 17 images per batch; measured
 #                                   images/s at 7 / 17 / 32 per batch: 1 660 / 1 830 / 1 830, scripts/time_dropin_540k.py) and below
-#                                   an eighth of the HBM that is free when the graphs are made (two slots, each a graph pool + its
+#                                   a sixteenth of the HBM that is free when the graphs are made (four slots, each a graph pool + its
 #                                   warm-up's blocks: at most half of it)
 TOPK = 100             # rays_to_output of reference :90
 
@@ -129,24 +131,31 @@ class CapturedEvalBatch:
         return _eval_from_tokens(id_module, session, tokens, keep, rows, self.gt, model_up, k)
 
     def submit(self, images, gt, tag):
+        """``images`` [b,H,W,C], ``gt`` [b,4,4] with b <= B: a batch shorter than the captured shape (a dataset's tail) is padded with
+        copies of its last image -- an image's result does not depend on what else is in its batch -- and ``collect`` returns its b rows."""
+        b = images.shape[0]
         with torch.cuda.stream(self.stream):
-            if not (images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()):
+            if b < self.shape[0] or not (images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()):
                 if self.staging is None:
                     self.staging = torch.empty(self.shape, dtype=torch.float32, device=self.xin.device)
-                self.staging.copy_(images, non_blocking=True)
+                self.staging[:b].copy_(images, non_blocking=True)
+                if b < self.shape[0]:
+                    self.staging[b:].copy_(self.staging[b - 1:b].expand(self.shape[0] - b, -1, -1, -1))
                 images = self.staging
             self.fe.preprocess(images, out=(self.xin, self.alpha))
-            self.gt.copy_(gt, non_blocking=True)
+            self.gt[:b].copy_(gt, non_blocking=True)
+            if b < self.shape[0]:
+                self.gt[b:].copy_(torch.eye(4, device=self.gt.device).expand(self.shape[0] - b, 4, 4))
             self.graph.replay()
             self.host_c2w.copy_(self.c2w, non_blocking=True)
             self.host_summary.copy_(self.summary, non_blocking=True)
             self.done.record(self.stream)
-        self.pending = tag
+        self.pending = (tag, b)
 
     def collect(self):
         self.done.synchronize()
-        tag, self.pending = self.pending, None
-        return tag, self.host_c2w.clone(), self.host_summary.clone()
+        (tag, b), self.pending = self.pending, None
+        return tag, self.host_c2w[:b].clone(), self.host_summary[:b].clone()
 
 
 def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id):
@@ -154,7 +163,7 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
     device = rays_ori.device
     n, H_, W_, C_ = dataset.all_rgbs.shape
     session = id_module.ray_session(rays_ori, rays_dirs, rays_rgb)
-    budget = min(LOGITS_BUDGET_BYTES, torch.cuda.mem_get_info(device)[0] // 8) if not session.graphs else session.logits_budget
+    budget = min(LOGITS_BUDGET_BYTES, torch.cuda.mem_get_info(device)[0] // (4 * EVAL_SLOTS)) if not session.graphs else session.logits_budget
     session.logits_budget = budget                      # (the batch size of graphs that exist stands: their memory is no longer "free")
     B = max(1, min(EVAL_BATCH, budget // (256 * 4 * max(session.n_rays, 1))))
     up = tuple(float(v) for v in torch.as_tensor(model_up).detach().cpu().reshape(-1).tolist())
@@ -180,7 +189,7 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
                 s.stream.synchronize()
                 s.pending = None
             s.stream.wait_stream(cur)
-        for b in range(n_full):
+        for b in range(n_full + (1 if n_full * B < n else 0)):          # the tail goes through a captured batch too, padded (submit)
             slot = slots[b % len(slots)]
             if slot.pending is not None:
                 harvest(*slot.collect())
@@ -189,7 +198,7 @@ def _batched_route(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up, 
             if slot.pending is not None:
                 harvest(*slot.collect())
             cur.wait_stream(slot.stream)
-    if n_full * B < n:                                  # the tail batch: the same launches, eagerly
+    elif n:                                             # a dataset smaller than one batch: the same launches, eagerly
         lo = n_full * B
         imgs = dataset.all_rgbs[lo:].to(device=device, dtype=torch.float32, non_blocking=True)
         gt = _as_4x4(dataset.poses[lo:]).to(device=device, dtype=torch.float32, non_blocking=True)

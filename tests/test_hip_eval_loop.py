@@ -1,7 +1,7 @@
 """GPU: the evaluation loop behind the reference's own call signatures ("in the caller").
 
 ``test_pose_estimation(dataset, id_module, rays_ori, rays_dirs, rays_rgb, model_up)`` exactly as train_eval_pose_est.py:131-149
-calls it: batches of images through one set of launches (captured hipGraphs + an eager tail batch) must return, bit for bit, what the
+calls it: batches of images through one set of launches (captured hipGraphs, the tail batch padded) must return, bit for bit, what the
 image-by-image route (``IdentificationModule.test_image`` + pose solve + error metrics per image, reference test.py:66-247) returns.
 """
 import numpy as np
@@ -60,7 +60,7 @@ def _rays(dev):
 
 
 def test_batched_eval_loop_equals_image_by_image(dev, monkeypatch, capsys):
-    """11 RGBA images, EVAL_BATCH = 4: two captured batches on two alternating graphs, a tail batch of 3 run eagerly -- against
+    """11 RGBA images, EVAL_BATCH = 4: two captured batches on two alternating graphs, a tail batch of 3 padded to 4 through the first graph again -- against
     the same call forced image by image.  Every field of every result record is EQUAL."""
     import iffnerf_amd.pose_estimation.test as pt
     mod = _module(dev, monkeypatch)
