@@ -317,6 +317,30 @@ def test_vit_gemm_forms_return_the_same_bits(dev):
         ViTHandle(net.state_dict(), dev, gemm_form=99)
 
 
+def test_vit_dma_gemm_reproduces_itself_under_concurrency(dev):
+    """The batch-of-32 forward (operand tiles by LDS-DMA into two buffers: a read that overtook its DMA, or a refill that overtook a read,
+    would show as a rare wrong tile) 40 times on four streams at once, both precisions: every output equals the first bit for bit, and
+    the first equals the register-staged kernels'."""
+    from iffnerf_amd.hip_vit import ViTHandle
+    from iffnerf_amd.pose_estimation.backbone import create_standin_backbone
+    net, grid, C = create_standin_backbone(seed=6)
+    net = net.to(dev)
+    x = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(77)).to(dev)
+    for prec in ("fp32", "bf16"):
+        want = ViTHandle(net.state_dict(), dev, precision=prec, gemm_form=1).forward(x).clone()
+        vits = [ViTHandle(net.state_dict(), dev, precision=prec) for _ in range(4)]          # a handle owns its workspace: one per stream
+        streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        torch.cuda.synchronize(dev)
+        outs = []
+        for rep in range(10):
+            for v, st in zip(vits, streams):
+                with torch.cuda.stream(st):
+                    outs.append(v.forward(x).clone())
+        torch.cuda.synchronize(dev)
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, want)]
+        assert not bad, (prec, bad[:8], len(outs))
+
+
 def test_native_vit_small_activations(dev):
     """The fp32 class splits an operand into two fp16 pieces; for |v| < 2^-3 the low piece is an fp16 SUBNORMAL (csrc/vit_kernels.hip
     split_h).  Move every matrix product's activations there -- LayerNorm gains and biases times 2^-7, the weights that consume them
