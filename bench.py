@@ -77,8 +77,9 @@ def parse_args():
                     help="BASELINE.json workload (default: configs[1], the one the metric is quoted on)")
     ap.add_argument("--in-flight", type=int, default=4, help="steps kept in flight on separate streams")
     ap.add_argument("--batch", type=int, default=0, help="queries per step and rank (default: the workload's: lego16k 32, truck32k 16, bicycle64k 8, lego540k 2, lego_b64 64)")
-    ap.add_argument("--gemm", default="auto", choices=("auto", "bf16x3", "f16x2"),
-                    help="matrix-product arithmetic of the encoder / logits (both fp32-accurate; DESIGN.md section 4)")
+    ap.add_argument("--gemm", default="auto", choices=("auto", "bf16x3", "f16x2", "f16x1"),
+                    help="matrix-product arithmetic of the encoder / logits (auto / bf16x3 / f16x2: fp32-accurate, DESIGN.md section 4; f16x1: ONE "
+                         "fp16 product per block, a throughput class outside the reference's accuracy class -- a development measurement, never `value`'s)")
     ap.add_argument("--trunk-variant", type=int, default=0, help="work split of the fused F16X2 launch (0 = default; tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the explore_model + test_pose_estimation measurement")
@@ -286,6 +287,57 @@ def dropin_rates(ck, idw, device, gen_points, n_images, hw=800, host_dataset=Fal
                                         idm._idnet().mfma_products())}
 
 
+def fast_class_report(args, ck, idw, pipe, gen_points, device, value):
+    """IFF_GEMM_F16X1 next to the default (never part of `value`): the north star names "bf16 MFMA tiles" for the ray x patch products
+    and logits within 1e-4 of the reference -- one fp16 product per block (11 significant bits per operand, more than bf16's 8) is that
+    arithmetic at the matrix cores' full rate, and this object says what it buys and what it costs.  Throughput: this same bench
+    (`--gemm f16x1 --no-extras`, same K and W) in a child process.  Accuracy: logits, top-100 lists and poses of 16 query token sets on
+    one emitted ray set against the default arithmetic (itself within 1e-4 of the oracle at full size: tests/test_hip_fullsize.py)."""
+    import subprocess
+    import torch
+    from iffnerf_amd import synthetic, hip_identify as H
+    from iffnerf_amd.pipeline import PosePipeline
+    fast = PosePipeline.from_checkpoints(ck, idw, device, model_up=(0.0, 0.0, 1.0), gemm_mode=H.GEMM_F16X1)
+    if fast.idnet.gemm_mode != H.GEMM_F16X1:
+        return {"skipped": "the encoder does not fit fp16's range: the handle fell back to %s" % fast.idnet.gemm_description()}
+    ori, dirs, rgb = pipe.emit(gen_points, seed=4242)
+    Q = 16
+    err = lmax = t_max = r_max = t_sum = r_sum = 0.0
+    common, same_set = [], 0
+    for q in range(Q):
+        tok = synthetic.make_tokens(M_TOKENS, 384, seed=7000 + q).to(device)
+        la, lb = pipe.logits(tok, ori, dirs, rgb)[0], fast.logits(tok, ori, dirs, rgb)[0]
+        err, lmax = max(err, float((la - lb).abs().max())), max(lmax, float(la.abs().max()))
+        pa, ia, _ = pipe.identify(tok, ori, dirs, rgb, k=TOPK, materialize_map=False)
+        pb, ib, _ = fast.identify(tok, ori, dirs, rgb, k=TOPK, materialize_map=False)
+        n = len(set(ia.tolist()) & set(ib.tolist()))
+        common.append(n); same_set += int(n == TOPK)
+        dt = float((pa[:3, 3] - pb[:3, 3]).norm())
+        rot = pa[:3, :3].double() @ pb[:3, :3].double().T
+        dr = float(torch.arccos(((torch.trace(rot) - 1) / 2).clamp(-1, 1)))
+        t_max, r_max, t_sum, r_sum = max(t_max, dt), max(r_max, dr), t_sum + dt, r_sum + dr
+    del fast
+    torch.cuda.empty_cache()
+    out = {"arithmetic": "IFF_GEMM_F16X1: fp16 operands on the fp16 MFMA, ONE product per block (the default issues three), fp32 accumulate; "
+                         "everything outside the ray encoder / logits launch unchanged",
+           "accuracy_against_default": {"queries": Q, "max_abs_logit_diff": round(err, 5), "max_abs_logit": round(lmax, 2),
+                                        "top100_same_100_rays": "%d/%d" % (same_set, Q), "top100_common_rays_min": min(common),
+                                        "pose_translation_diff_max": round(t_max, 6), "pose_translation_diff_mean": round(t_sum / Q, 6),
+                                        "pose_rotation_diff_rad_max": round(r_max, 6), "pose_rotation_diff_rad_mean": round(r_sum / Q, 6)},
+           "note": "outside the north star's parity bars (logits within 1e-4, pose within 1e-4 rad / 1e-3 units): a labelled throughput class, "
+                   "never the default and never `value`"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gemm", "f16x1", "--no-extras", "--no-cpu-baseline", "--no-instrument", "--config", args.config,
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--in-flight", str(args.in_flight)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        out.update({"poses_per_s": line["value"], "ms_per_step": line["ms_per_step"], "over_value": round(line["value"] / value, 3)})
+    except Exception as e:        # the accuracy half stands on its own
+        out["poses_per_s"] = None
+        out["throughput_error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
 def dropin_roofline(n_rays, kept_rows, issued_rows, s_per_image, products):
     """The roof of the evaluation loop (never part of `value`): per image the route writes the logits of the kept token rows
     ([kept, N] fp32: iff_logits_from_cache_rows) and reads them back once for the column sums (iff_attn_colsum_rows) -- the round
@@ -343,7 +395,7 @@ def main():
     ck = synthetic.make_workload_ckpt(args.config)
     idw = synthetic.make_id_weights(seed=99)
     from iffnerf_amd import _lib, hip_identify as H
-    gemm_mode = {"auto": H.GEMM_DEFAULT, "bf16x3": H.GEMM_BF16X3, "f16x2": H.GEMM_F16X2}[args.gemm]
+    gemm_mode = {"auto": H.GEMM_DEFAULT, "bf16x3": H.GEMM_BF16X3, "f16x2": H.GEMM_F16X2, "f16x1": H.GEMM_F16X1}[args.gemm]
     pipe = PosePipeline.from_checkpoints(ck, idw, device, model_up=(0.0, 0.0, 1.0), gemm_mode=gemm_mode,
                                          trunk_variant=args.trunk_variant)
     # cold configs: rank r owns global queries r*B .. r*B+B-1; lego_b64: every rank sees the same B queries (shared rays)
@@ -525,6 +577,8 @@ def main():
                           "stops at their count on the device (iff_token_assemble_compact, iff_logits_from_cache_rows, iff_attn_colsum_rows)")
             result["dropin"] = dr
             result["dropin_poses_per_s"] = dr["this_workload"]["poses_per_s"]
+            if args.config == "lego16k" and args.gemm == "auto":
+                result["fast_class"] = fast_class_report(args, ck, idw, pipe, gen_points, device, result["value"])
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -530,7 +530,7 @@ extern "C" int iff_idnet_dims(const iff_idnet* n, int32_t* feature_c, int32_t* f
 
 extern "C" int32_t iff_idnet_gemm_mode(const iff_idnet* n) {
     if (!n) return -1;
-    if (n->dev.trunk_f16) return IFF_GEMM_F16X2;
+    if (n->dev.trunk_f16) return n->dev.trunk_f16 == 2 ? IFF_GEMM_F16X1 : IFF_GEMM_F16X2;
     return n->dev.gemm_mode == 0 ? IFF_GEMM_F32 : (n->dev.fused_trunk ? IFF_GEMM_BF16X3 : IFF_GEMM_BF16X3_LAYERED);
 }
 
@@ -572,14 +572,14 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
                     d->k_w && d->k_b, "iff_idnet_create: null weight");
     const int C = d->feature_c, Fe = d->fea, IF = d->img_fea;
     if (int rc = check_idnet_dims(C, Fe, IF)) return rc;
-    IFF_REQUIRE(d->gemm_mode >= 0 && d->gemm_mode <= 3, "iff_idnet_create: gemm_mode must be one of IFF_GEMM_* (0..3)");
+    IFF_REQUIRE(d->gemm_mode >= 0 && d->gemm_mode <= 4, "iff_idnet_create: gemm_mode must be one of IFF_GEMM_* (0..4)");
     IFF_REQUIRE(d->trunk_variant >= 0 && d->trunk_variant <= 4, "iff_idnet_create: trunk_variant must be 0 (choose) or 1..4");
     const int KQ = (IF + 15) / 16 * 16;
     const int XW = 160;                  // encoder input 141 padded to a multiple of 32 (identify_kernels.hip)
     const int QLD = C + 16;
     const int KXS = (IFF_RAY_INPUT + 15) / 16;
     const bool fused = (C == 256);
-    const bool want_f16 = fused && d->gemm_mode == IFF_GEMM_F16X2;
+    const bool want_f16 = fused && (d->gemm_mode == IFF_GEMM_F16X2 || d->gemm_mode == IFF_GEMM_F16X1);
     const IdLayout L = idnet_layout(C, Fe, IF, fused, want_f16);
     const size_t o_w1 = L.w1, o_b1 = L.b1, o_w2 = L.w2, o_b2 = L.b2, o_w3 = L.w3, o_b3 = L.b3, o_w4 = L.w4, o_b4 = L.b4, o_wk = L.wk,
                  o_bk = L.bk, o_wq = L.wq, o_bq = L.bq, o_p1 = L.p1, o_p2 = L.p2, o_p3 = L.p3, o_p4 = L.p4, o_pk = L.pk, o_wqf = L.wqf,
@@ -628,7 +628,7 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
         IFF_NET_HIP(launch_frag_order(b + o_p2, b + o_f2, C, s));
         IFF_NET_HIP(launch_frag_order(b + o_p3, b + o_f3, C + XW, s));
         v.f1 = b + o_f1; v.f2 = b + o_f2; v.f3 = b + o_f3;
-        v.fused_trunk = (d->gemm_mode == IFF_GEMM_BF16X3 || d->gemm_mode == IFF_GEMM_F16X2) ? 1 : 0;
+        v.fused_trunk = (d->gemm_mode == IFF_GEMM_BF16X3 || d->gemm_mode == IFF_GEMM_F16X2 || d->gemm_mode == IFF_GEMM_F16X1) ? 1 : 0;
     }
     if (want_f16) {
         std::vector<float> W1((size_t)C * IFF_RAY_INPUT), b1(C), W2((size_t)C * C), b2(C), W3((size_t)C * (C + IFF_RAY_INPUT)), b3(C);
@@ -642,7 +642,7 @@ extern "C" int iff_idnet_create(const iff_idnet_desc* d, void* stream, iff_idnet
             IFF_NET_HIP(launch_frag_order_h(d->l3_w, C + IFF_RAY_INPUT, 0, C, C / 16, ldexpf(1.0f, v.e_w3h), b + o_h3h, s));
             IFF_NET_HIP(launch_frag_order_h(d->l3_w, C + IFF_RAY_INPUT, C, IFF_RAY_INPUT, KXS, ldexpf(1.0f, v.e_w3x), b + o_h3x, s));
             v.h1 = b + o_h1; v.h2 = b + o_h2; v.h3h = b + o_h3h; v.h3x = b + o_h3x;
-            v.trunk_f16 = 1;
+            v.trunk_f16 = d->gemm_mode == IFF_GEMM_F16X1 ? 2 : 1;          // 2: one product per block (trunk_f16_kernels.hip, MODE + 4)
             v.trunk_variant = d->trunk_variant > 0 ? d->trunk_variant - 1 : 0;
         }
     }
@@ -1135,7 +1135,7 @@ static int validate_idnet_file(const char* path, const IdNetDev& v, size_t slab_
                     stored_is(v.h2, f16, L.h2) && stored_is(v.h3h, f16, L.h3h) && stored_is(v.h3x, f16, L.h3x);
     if (!ok) return fail(IFF_ERR_INVALID_ARGUMENT, "%s: the table offsets / slab size do not match the widths the file claims", path);
     auto small = [](int e) { return e >= -64 && e <= 64; };
-    IFF_REQUIRE(v.qf_ld == v.feature_c + 16 && (v.gemm_mode == 0 || v.gemm_mode == 1) && (v.trunk_f16 == 0 || v.trunk_f16 == 1) &&
+    IFF_REQUIRE(v.qf_ld == v.feature_c + 16 && (v.gemm_mode == 0 || v.gemm_mode == 1) && (v.trunk_f16 == 0 || v.trunk_f16 == 1 || v.trunk_f16 == 2) &&
                     (v.trunk_f16 == 0 || f16) && (v.fused_trunk == 0 || (v.fused_trunk == 1 && fused)) && v.trunk_variant >= 0 &&
                     v.trunk_variant <= 3 && small(v.e_x) && small(v.e_h1) && small(v.e_h2) && small(v.e_h3) && small(v.e_w1) &&
                     small(v.e_w2) && small(v.e_w3h) && small(v.e_w3x),

@@ -204,10 +204,12 @@ struct TrunkHArgs {
 
 template <int FG> struct WFragH { f16x8 p[FG][2]; };      // [feature group][hi, lo]
 
-template <int FG>
+// NP = products per block: 3 (hi hi + hi lo + lo hi: IFF_GEMM_F16X2, the fp32 class) or 1 (hi hi only: IFF_GEMM_F16X1, the lo planes are
+// neither loaded nor multiplied)
+template <int FG, int NP = 3>
 __device__ inline void trunk_load_w_h(WFragH<FG>& w, const uint4* __restrict__ Wf, int ks, int wave, int lane) {
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < (NP == 1 ? 1 : 2); ++pl)
 #pragma unroll
         for (int fg = 0; fg < FG; ++fg) {
             // uniform base (scalar registers, advanced by scalar adds) + one 32-bit lane offset: no vector address arithmetic
@@ -223,26 +225,30 @@ __device__ inline void trunk_load_w_h(WFragH<FG>& w, const uint4* __restrict__ W
 }
 
 // acc[fg][rg] += W(fg) * act(rg) over one 16-wide k-step: lo*hi, hi*lo, hi*hi (smallest contributions first)
-template <int FG, int RG>
+template <int FG, int RG, int NP = 3>
 __device__ inline void trunk_mfma_h(f32x16 (&acc)[FG][RG], const WFragH<FG>& w, const f16x8 (&a)[RG][2]) {
 #pragma unroll
     for (int fg = 0; fg < FG; ++fg)
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) {
-            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][1], a[rg][0], acc[fg][rg], 0, 0, 0);
-            acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][0], a[rg][1], acc[fg][rg], 0, 0, 0);
+            if (NP == 3) {
+                acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][1], a[rg][0], acc[fg][rg], 0, 0, 0);
+                acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][0], a[rg][1], acc[fg][rg], 0, 0, 0);
+            }
             acc[fg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.p[fg][0], a[rg][0], acc[fg][rg], 0, 0, 0);
         }
 }
 // the logits tile: rows = rays, columns = tokens (operands swapped)
-template <int FG, int RG>
+template <int FG, int RG, int NP = 3>
 __device__ inline void trunk_mfma_ht(f32x16 (&acc)[FG][RG], const WFragH<FG>& w, const f16x8 (&a)[RG][2]) {
 #pragma unroll
     for (int tg = 0; tg < FG; ++tg)
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) {
-            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][0], w.p[tg][1], acc[tg][rg], 0, 0, 0);
-            acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][1], w.p[tg][0], acc[tg][rg], 0, 0, 0);
+            if (NP == 3) {
+                acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][0], w.p[tg][1], acc[tg][rg], 0, 0, 0);
+                acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][1], w.p[tg][0], acc[tg][rg], 0, 0, 0);
+            }
             acc[tg][rg] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rg][0], w.p[tg][0], acc[tg][rg], 0, 0, 0);
         }
 }
@@ -327,8 +333,11 @@ __device__ __forceinline__ float2 logits_tile_epilogue(f32x16 (&acc)[RG], float 
 // MODE 0: rays -> h3 [N][256] fp32 (iff_ray_trunk).  MODE 1: rays -> logits + softmax partials (the fused per-query launch).
 // MODE 2: rays -> the h3 hi/lo planes in HBM (iff_ray_cache_build: the encoder once per resident ray set).
 // MODE 3: cached planes -> logits + softmax partials (iff_logits_from_cache: every later query batch skips the encoder).
-template <int MODE, int FG, int RG>
+// MODE_ = MODE + 4: the same launch with ONE fp16 product per block (IFF_GEMM_F16X1: 11 significant bits per operand, a third of the
+// matrix work, half the weight stream -- a throughput class that is NOT the reference's accuracy class; never the default).
+template <int MODE_, int FG, int RG>
 __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_trunk_h(TrunkHArgs a) {
+    constexpr int MODE = MODE_ & 3, NP = (MODE_ & 4) ? 1 : 3;
     constexpr bool LOGITS = MODE == 1 || MODE == 3;
     constexpr int TR = 32 * RG, NT = 64 * 8 / FG, NWAVE = 8 / FG;
     __shared__ __attribute__((aligned(16))) _Float16 S[2][TR][HSLD];
@@ -431,7 +440,7 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) v[rg][pl] = *reinterpret_cast<const f16x8*>(&S[pl][32 * rg + lr][16 * ks + 8 * lh]);
+            for (int pl = 0; pl < (NP == 1 ? 1 : 2); ++pl) v[rg][pl] = *reinterpret_cast<const f16x8*>(&S[pl][32 * rg + lr][16 * ks + 8 * lh]);
     };
     // relu(acc inv + bias) s -> hi/lo planes of this wave's 32 FG features for all TR rays
     auto write_planes = [&](const f32x16 (&acc)[FG][RG], const float* __restrict__ bias, float inv, float s) {
@@ -478,21 +487,21 @@ __global__ void __launch_bounds__(64 * 8 / FG, (FG == 1 && RG == 2) ? 4 : 2) k5_
 #pragma unroll
         for (int i = 0; i < DEPTH - 1; ++i) {
             if (i < NK) {
-                trunk_load_w_h(wa[i], WA, i, wsel, lane);
-                if (DUAL) trunk_load_w_h(wb[i], WB, i, wsel, lane);
+                trunk_load_w_h<FG, NP>(wa[i], WA, i, wsel, lane);
+                if (DUAL) trunk_load_w_h<FG, NP>(wb[i], WB, i, wsel, lane);
             }
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             if (ks + DEPTH - 1 < NK) {
-                trunk_load_w_h(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wsel, lane);
-                if (DUAL) trunk_load_w_h(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wsel, lane);
+                trunk_load_w_h<FG, NP>(wa[(ks + DEPTH - 1) % DEPTH], WA, ks + DEPTH - 1, wsel, lane);
+                if (DUAL) trunk_load_w_h<FG, NP>(wb[(ks + DEPTH - 1) % DEPTH], WB, ks + DEPTH - 1, wsel, lane);
             }
             if (AB == 2 && ks + 1 < NK) load_act(act[(ks + 1) & 1], ks + 1);
             __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them)
-            if (SWAP) trunk_mfma_ht<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
-            else trunk_mfma_h<FG, RG>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
-            if (DUAL) trunk_mfma_h<FG, RG>(accB, wb[ks % DEPTH], act[ks & (AB - 1)]);
+            if (SWAP) trunk_mfma_ht<FG, RG, NP>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
+            else trunk_mfma_h<FG, RG, NP>(accA, wa[ks % DEPTH], act[ks & (AB - 1)]);
+            if (DUAL) trunk_mfma_h<FG, RG, NP>(accB, wb[ks % DEPTH], act[ks & (AB - 1)]);
             __builtin_amdgcn_sched_barrier(0);
             if (AB == 1 && ks + 1 < NK) load_act(act[0], ks + 1);
         }
@@ -836,7 +845,12 @@ static TrunkHArgs base_args(const IdNetDev& n, const float* o, const float* d, c
 }
 
 template <int MODE>
-static hipError_t launch_variant(int variant, dim3 grid, const TrunkHArgs& a, hipStream_t s) {
+static hipError_t launch_variant(int variant, dim3 grid, const TrunkHArgs& a, hipStream_t s, bool one_product = false) {
+    if (one_product) {                   // IFF_GEMM_F16X1: the eight-wave forms only (64 rays, or 128 for the cached logits launch)
+        if (variant == 2) hipLaunchKernelGGL((k5_trunk_h<MODE + 4, 1, 4>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k5_trunk_h<MODE + 4, 1, 2>), grid, dim3(512), 0, s, a);
+        return hipGetLastError();
+    }
     if constexpr (MODE == 1 || MODE == 3) {
         if (variant == 3) {          // two tiles per workgroup, one stage apart (the cache build and the feature output keep the 8-wave form)
             const int64_t n_tiles = grid.x;
@@ -855,7 +869,7 @@ hipError_t launch_trunk_h_features(const IdNetDev& n, const float* o, const floa
     TrunkHArgs a = base_args(n, o, d, rgb, N);
     a.h3 = h3;
     const int TR = trunk_h_rays_per_wg(n.trunk_variant);
-    return launch_variant<0>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s);
+    return launch_variant<0>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), (unsigned)B), a, s, n.trunk_f16 == 2);
 }
 
 // qf [B*M][qf_ld] -> Qf planes + qscale in `ws` (layout: Qf | qscale | part), then the fused launch; `part_out` / `n_blk_out`
@@ -872,7 +886,7 @@ hipError_t launch_trunk_h_logits(const IdNetDev& n, const float* o, const float*
     a.logits = logits; a.part = part; a.Mpad = Mpad;
     const int TR = trunk_h_rays_per_wg(n.trunk_variant);
     const int64_t tiles = (N + TR - 1) / TR;
-    return launch_variant<1>(n.trunk_variant, dim3((unsigned)tiles, (unsigned)B, token_split(tiles, B, n_tb, true)), a, s);
+    return launch_variant<1>(n.trunk_variant, dim3((unsigned)tiles, (unsigned)B, token_split(tiles, B, n_tb, true)), a, s, n.trunk_f16 == 2);
 }
 
 // The per-model cache: the encoder's last hidden activation as fp16 hi/lo planes [2][N][256] (1 KB per ray),
@@ -882,7 +896,7 @@ hipError_t launch_trunk_h_cache(const IdNetDev& n, const float* o, const float* 
     TrunkHArgs a = base_args(n, o, d, rgb, N);
     a.planes = (_Float16*)planes;
     const int TR = trunk_h_rays_per_wg(n.trunk_variant);
-    return launch_variant<2>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), 1u), a, s);
+    return launch_variant<2>(n.trunk_variant, dim3((unsigned)((N + TR - 1) / TR), 1u), a, s, n.trunk_f16 == 2);
 }
 
 hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, int64_t N, const float* qf, int M, float divisor,
@@ -900,5 +914,5 @@ hipError_t launch_trunk_h_logits_cached(const IdNetDev& n, const void* planes, i
     a.rows = rows;
     const int TR = trunk_h_rays_per_wg(variant);
     const int64_t tiles = (N + TR - 1) / TR;
-    return launch_variant<3>(variant, dim3((unsigned)tiles, 1u, token_split(tiles, 1, n_tb, false)), a, s);
+    return launch_variant<3>(variant, dim3((unsigned)tiles, 1u, token_split(tiles, 1, n_tb, false)), a, s, n.trunk_f16 == 2);
 }

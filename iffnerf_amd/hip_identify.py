@@ -14,7 +14,8 @@ import torch
 from . import _lib
 from ._lib import check, dptr, fvec, stream_ptr
 
-GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_LAYERED, GEMM_F16X2 = 0, 1, 2, 3        # include/iffnerf_hip.h IFF_GEMM_*
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_LAYERED, GEMM_F16X2, GEMM_F16X1 = 0, 1, 2, 3, 4        # include/iffnerf_hip.h IFF_GEMM_*
+# (GEMM_F16X1: ONE fp16 product per block -- a throughput class outside the reference's accuracy class; opt-in only)
 GEMM_DEFAULT = GEMM_F16X2        # falls back to BF16X3 by itself when a network does not fit fp16's range
 F16_ORIGIN_BOUND = 64.0          # |ray origin| the F16X2 scale plan covers (csrc/api.hip plan_f16_scales); PosePipeline picks BF16X3 beyond
 
@@ -101,18 +102,19 @@ class IdNetHandle:
     # ------------------------------------------------------------------ bookkeeping for bench.py's roofline
     def mfma_products(self) -> int:
         """MFMA products the matrix-product mode issues per fp32-accurate product (include/iffnerf_hip.h IFF_GEMM_*)."""
-        return {GEMM_F32: 1, GEMM_BF16X3: 6, GEMM_BF16X3_LAYERED: 6, GEMM_F16X2: 3}[self.gemm_mode]
+        return {GEMM_F32: 1, GEMM_BF16X3: 6, GEMM_BF16X3_LAYERED: 6, GEMM_F16X2: 3, GEMM_F16X1: 1}[self.gemm_mode]
 
     def gemm_description(self) -> str:
         return {GEMM_F32: "fp32-input MFMA (k-ordered fmaf chain)",
                 GEMM_BF16X3: "3xBF16 split on the bf16 MFMA (6 products, fp32-accurate), fp32 accumulate",
                 GEMM_BF16X3_LAYERED: "3xBF16 split on the bf16 MFMA, one launch per layer",
                 GEMM_F16X2: "2xFP16 split on the fp16 MFMA (3 products, fp32-accurate), fp32 accumulate",
+                GEMM_F16X1: "fp16 operands on the fp16 MFMA (1 product, 11 significant bits: NOT the fp32 class), fp32 accumulate",
                 }[self.gemm_mode] + "; march and shading in fp32"
 
     def trunk_kernel_name(self) -> str:
         """Name of the fused encoder + logits kernel as rocprofv3 prints it (profiles/*.csv)."""
-        return {GEMM_F16X2: "k5_trunk_h<1, 1, 2>"}.get(self.gemm_mode, "k5_trunk<true, 1>")
+        return {GEMM_F16X2: "k5_trunk_h<1, 1, 2>", GEMM_F16X1: "k5_trunk_h<5, 1, 2>"}.get(self.gemm_mode, "k5_trunk<true, 1>")
 
     # ------------------------------------------------------------------ K5
     def ray_encode(self, o, d, rgb, want_features: bool = True, want_k: bool = False):

@@ -53,6 +53,8 @@ extern "C" {
 #define IFF_GEMM_BF16X3 1
 #define IFF_GEMM_BF16X3_LAYERED 2
 #define IFF_GEMM_F16X2  3
+#define IFF_GEMM_F16X1  4   /* ONE fp16 product per block (11 significant bits per operand): a throughput class, NOT the reference's accuracy
+                             * class (logits to ~1e-2 instead of 1e-4) -- opt-in, never a default; measured next to the default by bench.py */
 
 #define IFF_ISOCELL_DIRS 27         /* pose_estimation/sampling.py:229-234, isocell.py:6-68 (27 targets, N0=3) */
 #define IFF_RAY_FEATURES 384        /* DINOv2 ViT-S/14 width: pose_estimation/backbone.py:12-14 */

@@ -94,3 +94,7 @@ def test_roofline_object_states_both_hbm_readings():
     assert abs(r["frac"] - 1105920000 / 0.49e-3 / 8e12) < 1e-3 and abs(r["floor_ms_per_image"] - 0.1382) < 1e-3
     assert abs(r["mfma"]["frac_issued"] - 256 * 540000 * 3 * 512 / 0.49e-3 / 2.5e15) < 1e-3 and r["mfma"]["kernel"] == "iff_logits_from_cache_rows"
     assert '"roofline": dropin_roofline(' in src
+    # the one-product class is a labelled extra with its accuracy beside it, never the default arithmetic and never `value`
+    assert 'result["fast_class"] = fast_class_report(' in src and '"--gemm", "f16x1"' in src
+    from iffnerf_amd import hip_identify as H
+    assert H.GEMM_DEFAULT == H.GEMM_F16X2 and H.GEMM_F16X1 == 4
