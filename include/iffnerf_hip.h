@@ -287,8 +287,8 @@ typedef struct iff_idnet_desc {
 
 int  iff_idnet_create(const iff_idnet_desc* desc, void* stream, iff_idnet** out);
 void iff_idnet_destroy(iff_idnet* net);
-/* the IFF_GEMM_* arithmetic the handle's fused encoder / logits launch actually runs (F16X2 may have fallen back to
- * BF16X3 at create time; ray_preprocessor.py:29-39 is computed to fp32 accuracy either way) */
+/* the IFF_GEMM_* arithmetic the handle's fused encoder / logits launch actually runs (F16X2 / F16X1 may have fallen back to
+ * BF16X3 at create time; ray_preprocessor.py:29-39 is computed to fp32 accuracy in every mode but F16X1) */
 int32_t iff_idnet_gemm_mode(const iff_idnet* net);
 /* layer widths of the handle: featureC of RayPreprocessor (pose_estimation/ray_preprocessor.py:6), its output width and the
  * image-token width of MultiHeadAttention (multihead_attention.py:31-45) */
