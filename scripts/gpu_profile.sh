@@ -13,8 +13,10 @@ for cfg in "${CFGS[@]}"; do
   python3 scripts/summarize_pmc.py gpurun_out/${T}_$cfg $cfg $P/sq1 $P/sq2 $P/sq3 $P/tcc $P/tcp $P/fetch $P/write $P/grbm > gpurun_out/${T}_${cfg}_summary.txt 2>&1
   mv gpurun_out/${T}_${cfg}_hbm_traffic.json gpurun_out/${T}_hbm_traffic_$cfg.json
   mv gpurun_out/${T}_${cfg}_pmc_counters.csv gpurun_out/${T}_pmc_counters_$cfg.csv
-  cp "$(ls $P/stats/*/*kernel_stats.csv $P/stats/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/${T}_bench_kernel_stats_$cfg.csv
-  cp "$(ls $P/stats_if1/*/*kernel_stats.csv $P/stats_if1/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/${T}_bench_kernel_stats_inflight1_$cfg.csv
+  # (bench.py runs a child bench for `fast_class`: the parent's statistics file is the larger one)
+  cp "$(ls -S $P/stats/*/*kernel_stats.csv $P/stats/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/${T}_bench_kernel_stats_$cfg.csv
+  # (bench.py runs a child bench for `fast_class`: the parent's statistics file is the larger one)
+  cp "$(ls -S $P/stats_if1/*/*kernel_stats.csv $P/stats_if1/*kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/${T}_bench_kernel_stats_inflight1_$cfg.csv
   tail -12 gpurun_out/${T}_${cfg}_summary.txt | cut -c1-400
   rm -rf "$P"        # the raw traces (20 MB per config): gpurun copies back at most 64 MiB
 done
